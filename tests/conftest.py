@@ -1,0 +1,25 @@
+import json
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(HERE, "golden", name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
