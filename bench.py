@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X cuHE backend.
+
+Metric (BASELINE.json): 64K-point forward NTT/s per node (u32[32768] zero-padded
+input -> u64[65536] natural-order output over P = 2^64-2^32+1: the contract of
+the reference's ntt_{1,2,3}_64k kernels that doc/Perf_NTT.txt times), with the
+HBM roofline fraction of that transform and, as a second figure in the same
+JSON line, DHS ciphertext mul+relin/s.
+
+A "step" = one pass of the hot path over one batch of `--batch` independent
+64K-point transforms, inputs already resident in HBM.  One process per GPU
+(torch.distributed / RCCL only for the barrier + max-over-ranks timing: the
+transforms are independent, so the path shards with no data-path collective).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="64K-point transforms per step per GPU")
+    ap.add_argument("--len", type=int, default=65536, dest="length")
+    ap.add_argument("--chunk", type=int, default=0, help="transforms per launch pair (0 = library default)")
+    ap.add_argument("--no-mulrelin", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with --nproc-per-node == --gpus"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from cuhe_amd import capi                      # raises if the HIP library is missing
+    lib, ck = capi.lib, capi.check
+    ck(lib.cuhe_hip_set_device_base(local_rank))
+    if args.chunk:
+        ck(lib.cuhe_hip_set_ntt_chunk(args.chunk))
+
+    L, B = args.length, args.batch
+    # synthetic input: uniform 32-bit words, generated on the device
+    gen = torch.Generator(device=dev); gen.manual_seed(0xC0FFEE + rank)
+    src = torch.randint(-(1 << 31), (1 << 31) - 1, (B, L // 2), dtype=torch.int32, device=dev, generator=gen)
+    dst = torch.empty((B, L), dtype=torch.int64, device=dev)
+    ck(lib.cuhe_hip_ntt_prepare(L, 0))
+
+    def step():
+        ck(lib.cuhe_hip_ntt_fwd_batched(dst.data_ptr(), src.data_ptr(), L, B, L // 2, 0, None))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ntt_per_s = world * B * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel pair, timed live with hipEvents on the launch stream
+        ms1, ms2, mst = C.c_float(0), C.c_float(0), C.c_float(0)
+        iters = max(3, min(args.steps, 10))
+        ck(lib.cuhe_hip_time_ntt_fwd(dst.data_ptr(), src.data_ptr(), L, B, iters, 0, None,
+                                     C.byref(ms1), C.byref(ms2), C.byref(mst)))
+        n_tr = iters * B
+        alg_bytes = 10 * L                              # 4*(L/2) + 8*L per transform
+        pair_s = (ms1.value + ms2.value) * 1e-3
+        achieved = n_tr * alg_bytes / pair_s / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "ntt_pass1<16,0> + ntt_pass2<16,false> (one transform = one launch pair)",
+                    "algorithmic_bytes_per_transform": alg_bytes,
+                    "pass1_ms_per_batch": round(ms1.value / iters, 4), "pass2_ms_per_batch": round(ms2.value / iters, 4)}
+
+        # ---- correctness spot check against the oracle (never timed, never shipped)
+        cpu = None
+        if not args.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            xs = src[:4].cpu().numpy().view(np.uint32)
+            got = dst[:4].cpu().numpy().view(np.uint64)
+            for b in range(2):
+                assert np.array_equal(got[b], O.ntt_ext(xs[b], L)), "GPU NTT differs from the oracle"
+            # ---- CPU baseline: the oracle's O(L log L) transform on the host cores, bounded sample
+            cores = os.cpu_count() or 1
+            sample = args.cpu_sample or max(cores * 8, 64)
+            xh = np.random.default_rng(1).integers(0, 1 << 32, (sample, L // 2), dtype=np.uint32)
+            O.ntt_ext_batch(xh[:cores], L, 0)            # warm-up
+            t1 = time.perf_counter()
+            _, used = O.ntt_ext_batch(xh, L, 0)
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(sample / cdt, 1), "unit": "NTT/s", "cores": used, "kind": "port",
+                   "sample": "%d 64K-point forward transforms, oracle radix-2 NTT (u128 %% P), OpenMP over transforms, %.1f s"
+                             % (sample, cdt)}
+
+        mulrelin = None
+        if not args.no_mulrelin and world == 1:
+            mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args)
+
+        out = {
+            "metric": "64K-point fwd NTT/s (u32[32768] -> u64[65536] over P=2^64-2^32+1)",
+            "value": round(ntt_per_s, 1), "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (mod 2^64-2^32+1)", "data": "synthetic",
+            "config": {"workload": "batched 64K-point forward NTT, %d transforms per step per GPU, reference contract "
+                                   "of ntt_{1,2,3}_64k (cuhe/Base.cu:659-785)" % B,
+                       "transform_len": L, "batch_per_gpu": B, "sharding": "independent transforms per rank, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
+                                         "source": "doc/Perf_NTT.txt:14 (bundle 512)"},
+            "mul_relin": mulrelin,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def bench_mulrelin(lib, ck, torch, np, dev, args):
+    """DHS ciphertext multiply + relinearise per second on 64K-point transforms (BASELINE config 4 shape:
+    48 CRT primes < 2^24, w = 16).  NTT-domain operands -> reduced CRT-domain result, keys resident in HBM."""
+    d, p, w, mn, cut, m = 25, 2, 16, 576, 24, 65536
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
+    ck(lib.cuhe_hip_init(None, 0))
+    from cuhe_amd import capi
+    q = capi.get_params()
+    npn, L, K, W = q.numCrtPrime, q.nttLen, q.numEvalKey, lib.cuhe_hip_words_coeff(0)
+    rng = np.random.default_rng(7)
+    ek = rng.integers(0, 1 << 32, (K, q.rawLen, W), dtype=np.uint32)
+    ek[:, :, W - 1] &= 0x7FFF                        # keep below 2^(32W-17): any value works, crt reduces
+    t0 = time.perf_counter()
+    ck(lib.cuhe_hip_init_relin(ek.ctypes.data_as(C.c_void_p)))
+    init_s = time.perf_counter() - t0
+    logq = lib.cuhe_hip_log_coeff(0)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    a = torch.randint(0, 1 << 24, (npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    b = torch.randint(0, 1 << 24, (npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    na = torch.empty((npn, L), dtype=torch.int64, device=dev); nb = torch.empty_like(na); nc = torch.empty_like(na)
+    cr = torch.empty((npn, q.crtLen), dtype=torch.int32, device=dev)
+    raw = torch.zeros((q.rawLen, W), dtype=torch.int32, device=dev)
+    ck(lib.cuhe_hip_ntt(na.data_ptr(), a.data_ptr(), logq, 0, None))
+    ck(lib.cuhe_hip_ntt(nb.data_ptr(), b.data_ptr(), logq, 0, None))
+
+    def one():
+        ck(lib.cuhe_hip_ntt_mul(nc.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))      # cAnd
+        ck(lib.cuhe_hip_intt_mod(cr.data_ptr(), nc.data_ptr(), logq, 0, None))                     # relin: x2r
+        ck(lib.cuhe_hip_icrt(raw.data_ptr(), cr.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_relinearization(nc.data_ptr(), raw.data_ptr(), 0, 0, None))
+        ck(lib.cuhe_hip_intt_mod(cr.data_ptr(), nc.data_ptr(), logq, 0, None))                     # n2c
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    key_bytes = 8 * K * npn * L
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s", "ms": round(dt * 1e3, 3),
+            "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "numEvalKey": K, "nttLen": L},
+            "algorithmic_bytes": key_bytes, "achieved_GBs": round(key_bytes / dt / 1e9, 1),
+            "frac_hbm": round(key_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "key_upload_s": round(init_s, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""ctypes binding of libcuhe_hip.so (include/cuhe_hip.h).  No fallback path:
+if the HIP library is missing or fails to load this module raises ImportError."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+LIB_PATH = _build.LIB
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "cuhe_amd: %s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+lib = C.CDLL(LIB_PATH)
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "mSize", "modLen", "modLen2", "rawLen", "crtLen", "nttLen",
+        "logCoeffMax", "logCoeffMin", "logCoeffCut",
+        "depth", "modMsg", "logMsg", "wordsMsg",
+        "logRelin", "numEvalKey", "logCrtPrime", "numCrtPrime")]
+
+
+i32, u32, u64, vp, sz, lng = C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t, C.c_long
+
+# name -> (restype, argtypes); mirrors include/cuhe_hip.h one to one
+SIGNATURES = {
+    "cuhe_hip_last_error": (C.c_char_p, []),
+    "cuhe_hip_version": (C.c_char_p, []),
+    "cuhe_hip_set_parameters": (i32, [i32] * 6),
+    "cuhe_hip_reset_parameters": (i32, []),
+    "cuhe_hip_get_parameters": (i32, [C.POINTER(Params)]),
+    "cuhe_hip_num_crt_prime": (i32, [i32]),
+    "cuhe_hip_log_coeff": (i32, [i32]),
+    "cuhe_hip_words_coeff": (i32, [i32]),
+    "cuhe_hip_num_eval_key": (i32, [i32]),
+    "cuhe_hip_get_level": (i32, [i32]),
+    "cuhe_hip_multi_gpus": (i32, [i32]),
+    "cuhe_hip_num_gpus": (i32, []),
+    "cuhe_hip_set_device_base": (i32, [i32]),
+    "cuhe_hip_init": (i32, [vp, i32]),
+    "cuhe_hip_shutdown": (i32, []),
+    "cuhe_hip_get_coeff_modulus": (i32, [i32, vp, sz, C.POINTER(sz)]),
+    "cuhe_hip_get_crt_primes": (i32, [vp, i32]),
+    "cuhe_hip_reduce_kind": (i32, []),
+    "cuhe_hip_force_generic_reduce": (i32, [i32]),
+    "cuhe_hip_start_allocator": (i32, []),
+    "cuhe_hip_stop_allocator": (i32, []),
+    "cuhe_hip_malloc": (vp, [i32, sz]),
+    "cuhe_hip_free": (i32, [i32, vp]),
+    "cuhe_hip_memset_async": (i32, [i32, vp, i32, sz, vp]),
+    "cuhe_hip_memcpy_h2d": (i32, [i32, vp, vp, sz, vp]),
+    "cuhe_hip_memcpy_d2h": (i32, [i32, vp, vp, sz, vp]),
+    "cuhe_hip_memcpy_d2d": (i32, [i32, vp, vp, sz, vp]),
+    "cuhe_hip_memcpy_peer": (i32, [vp, i32, vp, i32, sz, vp]),
+    "cuhe_hip_stream_sync": (i32, [i32, vp]),
+    "cuhe_hip_crt": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_icrt": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_crt_add": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_crt_add_int": (i32, [vp, vp, C.c_uint, i32, i32, vp]),
+    "cuhe_hip_crt_add_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_crt_mul_int": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_crt_mod_switch": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_nttw": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_intt": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_intt_hold": (i32, [vp, i32, i32, vp]),
+    "cuhe_hip_intt_double_deg": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_intt_mod": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_intt_result": (vp, [i32]),
+    "cuhe_hip_ntt_mul": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt_mul_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt_add": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt_add_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_barrett": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_barrett_hold": (i32, [vp, i32, i32, vp]),
+    "cuhe_hip_ntt_one": (i32, [vp, vp, i32, vp]),
+    "cuhe_hip_nttw_one": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_intt_one": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_init_relin": (i32, [vp]),
+    "cuhe_hip_relinearization": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt_fwd_batched": (i32, [vp, vp, i32, i32, lng, i32, vp]),
+    "cuhe_hip_ntt_inv_batched": (i32, [vp, vp, i32, i32, lng, i32, i32, i32, vp]),
+    "cuhe_hip_ntt_prepare": (i32, [i32, i32]),
+    "cuhe_hip_set_ntt_chunk": (i32, [i32]),
+    "cuhe_hip_time_ntt_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp] + [C.POINTER(C.c_float)] * 3),
+    "cuhe_hip_modp_add": (i32, [vp, vp, vp, sz, i32, vp]),
+    "cuhe_hip_modp_sub": (i32, [vp, vp, vp, sz, i32, vp]),
+    "cuhe_hip_modp_mul": (i32, [vp, vp, vp, sz, i32, vp]),
+    "cuhe_hip_modp_shl": (i32, [vp, vp, i32, sz, i32, vp]),
+}
+for _n, (_r, _a) in SIGNATURES.items():
+    _f = getattr(lib, _n)
+    _f.restype = _r
+    _f.argtypes = _a
+
+
+class CuheError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        raise CuheError("cuhe_hip status %d: %s" % (status, lib.cuhe_hip_last_error().decode()))
+    return status
+
+
+def get_params():
+    q = Params()
+    check(lib.cuhe_hip_get_parameters(C.byref(q)))
+    return q

@@ -1,0 +1,837 @@
+// cuhe_hip.hip -- C ABI (include/cuhe_hip.h) of the gfx950 backend: context,
+// precomputation, launch sequencing.  Replaces the L2 "operation drivers" layer
+// of the reference (cuhe/Operations.cu, cuhe/Relinearization.cu,
+// cuhe/DeviceManager.cu, the upload half of cuhe/Base.cu) -- same entry points
+// and argument meaning, different machine mapping: every driver is ONE batched
+// launch sequence over all CRT primes, constants are HBM tables, evaluation keys
+// are device resident.
+#include "../../include/cuhe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "host_math.hpp"
+#include "ntt_kernels.cuh"
+#include "ops_kernels.cuh"
+
+using namespace cuhe;
+using cuhe::host::BigU;
+using cuhe::host::Params;
+
+namespace {
+
+// ------------------------------------------------------------------ errors
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(CUHE_EHIP, "%s failed at %s:%d : %s", #call, __FILE__, __LINE__,     \
+                        hipGetErrorString(e_));                                              \
+    } while (0)
+#define CHK(call) do { int r_ = (call); if (r_ != CUHE_OK) return r_; } while (0)
+
+// ------------------------------------------------------------------ state
+struct NttTab {
+    u64 *T1 = nullptr, *T2 = nullptr, *T2inv = nullptr, *scratch = nullptr;
+    int scratch_batch = 0;
+};
+struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0; };
+
+struct DevCtx {
+    bool ready = false;
+    NttTab ntt[3];                       // LG 14,15,16
+    // prime tables
+    u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
+    u64 *pinv = nullptr;
+    int maxW = 0;
+    std::vector<IcrtLevel> icrt;
+    // Barrett tables / scratch (cuhe/Operations.cu:193-209, Base.cu:181-223)
+    u64 *u_ntt = nullptr, *m_ntt = nullptr, *b_ntt = nullptr;
+    u32 *m_crt = nullptr, *b_src = nullptr, *b_crt = nullptr;
+    u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
+    // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
+    u64 *relin = nullptr, *ek = nullptr;
+    // allocator (cuhe/DeviceManager.cu:98-138)
+    std::multimap<size_t, void *> freeBlocks;
+    std::map<void *, size_t> allocated;
+};
+
+struct Global {
+    Params prm;
+    bool params_set = false, inited = false, relin_ready = false;
+    int ndev = 1, dev_base = 0;
+    std::vector<uint32_t> primes;
+    std::vector<BigU> coeffModulus;
+    std::vector<int32_t> modulus;
+    int reduce_kind = 0;                 // 0 generic, 1 x^n+1, 2 prime m
+    bool force_generic = false;
+    bool allocator_on = false;
+    int ntt_chunk = 0;
+    std::vector<DevCtx> dev;
+    std::mutex mu;
+} G_;
+
+inline int lg_index(int len) { return len == 16384 ? 0 : len == 32768 ? 1 : len == 65536 ? 2 : -1; }
+inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+int set_dev(int dev) {
+    if (dev < 0 || dev >= G_.ndev) return fail(CUHE_EINVAL, "device %d out of range (numGPUs=%d)", dev, G_.ndev);
+    HIPCHK(hipSetDevice(G_.dev_base + dev));
+    if ((int)G_.dev.size() < G_.ndev) G_.dev.resize(G_.ndev);
+    return CUHE_OK;
+}
+
+template <typename T>
+int upload(T **dptr, const std::vector<T> &h) {
+    HIPCHK(hipMalloc((void **)dptr, std::max<size_t>(h.size(), 1) * sizeof(T)));
+    if (!h.empty()) HIPCHK(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return CUHE_OK;
+}
+
+// ------------------------------------------------------------------ NTT tables + launch
+template <int LG>
+int make_ntt_tables(NttTab &tab) {
+    using Gm = NttGeom<LG>;
+    constexpr int L = 1 << LG, N1 = L / 64, R1 = Gm::R1, R2 = Gm::R2;
+    std::vector<u64> r(L);
+    const u64 w = host::powP(host::G, 65536 / L);                 // cuhe/Base.cu:63-70
+    r[0] = 1;
+    for (int i = 1; i < L; ++i) r[i] = host::mulP(r[i - 1], w);
+    std::vector<u64> t1((size_t)R1 * R2), t2(L), t2i(L);
+    for (int c = 0; c < R1; ++c)
+        for (int b = 0; b < R2; ++b) t1[(size_t)c * R2 + b] = r[(64L * b * c) % L];
+    const u64 linv = host::powP((u64)L, host::P - 2);             // cuhe/Base.cu:489,656,841
+    for (int j2 = 0; j2 < 64; ++j2)
+        for (int k1 = 0; k1 < N1; ++k1) {
+            const u64 v = r[((long)j2 * k1) % L];
+            t2[(size_t)j2 * N1 + k1] = v;
+            t2i[(size_t)j2 * N1 + k1] = host::mulP(v, linv);
+        }
+    CHK(upload(&tab.T1, t1));
+    CHK(upload(&tab.T2, t2));
+    CHK(upload(&tab.T2inv, t2i));
+    return CUHE_OK;
+}
+
+int ensure_ntt(int dev, int len, int batch_hint) {
+    const int li = lg_index(len);
+    if (li < 0) return fail(CUHE_EINVAL, "unsupported transform length %d (16384/32768/65536 only)", len);
+    NttTab &tab = G_.dev[dev].ntt[li];
+    if (!tab.T1) {
+        if (li == 0) CHK(make_ntt_tables<14>(tab));
+        else if (li == 1) CHK(make_ntt_tables<15>(tab));
+        else CHK(make_ntt_tables<16>(tab));
+    }
+    int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (64 << 20) / (len * 8);   // 64 MiB slab: MALL resident
+    if (chunk < 8) chunk = 8;
+    chunk = (chunk + 7) & ~7;
+    int want = std::min(chunk, (std::max(batch_hint, 1) + 7) & ~7);
+    if (tab.scratch_batch < want) {
+        if (tab.scratch) HIPCHK(hipFree(tab.scratch));
+        HIPCHK(hipMalloc((void **)&tab.scratch, (size_t)want * len * sizeof(u64)));
+        tab.scratch_batch = want;
+    }
+    return CUHE_OK;
+}
+
+template <int LG, int MODE>
+int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, long src_stride, int nb,
+                 WindowArgs wa, hipStream_t st) {
+    using Gm = NttGeom<LG>;
+    static bool attr_done[64] = {false};
+    auto kern = ntt_pass1<LG, MODE>;
+    int cur = 0;
+    HIPCHK(hipGetDevice(&cur));
+    if (!attr_done[cur & 63]) {
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)NttLds<LG>::bytes));
+        attr_done[cur & 63] = true;
+    }
+    const int tiles = 64 / Gm::NC;
+    const int grid = ((nb + 7) / 8) * 8 * tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNttThreads), NttLds<LG>::bytes, st, src, scratch, tab.T1,
+                       inv ? tab.T2inv : tab.T2, src_stride, nb, wa);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+template <int LG, bool INV>
+int launch_pass2(void *dst, const u64 *scratch, long dst_stride, int nb, int nstore, const u32 *primes,
+                 const u64 *pinv, int prime0, hipStream_t st) {
+    constexpr int N1 = (1 << LG) / 64;
+    const int tiles = N1 / kNttThreads;
+    const int grid = ((nb + 7) / 8) * 8 * tiles;
+    hipLaunchKernelGGL((ntt_pass2<LG, INV>), dim3(grid), dim3(kNttThreads), 0, st, dst, scratch, dst_stride, nb,
+                       nstore, primes, pinv, prime0);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
+struct EvTimer {                 // optional per-pass hipEvent timing (bench)
+    std::vector<hipEvent_t> ev;
+    bool on = false;
+};
+
+// one batched transform, chunked so that the pass-1 -> pass-2 slab stays cache resident
+template <int LG>
+int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
+               int prime0, WindowArgs wa, DevCtx &D, hipStream_t st, EvTimer *tm) {
+    constexpr int L = 1 << LG;
+    NttTab &tab = D.ntt[LG - 14];
+    const int chunk = tab.scratch_batch;
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = std::min(chunk, batch - b0);
+        if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
+        if (mode == kSrcU32Ext) {
+            const u32 *s = (const u32 *)src + (long)b0 * src_stride;
+            CHK((launch_pass1<LG, kSrcU32Ext>(s, tab.scratch, tab, false, src_stride, nb, wa, st)));
+        } else if (mode == kSrcWindow) {
+            WindowArgs w2 = wa; w2.wid0 += b0;
+            CHK((launch_pass1<LG, kSrcWindow>(src, tab.scratch, tab, false, 0, nb, w2, st)));
+        } else {
+            const u64 *s = (const u64 *)src + (long)b0 * src_stride;
+            CHK((launch_pass1<LG, kSrcU64Neg>(s, tab.scratch, tab, true, src_stride, nb, wa, st)));
+        }
+        if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
+        if (mode == kSrcU64Neg) {
+            u32 *d = (u32 *)dst + (long)b0 * dst_stride;
+            CHK((launch_pass2<LG, true>(d, tab.scratch, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, st)));
+        } else {
+            u64 *d = (u64 *)dst + (long)b0 * dst_stride;
+            CHK((launch_pass2<LG, false>(d, tab.scratch, dst_stride, nb, nstore, nullptr, nullptr, 0, st)));
+        }
+        if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
+    }
+    return CUHE_OK;
+}
+
+int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
+            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr) {
+    if (batch <= 0) return CUHE_OK;
+    CHK(ensure_ntt(dev, len, batch));
+    DevCtx &D = G_.dev[dev];
+    switch (len) {
+        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, st, tm);
+        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, st, tm);
+        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, st, tm);
+    }
+}
+
+// ------------------------------------------------------------------ helpers
+int need_init(int dev) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "cuhe_hip_init has not been called");
+    CHK(set_dev(dev));
+    if (!G_.dev[dev].ready) return fail(CUHE_ENOTINIT, "device %d not initialised", dev);
+    return CUHE_OK;
+}
+PrimeTab prime_tab(const DevCtx &D) { return PrimeTab{D.p, D.pinv, D.e64, D.pow32, D.maxW}; }
+
+int level_of(int logq, int *lvl, int *np, int *W) {
+    const Params &q = G_.prm;
+    *lvl = q.getLevel(logq);
+    if (*lvl >= q.depth) return fail(CUHE_EINVAL, "logq %d maps to level %d >= depth %d", logq, *lvl, q.depth);
+    *np = q.numCrtPrimeAt(*lvl);
+    *W = q.wordsCoeff(*lvl);
+    return CUHE_OK;
+}
+
+int barrett_impl(u32 *dst, const u32 *src, int lvl, int dev, hipStream_t st) {
+    const Params &q = G_.prm;
+    DevCtx &D = G_.dev[dev];
+    const int np = q.numCrtPrimeAt(lvl), n = q.modLen, L = q.nttLen, cl = q.crtLen;
+    PrimeTab pt = prime_tab(D);
+    const int kind = G_.force_generic ? 0 : G_.reduce_kind;
+    if (kind == 1) {
+        hipLaunchKernelGGL((k_reduce_special<0>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L);
+        HIPCHK(hipGetLastError());
+        return CUHE_OK;
+    }
+    if (kind == 2) {
+        hipLaunchKernelGGL((k_reduce_special<1>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L);
+        HIPCHK(hipGetLastError());
+        return CUHE_OK;
+    }
+    // generic: the sequence of cuhe/Operations.cu:460-501 with every per-prime loop batched
+    const size_t rows = (size_t)np * L;
+    const long pairs = (long)rows / 2;
+    const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
+    WindowArgs wa{0, 0, 0};
+    if (src != D.b_src) HIPCHK(hipMemcpyAsync(D.b_src, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    CHK(run_ntt(L, kSrcU32Ext, D.b_ntt, D.b_src + (n - 1), np, L, L, L, 0, wa, dev, st));            // f >> (n-1)
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, D.u_ntt, pairs);
+    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, 0, wa, dev, st));                      // u * (f>>(n-1))
+    hipLaunchKernelGGL(k_zero_rows, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_crt, n, L);
+    CHK(run_ntt(L, kSrcU32Ext, D.b_ntt, D.b_crt + n, np, L, L, L, 0, wa, dev, st));                  // q = (..)>>n
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, D.m_ntt, pairs);
+    hipLaunchKernelGGL(k_barrett_sub, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, D.b_crt, pt, n, n, L);
+    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, 0, wa, dev, st));                      // (m - x^n) * q
+    hipLaunchKernelGGL(k_barrett_sub, dim3((L + 255) / 256, np), dim3(256), 0, st, D.b_src, D.b_crt, pt, 0, L, L);
+    hipLaunchKernelGGL(k_barrett_sub_mc, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, D.m_crt, pt, n, cl, L);
+    hipLaunchKernelGGL(k_gather_rows, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, D.b_src, cl, L);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
+int init_device(int dev) {
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    const Params &q = G_.prm;
+    const int pnum = q.numCrtPrime, L = q.nttLen, n = q.modLen, cl = q.crtLen;
+    // ---- prime tables (preload_crt_p / preload_crt_invp: cuhe/Base.cu:145-160)
+    D.maxW = q.wordsCoeff(0) + 1;
+    std::vector<u32> hp(G_.primes), he(pnum), hpow((size_t)pnum * D.maxW), hinv((size_t)pnum * (pnum - 1) / 2 + 1, 0);
+    std::vector<u64> hpi(pnum);
+    for (int i = 0; i < pnum; ++i) {
+        const u32 p = hp[i];
+        hpi[i] = (u64)(((host::u128)1 << 64) / p);
+        he[i] = (u32)((((host::u128)1) << 64) % p);
+        u64 c = 1 % p;
+        for (int k = 0; k < D.maxW; ++k) { hpow[(size_t)i * D.maxW + k] = (u32)c; c = (c << 32) % p; }
+    }
+    for (int i = 1; i < pnum; ++i)                                 // cuhe/Operations.cu:91-99
+        for (int j = 0; j < i; ++j) hinv[(size_t)i * (i - 1) / 2 + j] = host::invmod32(hp[i] % hp[j], hp[j]);
+    CHK(upload(&D.p, hp)); CHK(upload(&D.pinv, hpi)); CHK(upload(&D.e64, he));
+    CHK(upload(&D.pow32, hpow)); CHK(upload(&D.invp, hinv));
+    // ---- ICRT constants for every level, all resident (cuhe/Operations.cu:107-156)
+    D.icrt.resize(q.depth);
+    for (int lvl = 0; lvl < q.depth; ++lvl) {
+        IcrtLevel &I = D.icrt[lvl];
+        I.np = pnum - lvl; I.W = q.wordsCoeff(lvl);
+        const BigU &M = G_.coeffModulus[lvl];
+        std::vector<u32> hM(I.W), hmi((size_t)I.np * I.W), hbi(I.np);
+        std::vector<double> hrp(I.np);
+        M.to_words(hM.data(), I.W);
+        for (int i = 0; i < I.np; ++i) {
+            BigU mi = M.div_small(hp[i]);
+            mi.to_words(&hmi[(size_t)i * I.W], I.W);
+            hbi[i] = host::invmod32(mi.mod_small(hp[i]), hp[i]);
+            hrp[i] = 1.0 / (double)hp[i];
+        }
+        CHK(upload(&I.M, hM)); CHK(upload(&I.mi, hmi)); CHK(upload(&I.bi, hbi)); CHK(upload(&I.rp, hrp));
+    }
+    // ---- transforms + scratch (initNtt: cuhe/Operations.cu:173-184)
+    CHK(ensure_ntt(dev, L, pnum));
+    HIPCHK(hipMalloc((void **)&D.hold, (size_t)pnum * L * sizeof(u32)));
+    // ---- Barrett (initBarrett: cuhe/Operations.cu:196-238)
+    HIPCHK(hipMalloc((void **)&D.b_src, (size_t)pnum * L * sizeof(u32)));
+    HIPCHK(hipMalloc((void **)&D.b_crt, (size_t)pnum * L * sizeof(u32)));
+    HIPCHK(hipMalloc((void **)&D.b_ntt, (size_t)pnum * L * sizeof(u64)));
+    HIPCHK(hipMalloc((void **)&D.u_ntt, (size_t)pnum * L * sizeof(u64)));
+    HIPCHK(hipMalloc((void **)&D.m_ntt, (size_t)pnum * L * sizeof(u64)));
+    std::vector<long long> u;
+    if (!host::barrett_u(G_.modulus, u)) return fail(CUHE_EINVAL, "polynomial modulus has unbounded Barrett quotient");
+    std::vector<u32> hu((size_t)pnum * cl, 0), hm((size_t)pnum * cl, 0);
+    for (int i = 0; i < pnum; ++i)
+        for (int k = 0; k < n; ++k) {
+            hu[(size_t)i * cl + k] = host::smod(u[k], hp[i]);
+            hm[(size_t)i * cl + k] = host::smod(G_.modulus[k], hp[i]);   // m - x^n: coefficient n dropped
+        }
+    CHK(upload(&D.m_crt, hm));
+    u32 *tmp = nullptr;
+    CHK(upload(&tmp, hu));
+    WindowArgs wa{0, 0, 0};
+    CHK(run_ntt(L, kSrcU32Ext, D.u_ntt, tmp, pnum, cl, L, L, 0, wa, dev, 0));
+    CHK(run_ntt(L, kSrcU32Ext, D.m_ntt, D.m_crt, pnum, cl, L, L, 0, wa, dev, 0));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(tmp));
+    D.ready = true;
+    return CUHE_OK;
+}
+
+template <int OP>
+__global__ void k_modp_test(u64 *z, const u64 *x, const u64 *y, int l, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 a = x[i];
+    if (OP == 0) z[i] = addp(canon(a), canon(y[i]));
+    else if (OP == 1) z[i] = subp(canon(a), canon(y[i]));
+    else if (OP == 2) z[i] = mulp(canon(a), canon(y[i]));
+    else {
+        // runtime shift amount: square-and-multiply on 2 (test hook only; kernels use compile-time shifts)
+        u64 r = canon(a), b = 2; int e = l % 192;
+        while (e) { if (e & 1) r = mulp(r, b); b = mulp(b, b); e >>= 1; }
+        z[i] = r;
+    }
+}
+template <int K>
+__global__ void k_shl_const(u64 *z, const u64 *x, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = (K >= 96) ? negp(shlp<(K >= 96 ? K - 96 : K)>(canon(x[i]))) : shlp<(K >= 96 ? K - 96 : K)>(canon(x[i]));
+}
+
+template <int K>
+void shl_dispatch(int l, uint64_t *z, const uint64_t *x, size_t n, hipStream_t st, bool &done) {
+    if constexpr (K < 192) {
+        if (l == K) { hipLaunchKernelGGL((k_shl_const<K>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64 *)z, (const u64 *)x, n); done = true; }
+        else shl_dispatch<K + 3>(l, z, x, n, st, done);
+    }
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char *cuhe_hip_last_error(void) { return g_err.c_str(); }
+const char *cuhe_hip_version(void) { return "cuhe_amd 0.1 (gfx950)"; }
+
+int cuhe_hip_set_parameters(int d, int p, int w, int min, int cut, int m) {
+    if (d < 1 || p < 2 || w < 0 || w > 31 || min < 1 || cut < 1 || m < 3)
+        return fail(CUHE_EINVAL, "setParameters(%d,%d,%d,%d,%d,%d): invalid", d, p, w, min, cut, m);
+    G_.prm.set(d, p, w, min, cut, m);
+    if (lg_index(G_.prm.nttLen) < 0)
+        return fail(CUHE_EINVAL, "ring degree %d needs nttLen %d (supported: 16384/32768/65536)", G_.prm.modLen, G_.prm.nttLen);
+    if (G_.prm.numCrtPrime > 103 * 4) return fail(CUHE_EINVAL, "too many CRT primes (%d)", G_.prm.numCrtPrime);
+    G_.params_set = true;
+    return CUHE_OK;
+}
+int cuhe_hip_reset_parameters(void) { G_.prm = Params(); G_.params_set = false; return CUHE_OK; }
+int cuhe_hip_get_parameters(cuhe_params_t *o) {
+    if (!o) return fail(CUHE_EINVAL, "null");
+    const Params &q = G_.prm;
+    *o = cuhe_params_t{q.mSize, q.modLen, q.modLen2, q.rawLen, q.crtLen, q.nttLen, q.logCoeffMax, q.logCoeffMin,
+                       q.logCoeffCut, q.depth, q.modMsg, q.logMsg, q.wordsMsg, q.logRelin, q.numEvalKey,
+                       q.logCrtPrime, q.numCrtPrime};
+    return CUHE_OK;
+}
+int cuhe_hip_num_crt_prime(int lvl) { return G_.prm.numCrtPrimeAt(lvl); }
+int cuhe_hip_log_coeff(int lvl) { return G_.prm.logCoeff(lvl); }
+int cuhe_hip_words_coeff(int lvl) { return G_.prm.wordsCoeff(lvl); }
+int cuhe_hip_num_eval_key(int lvl) { return G_.prm.numEvalKeyAt(lvl); }
+int cuhe_hip_get_level(int logq) { return G_.prm.getLevel(logq); }
+
+int cuhe_hip_multi_gpus(int num) {
+    int cnt = 0;
+    HIPCHK(hipGetDeviceCount(&cnt));
+    if (num < 1 || G_.dev_base + num > cnt) return fail(CUHE_EINVAL, "multiGPUs(%d): %d device(s) visible", num, cnt);
+    if (G_.inited) return fail(CUHE_EINVAL, "multiGPUs must precede initCuHE (cuhe/DeviceManager.cu:38-41)");
+    G_.ndev = num;
+    G_.dev.resize(num);
+    return CUHE_OK;
+}
+int cuhe_hip_num_gpus(void) { return G_.ndev; }
+int cuhe_hip_set_device_base(int dev) {
+    if (G_.inited) return fail(CUHE_EINVAL, "set_device_base must precede init");
+    G_.dev_base = dev;
+    return CUHE_OK;
+}
+
+int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
+    if (!G_.params_set) return fail(CUHE_EINVAL, "setParameters must precede initCuHE");
+    if (G_.inited) return fail(CUHE_EINVAL, "already initialised");
+    const Params &q = G_.prm;
+    if (modulus) {
+        if (ncoeffs != q.modLen + 1 || modulus[q.modLen] != 1)
+            return fail(CUHE_EINVAL, "modulus must be monic of degree modLen=%d", q.modLen);
+        G_.modulus.assign(modulus, modulus + ncoeffs);
+    } else {
+        G_.modulus = host::cyclotomic(q.mSize);
+        if ((int)G_.modulus.size() != q.modLen + 1) return fail(CUHE_EINVAL, "cyclotomic(%d) degree mismatch", q.mSize);
+    }
+    // which exact reduction applies
+    {
+        const int n = q.modLen;
+        bool xn1 = (G_.modulus[0] == 1), ones = true;
+        for (int i = 1; i < n; ++i) { if (G_.modulus[i] != 0) xn1 = false; }
+        for (int i = 0; i <= n; ++i) { if (G_.modulus[i] != 1) ones = false; }
+        G_.reduce_kind = xn1 ? 1 : (ones ? 2 : 0);
+    }
+    G_.primes = host::gen_crt_primes(q);                           // cuhe/Operations.cu:37-80
+    G_.coeffModulus.assign(q.depth, BigU(1));                      // cuhe/Operations.cu:81-90
+    for (int i = 0; i < q.depth; ++i)
+        for (int j = 0; j < q.numCrtPrime - i; ++j) G_.coeffModulus[i].mul_small(G_.primes[j]);
+    G_.dev.resize(G_.ndev);
+    G_.inited = true;
+    for (int dev = 0; dev < G_.ndev; ++dev) {
+        int r = init_device(dev);
+        if (r != CUHE_OK) { G_.inited = false; return r; }
+    }
+    for (int i = 0; i < G_.ndev; ++i) {                             // cuhe/CuHE.cu:42-45 peer access
+        hipSetDevice(G_.dev_base + i);
+        for (int j = 0; j < G_.ndev; ++j)
+            if (i != j) { int can = 0; hipDeviceCanAccessPeer(&can, G_.dev_base + i, G_.dev_base + j);
+                          if (can) hipDeviceEnablePeerAccess(G_.dev_base + j, 0); }
+    }
+    (void)hipGetLastError();
+    return CUHE_OK;
+}
+
+int cuhe_hip_shutdown(void) {
+    for (int d = 0; d < (int)G_.dev.size(); ++d) {
+        hipSetDevice(G_.dev_base + d);
+        DevCtx &D = G_.dev[d];
+        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch); t = NttTab(); }
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.b_ntt, D.m_crt, D.b_src, D.b_crt,
+                        D.hold, D.relin, D.ek};
+        for (void *p : ptrs) if (p) hipFree(p);
+        for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
+        for (auto &kv : D.freeBlocks) hipFree(kv.second);
+        for (auto &kv : D.allocated) hipFree(kv.first);
+        D = DevCtx();
+    }
+    G_.inited = false; G_.relin_ready = false; G_.allocator_on = false;
+    return CUHE_OK;
+}
+
+int cuhe_hip_get_coeff_modulus(int lvl, uint8_t *le, size_t cap, size_t *len) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
+    if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    const BigU &M = G_.coeffModulus[lvl];
+    size_t nb = M.w.size() * 4;
+    if (len) *len = nb;
+    if (cap < nb) return fail(CUHE_EINVAL, "buffer too small");
+    memcpy(le, M.w.data(), nb);
+    return CUHE_OK;
+}
+int cuhe_hip_get_crt_primes(uint32_t *out, int cap) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
+    if (cap < (int)G_.primes.size()) return fail(CUHE_EINVAL, "buffer too small");
+    memcpy(out, G_.primes.data(), G_.primes.size() * 4);
+    return CUHE_OK;
+}
+int cuhe_hip_reduce_kind(void) { return G_.force_generic ? 0 : G_.reduce_kind; }
+int cuhe_hip_force_generic_reduce(int on) { G_.force_generic = on != 0; return CUHE_OK; }
+
+// ---------------------------------------------------------------- allocator
+int cuhe_hip_start_allocator(void) { G_.allocator_on = true; return CUHE_OK; }   // no "grab all VRAM" 
+int cuhe_hip_stop_allocator(void) {
+    G_.allocator_on = false;
+    for (int d = 0; d < (int)G_.dev.size(); ++d) {
+        hipSetDevice(G_.dev_base + d);
+        for (auto &kv : G_.dev[d].freeBlocks) hipFree(kv.second);
+        G_.dev[d].freeBlocks.clear();
+    }
+    return CUHE_OK;
+}
+void *cuhe_hip_malloc(int dev, size_t bytes) {
+    if (set_dev(dev) != CUHE_OK) return nullptr;
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    if (G_.allocator_on) {
+        auto it = D.freeBlocks.find(bytes);
+        if (it != D.freeBlocks.end()) { void *p = it->second; D.freeBlocks.erase(it); D.allocated[p] = bytes; return p; }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(CUHE_EHIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    D.allocated[p] = bytes;
+    return p;
+}
+int cuhe_hip_free(int dev, void *ptr) {
+    if (!ptr) return CUHE_OK;
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.allocated.find(ptr);
+    if (it == D.allocated.end()) return fail(CUHE_EINVAL, "free of unknown pointer");
+    const size_t sz = it->second;
+    D.allocated.erase(it);
+    if (G_.allocator_on) D.freeBlocks.insert({sz, ptr});
+    else HIPCHK(hipFree(ptr));
+    return CUHE_OK;
+}
+int cuhe_hip_memset_async(int dev, void *p, int v, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemsetAsync(p, v, n, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_h2d(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_d2h(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_d2d(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_peer(void *d, int dd, const void *s, int sd, size_t n, void *st) {
+    CHK(set_dev(sd));
+    HIPCHK(hipMemcpyPeerAsync(d, G_.dev_base + dd, s, G_.dev_base + sd, n, S(st)));
+    return CUHE_OK;
+}
+int cuhe_hip_stream_sync(int dev, void *st) { CHK(set_dev(dev)); HIPCHK(hipStreamSynchronize(S(st))); return CUHE_OK; }
+
+// ---------------------------------------------------------------- drivers
+int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    DevCtx &D = G_.dev[dev];
+    if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
+    const Params &q = G_.prm;
+    hipLaunchKernelGGL(k_crt, dim3((q.modLen + 63) / 64), dim3(64), (size_t)W * 64 * 4, S(st), dst, src, prime_tab(D),
+                       np, W, q.modLen, q.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (lvl < 0) return fail(CUHE_EINVAL, "icrt below level 0");
+    DevCtx &D = G_.dev[dev];
+    const Params &q = G_.prm;
+    const IcrtLevel &I = D.icrt[lvl];
+    IcrtTab it{I.M, I.mi, I.bi, I.rp};
+    hipLaunchKernelGGL(k_icrt, dim3((q.modLen + 63) / 64), dim3(64), (size_t)(np + W) * 64 * 4, S(st), dst, src,
+                       prime_tab(D), it, np, W, q.modLen, q.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_crt_add(uint32_t *sum, const uint32_t *x, const uint32_t *y, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    hipLaunchKernelGGL(k_crt_add, dim3((q.modLen + 255) / 256, np), dim3(256), 0, S(st), sum, x, y, prime_tab(G_.dev[dev]),
+                       q.modLen, q.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_crt_add_int(uint32_t *sum, const uint32_t *x, unsigned a, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    hipLaunchKernelGGL(k_crt_add_int, dim3((np + 63) / 64), dim3(64), 0, S(st), sum, x, a, prime_tab(G_.dev[dev]), np,
+                       G_.prm.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_crt_add_nx1(uint32_t *sum, const uint32_t *x, const uint32_t *s, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    hipLaunchKernelGGL(k_crt_add_nx1, dim3((q.modLen + 255) / 256, np), dim3(256), 0, S(st), sum, x, s,
+                       prime_tab(G_.dev[dev]), q.modLen, q.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_crt_mul_int(uint32_t *prod, const uint32_t *x, int a, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    hipLaunchKernelGGL(k_crt_mul_int, dim3((np + 63) / 64), dim3(64), 0, S(st), prod, x, a, prime_tab(G_.dev[dev]), np,
+                       G_.prm.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_crt_mod_switch(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (np < 2) return fail(CUHE_EINVAL, "modSwitch needs >= 2 primes");
+    const Params &q = G_.prm;
+    DevCtx &D = G_.dev[dev];
+    hipLaunchKernelGGL(k_modswitch, dim3((q.modLen + 255) / 256, np - 1), dim3(256), 0, S(st), dst, src, prime_tab(D),
+                       D.invp, np, q.modLen, q.crtLen, q.modMsg);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
+int cuhe_hip_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcU32Ext, X, x, np, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_nttw(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    if (!q.logRelin) return fail(CUHE_EINVAL, "logRelin = 0");
+    return run_ntt(q.nttLen, kSrcWindow, X, x, q.numEvalKeyAt(lvl), 0, q.nttLen, q.nttLen, 0,
+                   WindowArgs{W, q.logRelin, 0}, dev, S(st));
+}
+int cuhe_hip_intt(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcU64Neg, x, X, np, q.nttLen, q.crtLen, q.crtLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_intt_hold(const uint64_t *X, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcU64Neg, G_.dev[dev].hold, X, np, q.nttLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0},
+                   dev, S(st));
+}
+int cuhe_hip_intt_double_deg(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcU64Neg, x, X, np, q.nttLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_barrett(uint32_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
+    CHK(need_init(dev));
+    if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    return barrett_impl(dst, src, lvl, dev, S(st));
+}
+int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *st) {
+    CHK(need_init(dev));
+    return cuhe_hip_barrett(dst, G_.dev[dev].hold, lvl, dev, st);
+}
+int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
+    CHK(cuhe_hip_intt_hold(X, logq, dev, st));
+    int lvl = G_.prm.getLevel(logq);
+    if (lvl < 0) return fail(CUHE_EINVAL, "inttMod below level 0");
+    return barrett_impl(x, G_.dev[dev].hold, lvl, dev, S(st));
+}
+uint32_t *cuhe_hip_intt_result(int dev) {
+    if (!G_.inited || dev < 0 || dev >= (int)G_.dev.size()) return nullptr;
+    return G_.dev[dev].hold;
+}
+
+static int binop(bool mul, bool nx1, uint64_t *z, const uint64_t *x, const uint64_t *y, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    const int L = G_.prm.nttLen;
+    if (!nx1) {
+        const long pairs = (long)np * L / 2;
+        const int grid = (int)std::min<long>((pairs + 255) / 256, 8192);
+        if (mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, pairs);
+        else hipLaunchKernelGGL((k_ntt_binop<false>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, pairs);
+    } else {
+        dim3 grid((L / 2 + 255) / 256, np);
+        if (mul) hipLaunchKernelGGL((k_ntt_binop_nx1<true>), grid, dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, np, L / 2);
+        else hipLaunchKernelGGL((k_ntt_binop_nx1<false>), grid, dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, np, L / 2);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_ntt_mul(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *st) { return binop(true, false, z, y, x, logq, dev, st); }
+int cuhe_hip_ntt_mul_nx1(uint64_t *z, const uint64_t *x, const uint64_t *s, int logq, int dev, void *st) { return binop(true, true, z, x, s, logq, dev, st); }
+int cuhe_hip_ntt_add(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *st) { return binop(false, false, z, y, x, logq, dev, st); }
+int cuhe_hip_ntt_add_nx1(uint64_t *z, const uint64_t *x, const uint64_t *s, int logq, int dev, void *st) { return binop(false, true, z, x, s, logq, dev, st); }
+
+int cuhe_hip_ntt_one(uint64_t *X, const uint32_t *x, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcU32Ext, X, x, 1, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_nttw_one(uint64_t *X, const uint32_t *x, int coeffwords, int relinIdx, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcWindow, X, x, 1, 0, q.nttLen, q.nttLen, 0, WindowArgs{coeffwords, q.logRelin, relinIdx},
+                   dev, S(st));
+}
+int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (crtidx < 0 || crtidx >= q.numCrtPrime) return fail(CUHE_EINVAL, "crtidx %d", crtidx);
+    return run_ntt(q.nttLen, kSrcU64Neg, x, X, 1, q.nttLen, q.nttLen, q.nttLen, crtidx, WindowArgs{0, 0, 0}, dev, S(st));
+}
+
+// ---------------------------------------------------------------- relinearisation
+int cuhe_hip_init_relin(const uint32_t *ek_host) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
+    const Params &q = G_.prm;
+    const int K = q.numEvalKey, np = q.numCrtPrime, L = q.nttLen, W0 = q.wordsCoeff(0);
+    if (K <= 0) return fail(CUHE_EINVAL, "numEvalKey = 0");
+    const size_t rawBytes = (size_t)q.rawLen * W0 * 4;
+    for (int dev = 0; dev < G_.ndev; ++dev) {
+        CHK(set_dev(dev));
+        DevCtx &D = G_.dev[dev];
+        if (D.ek) { hipFree(D.ek); D.ek = nullptr; }
+        if (D.relin) { hipFree(D.relin); D.relin = nullptr; }
+        HIPCHK(hipMalloc((void **)&D.ek, (size_t)np * K * L * sizeof(u64)));
+        HIPCHK(hipMalloc((void **)&D.relin, (size_t)K * L * sizeof(u64)));
+        u32 *raw = nullptr, *crt = nullptr; u64 *ntt = nullptr;
+        HIPCHK(hipMalloc((void **)&raw, rawBytes));
+        HIPCHK(hipMalloc((void **)&crt, (size_t)np * q.crtLen * 4));
+        HIPCHK(hipMalloc((void **)&ntt, (size_t)np * L * 8));
+        for (int j = 0; j < K; ++j) {                              // cuhe/Relinearization.cu:49-56
+            HIPCHK(hipMemcpy(raw, ek_host + (size_t)j * q.rawLen * W0, rawBytes, hipMemcpyHostToDevice));
+            HIPCHK(hipMemsetAsync(crt, 0, (size_t)np * q.crtLen * 4, 0));
+            CHK(cuhe_hip_crt(crt, raw, q.logCoeff(0), dev, nullptr));
+            CHK(cuhe_hip_ntt((uint64_t *)ntt, crt, q.logCoeff(0), dev, nullptr));
+            // ek[prime i][key j][L]
+            HIPCHK(hipMemcpy2DAsync(D.ek + (size_t)j * L, (size_t)K * L * 8, ntt, (size_t)L * 8, (size_t)L * 8, np,
+                                    hipMemcpyDeviceToDevice, 0));
+        }
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(raw); hipFree(crt); hipFree(ntt);
+    }
+    G_.relin_ready = true;
+    return CUHE_OK;
+}
+int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
+    CHK(need_init(dev));
+    if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    DevCtx &D = G_.dev[dev];
+    const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = q.nttLen;
+    CHK(cuhe_hip_nttw((uint64_t *)D.relin, src, q.logCoeff(lvl), dev, st));
+    hipLaunchKernelGGL(k_relin_mac, dim3(L / 256, np), dim3(256), 0, S(st), (u64 *)dst, D.relin, D.ek, k,
+                       (long)q.numEvalKey * L, L);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
+// ---------------------------------------------------------------- batched primitives
+int cuhe_hip_ntt_prepare(int len, int dev) {
+    CHK(set_dev(dev));
+    return ensure_ntt(dev, len, 1 << 20);
+}
+int cuhe_hip_set_ntt_chunk(int chunk) {
+    G_.ntt_chunk = chunk;
+    for (auto &D : G_.dev) for (auto &t : D.ntt) if (t.scratch) { hipFree(t.scratch); t.scratch = nullptr; t.scratch_batch = 0; }
+    return CUHE_OK;
+}
+int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {
+    CHK(set_dev(dev));
+    if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);
+    if (src_stride < len / 2) return fail(CUHE_EINVAL, "src_stride %ld < len/2", src_stride);
+    return run_ntt(len, kSrcU32Ext, dst, src, batch, src_stride, len, len, 0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_ntt_inv_batched(uint32_t *dst, const uint64_t *src, int len, int batch, long dst_stride, int nstore,
+                             int prime0, int dev, void *st) {
+    CHK(need_init(dev));
+    if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);
+    if (prime0 < 0 || prime0 + batch > G_.prm.numCrtPrime) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + batch);
+    return run_ntt(len, kSrcU64Neg, dst, src, batch, len, dst_stride, nstore, prime0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *st,
+                          float *ms1, float *ms2, float *mst) {
+    CHK(set_dev(dev));
+    if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);
+    EvTimer tm; tm.on = true;
+    for (int it = 0; it < iters; ++it)
+        CHK(run_ntt(len, kSrcU32Ext, dst, src, batch, len / 2, len, len, 0, WindowArgs{0, 0, 0}, dev, S(st), &tm));
+    HIPCHK(hipStreamSynchronize(S(st)));
+    float a = 0, b = 0, tot = 0;
+    for (size_t i = 0; i + 2 < tm.ev.size(); i += 3) {
+        float t1 = 0, t2 = 0;
+        hipEventElapsedTime(&t1, tm.ev[i], tm.ev[i + 1]);
+        hipEventElapsedTime(&t2, tm.ev[i + 1], tm.ev[i + 2]);
+        a += t1; b += t2;
+    }
+    if (!tm.ev.empty()) hipEventElapsedTime(&tot, tm.ev.front(), tm.ev.back());
+    for (auto e : tm.ev) hipEventDestroy(e);
+    if (ms1) *ms1 = a;
+    if (ms2) *ms2 = b;
+    if (mst) *mst = tot;
+    return CUHE_OK;
+}
+
+// ---------------------------------------------------------------- field test hooks
+static int modp_op(int op, uint64_t *z, const uint64_t *x, const uint64_t *y, int l, size_t n, int dev, void *st) {
+    CHK(set_dev(dev));
+    const int grid = (int)((n + 255) / 256);
+    if (op == 0) hipLaunchKernelGGL((k_modp_test<0>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, l, n);
+    else if (op == 1) hipLaunchKernelGGL((k_modp_test<1>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, l, n);
+    else if (op == 2) hipLaunchKernelGGL((k_modp_test<2>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)x, (const u64 *)y, l, n);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_modp_add(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *st) { return modp_op(0, z, x, y, 0, n, dev, st); }
+int cuhe_hip_modp_sub(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *st) { return modp_op(1, z, x, y, 0, n, dev, st); }
+int cuhe_hip_modp_mul(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *st) { return modp_op(2, z, x, y, 0, n, dev, st); }
+
+int cuhe_hip_modp_shl(uint64_t *z, const uint64_t *x, int l, size_t n, int dev, void *st) {
+    CHK(set_dev(dev));
+    if (l < 0 || l >= 192 || l % 3) return fail(CUHE_EINVAL, "shift %d: multiples of 3 in [0,192) (cuhe/ModP.h:151)", l);
+    bool done = false;
+    shl_dispatch<0>(l, z, x, n, S(st), done);
+    HIPCHK(hipGetLastError());
+    return done ? CUHE_OK : fail(CUHE_EINVAL, "shift %d", l);
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// modp.cuh -- device arithmetic in the field Z_P, P = 2^64 - 2^32 + 1, for gfx950.
+//
+// Replaces cuhe/ModP.h:151-289 of the reference (inline-PTX carry chains) with
+// wave64-friendly 32/64-bit integer code the AMDGPU backend lowers to
+// v_add_co/v_addc_co/v_mad_u64_u32.  All results are CANONICAL residues in
+// [0, P) (the reference's `> valP` compares can return P for 0 -- SURVEY A.7 --
+// which would corrupt the later `% p_i`; we do not reproduce that).
+//
+// Identities used: phi = 2^32, phi^2 = phi - 1, phi^3 = -1 (mod P), so 2 has
+// order 192 and 8 = 2^3 is a primitive 64-th root of unity: every butterfly
+// inside a <=64-point sub-transform is an add/sub plus a shift.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cuhe {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+static constexpr u64 kP = 0xffffffff00000001ULL;
+static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
+
+// canonical -> canonical
+__device__ __forceinline__ u64 addp(u64 a, u64 b) {
+    u64 s = a + b;
+    u64 t = s + kEps;            // s - P (mod 2^64)
+    bool carry = s < a;          // true sum >= 2^64
+    bool ge = t < s;             // s >= P
+    return (carry | ge) ? t : s;
+}
+__device__ __forceinline__ u64 subp(u64 a, u64 b) {
+    u64 d = a - b;
+    return (a < b) ? d - kEps : d;     // + P
+}
+__device__ __forceinline__ u64 negp(u64 a) { return a ? kP - a : 0; }
+
+// any u64 -> canonical
+__device__ __forceinline__ u64 canon(u64 r) {
+    u64 t = r + kEps;
+    return (t < r) ? t : r;
+}
+
+// 128-bit (hi:lo) -> canonical; hi = hh:hl.  lo + hl*(phi-1) - hh
+__device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
+    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= kEps;                       // borrowed 2^64 = eps
+    u64 t1 = ((u64)hl << 32) - hl;                 // hl * eps  (< P)
+    u64 r = t0 + t1;
+    if (r < t0) r += kEps;
+    return canon(r);
+}
+
+// canonical x canonical -> canonical
+__device__ __forceinline__ u64 mulp(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 t = (u64)a0 * b0;
+    u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v = (u64)a1 * b0 + (u32)u;
+    u64 w = (u64)a1 * b1 + (u >> 32) + (v >> 32);
+    u64 lo = (v << 32) | (u32)t;
+    return reduce128(lo, w);
+}
+
+// canonical u64 times a u32 -> canonical  (96-bit product)
+__device__ __forceinline__ u64 mulp_u32(u64 a, u32 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+    u64 t = (u64)a0 * b;
+    u64 u = (u64)a1 * b + (t >> 32);
+    u64 lo = (u << 32) | (u32)t;
+    u32 mid = (u32)(u >> 32);                      // bits 64..95
+    u64 t1 = ((u64)mid << 32) - mid;
+    u64 r = lo + t1;
+    if (r < lo) r += kEps;
+    return canon(r);
+}
+
+// x * 2^K mod P for a compile-time K in [0, 96); x canonical.
+//   x*2^K = lo + mid*2^64 + hi*2^96  ==  lo + mid*eps - hi
+template <int K>
+__device__ __forceinline__ u64 shlp(u64 x) {
+    static_assert(K >= 0 && K < 96, "shift out of range");
+    if constexpr (K == 0) {
+        return x;
+    } else if constexpr (K < 32) {
+        u64 lo = x << K;
+        u32 mid = (u32)(x >> (64 - K));
+        u64 t1 = ((u64)mid << 32) - mid;
+        u64 r = lo + t1;
+        if (r < lo) r += kEps;
+        return canon(r);
+    } else if constexpr (K == 32) {
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+        u64 lo = (u64)x0 << 32;
+        u64 t1 = ((u64)x1 << 32) - x1;
+        u64 r = lo + t1;
+        if (r < lo) r += kEps;
+        return canon(r);
+    } else if constexpr (K < 64) {
+        u64 lo = x << K;                           // low 64 bits
+        u32 mid = (u32)(x >> (64 - K));            // bits 64..95
+        u64 hi = x >> (96 - K);                    // bits 96.. (< 2^(K-32))
+        u64 t1 = ((u64)mid << 32) - mid;
+        u64 r = lo + t1;
+        if (r < lo) r += kEps;
+        r = canon(r);
+        return subp(r, hi);
+    } else if constexpr (K == 64) {
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+        u64 t1 = ((u64)x0 << 32) - x0;             // x0 * eps
+        return subp(t1, (u64)x1);
+    } else {
+        u32 mid = (u32)(x << (K - 64));            // bits 64..95
+        u64 hi = x >> (96 - K);
+        u64 t1 = ((u64)mid << 32) - mid;
+        return subp(t1, hi);
+    }
+}
+
+// (u - v) * 2^K for K in [0,192): K >= 96 folds the sign into the subtraction.
+template <int K>
+__device__ __forceinline__ u64 sub_shlp(u64 u, u64 v) {
+    if constexpr (K >= 96) return shlp<K - 96>(subp(v, u));
+    else return shlp<K>(subp(u, v));
+}
+
+// canonical value mod a 32-bit prime p; m = floor(2^64 / p)
+__device__ __forceinline__ u32 mod_small(u64 x, u32 p, u64 m) {
+    u64 q = __umul64hi(x, m);
+    u64 r = x - q * p;
+    if (r >= p) r -= p;
+    return (u32)r;
+}
+
+// ---------------------------------------------------------------------------
+// In-register N-point DFT over Z_P with root 2^(192/N) (N | 64), natural order
+// in and out.  Radix-2 DIF with compile-time shifts; the final bit reversal is
+// register renaming.  Replaces _ntt4/_ntt8/_ntt8_ext + the 8x8 LDS transposes
+// of cuhe/Base.cu:225-306.
+// ---------------------------------------------------------------------------
+template <int N, int LEN, int BASE, int J>
+__device__ __forceinline__ void dif_pair(u64 (&x)[N]) {
+    constexpr int H = LEN / 2;
+    constexpr int K = (192 / LEN) * J;
+    u64 u = x[BASE + J], v = x[BASE + J + H];
+    x[BASE + J] = addp(u, v);
+    x[BASE + J + H] = sub_shlp<K>(u, v);
+}
+template <int N, int LEN, int BASE, int J>
+struct DifBlock {
+    static __device__ __forceinline__ void run(u64 (&x)[N]) {
+        dif_pair<N, LEN, BASE, J>(x);
+        if constexpr (J + 1 < LEN / 2) DifBlock<N, LEN, BASE, J + 1>::run(x);
+    }
+};
+template <int N, int LEN, int BASE>
+struct DifStage {
+    static __device__ __forceinline__ void run(u64 (&x)[N]) {
+        DifBlock<N, LEN, BASE, 0>::run(x);
+        if constexpr (BASE + LEN < N) DifStage<N, LEN, BASE + LEN>::run(x);
+    }
+};
+template <int N, int LEN>
+struct DifAll {
+    static __device__ __forceinline__ void run(u64 (&x)[N]) {
+        DifStage<N, LEN, 0>::run(x);
+        if constexpr (LEN > 2) DifAll<N, LEN / 2>::run(x);
+    }
+};
+template <int N>
+__host__ __device__ constexpr int bitrev(int i) {
+    int r = 0;
+    for (int b = 1; b < N; b <<= 1) { r = (r << 1) | (i & 1); i >>= 1; }
+    return r;
+}
+// y[k] = sum_j x[j] * (2^(192/N))^(j*k); result left in x with x[bitrev(k)] = y[k].
+template <int N>
+__device__ __forceinline__ void dft_bitrev(u64 (&x)[N]) { DifAll<N, N>::run(x); }
+
+}  // namespace cuhe

@@ -1,0 +1,194 @@
+// ntt_kernels.cuh -- batched length-L cyclic NTT / INTT over Z_P for gfx950
+// (L = 2^LG, LG in {14,15,16}; root w_L = g^(65536/L), natural order in/out).
+//
+// Replaces the reference's 3-pass 64x64x{4,8,16} scheme, one prime per launch,
+// 64-thread blocks (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398) with a
+// 2-pass "four-step" split  L = N1 x 64,  N1 = L/64 = R1 x R2:
+//
+//   pass 1 (ntt_pass1):  for every column j2 < 64, an N1-point DFT over the
+//       stride-64 samples x[64*j1 + j2].  A 256-thread workgroup owns NC
+//       adjacent columns.  Each thread does R1-point DFTs in registers
+//       (compile-time power-of-two twiddles: shifts only), multiplies by the
+//       inner twiddle w_N1^(b*c) (LDS table), exchanges through LDS, does
+//       R2-point DFTs in registers, multiplies by the outer twiddle
+//       w_L^(j2*k1) and writes scratch[j2][k1] (coalesced, L2/MALL resident).
+//   pass 2 (ntt_pass2):  one thread per k1 loads the 64 values scratch[.][k1]
+//       (512 B contiguous per wave-load), does a 64-point DFT entirely in
+//       registers (w_64 = 8: shifts only, no LDS, no barrier) and stores
+//       X[k1 + N1*k2] (512 B contiguous per wave-store) in natural order.
+//
+// Exactly two general modular multiplications per point; everything else is
+// add/sub/shift.  HBM traffic per transform is the algorithmic 4*(L/2) + 8*L
+// bytes when the scratch slab stays cache resident (the host driver chunks the
+// batch to make it so).
+//
+// The inverse transform reuses the same passes on index-negated input
+// (cuhe/Base.cu:454,622,799) with L^-1 folded into the outer twiddle table and
+// `mod p_i` + u64->u32 narrowing fused into the pass-2 store
+// (cuhe/Base.cu:469-490).  The relinearisation window extraction
+// (cuhe/Base.cu:345-372) is fused into the pass-1 load.
+#pragma once
+#include "modp.cuh"
+
+namespace cuhe {
+
+template <int LG> struct NttGeom;
+template <> struct NttGeom<14> { static constexpr int R1 = 16, R2 = 16, NC = 32; };
+template <> struct NttGeom<15> { static constexpr int R1 = 16, R2 = 32, NC = 16; };
+template <> struct NttGeom<16> { static constexpr int R1 = 32, R2 = 32, NC = 8; };
+
+static constexpr int kNttThreads = 256;
+
+template <int LG>
+struct NttLds {
+    using G = NttGeom<LG>;
+    static constexpr int RS = G::R2 + 1;                 // row stride (u64), odd: conflict-free reads
+    static constexpr int CS = G::R1 * RS + 2;            // column stride (u64), == 2 mod 16
+    static constexpr int XCH = G::NC * CS;               // exchange buffer (u64)
+    static constexpr int T1N = G::R1 * G::R2;            // inner twiddle table (u64)
+    static constexpr size_t bytes = (size_t)(XCH + T1N) * sizeof(u64);
+};
+
+enum : int { kSrcU32Ext = 0, kSrcWindow = 1, kSrcU64Neg = 2 };
+
+// blockIdx -> (batch, tile) with every tile of one transform on one XCD
+// (block b runs on XCD b % 8: MI355X_MICROARCH "Workgroup dispatch"; speed only).
+__device__ __forceinline__ void xcd_map(int tiles, int &batch, int &tile) {
+    int g = blockIdx.x;
+    int xcd = g & 7, r = g >> 3;
+    tile = r % tiles;
+    batch = (r / tiles) * 8 + xcd;
+}
+
+struct WindowArgs { int words, w, wid0; };
+
+// first DIF stage when the upper half of the input is zero (u + 0, (u - 0)*w^j)
+template <int N, int J>
+struct ExtStage {
+    static __device__ __forceinline__ void run(u64 (&x)[N]) {
+        x[J + N / 2] = shlp<(192 / N) * J>(x[J]);
+        if constexpr (J + 1 < N / 2) ExtStage<N, J + 1>::run(x);
+    }
+};
+
+template <int N, bool EXT>
+__device__ __forceinline__ void dft_regs(u64 (&x)[N]) {
+    if constexpr (EXT) {
+        ExtStage<N, 0>::run(x);
+        if constexpr (N > 2) DifAll<N, N / 2>::run(x);
+    } else {
+        DifAll<N, N>::run(x);
+    }
+}
+
+template <int LG, int MODE>
+__global__ __launch_bounds__(kNttThreads, 2)
+void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
+               const u64 *__restrict__ T1, const u64 *__restrict__ T2,
+               long src_stride, int nbatch, WindowArgs wa) {
+    using G = NttGeom<LG>;
+    using S = NttLds<LG>;
+    constexpr int L = 1 << LG, N1 = L / 64, R1 = G::R1, R2 = G::R2, NC = G::NC;
+    constexpr int T = kNttThreads;
+    constexpr int IT1 = NC * R2 / T, IT3 = NC * R1 / T;
+    constexpr bool EXT = (MODE != kSrcU64Neg);
+    constexpr int NA = EXT ? R1 / 2 : R1;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 *xch = lds;
+    u64 *t1 = lds + S::XCH;
+
+    int batch, tile;
+    xcd_map(64 / NC, batch, tile);
+    if (batch >= nbatch) return;
+    const int t = threadIdx.x;
+    const int col0 = tile * NC;
+
+    for (int i = t; i < S::T1N; i += T) t1[i] = T1[i];
+
+    // ---- step (i): R1-point DFTs over a, j1 = a*R2 + b ----
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int e = t + T * it;
+        const int col = e % NC, b = e / NC;
+        u64 x[R1];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int idx = (a * R2 + b) * 64 + col0 + col;
+            if constexpr (MODE == kSrcU32Ext) {
+                const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
+                x[a] = src[idx];
+            } else if constexpr (MODE == kSrcWindow) {
+                // cuhe/Base.cu:361-371: w-bit window `wid` of a W-word coefficient
+                const u32 *co = (const u32 *)src_ + (long)idx * wa.words;
+                const int bit = wa.w * (wa.wid0 + batch);
+                const int wi = bit >> 5;
+                u64 s = co[wi];
+                if (wi + 1 < wa.words) s |= (u64)co[wi + 1] << 32;
+                s >>= (bit & 31);
+                x[a] = s & (u64)((1u << wa.w) - 1u);
+            } else {
+                const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
+                x[a] = src[(L - idx) & (L - 1)];
+            }
+        }
+        dft_regs<R1, EXT>(x);
+        if (it == 0) __syncthreads();            // t1 table visible
+#pragma unroll
+        for (int c = 0; c < R1; ++c) {
+            u64 v = x[bitrev<R1>(c)];
+            if (c != 0) v = mulp(v, t1[c * R2 + b]);
+            xch[col * S::CS + c * S::RS + b] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- step (iii): R2-point DFTs over b, k1 = c + R1*d ----
+    u64 *out = scratch + (long)batch * L;
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) {
+        const int e = t + T * it;
+        const int c = e % R1, col = e / R1;
+        u64 y[R2];
+#pragma unroll
+        for (int b = 0; b < R2; ++b) y[b] = xch[col * S::CS + c * S::RS + b];
+        dft_regs<R2, false>(y);
+        const int j2 = col0 + col;
+#pragma unroll
+        for (int d = 0; d < R2; ++d) {
+            const int o = j2 * N1 + c + R1 * d;
+            out[o] = mulp(y[bitrev<R2>(d)], T2[o]);
+        }
+    }
+}
+
+template <int LG, bool INV>
+__global__ __launch_bounds__(kNttThreads, 2)
+void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch,
+               long dst_stride, int nbatch, int nstore,
+               const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
+    constexpr int L = 1 << LG, N1 = L / 64;
+    int batch, tile;
+    xcd_map(N1 / kNttThreads, batch, tile);
+    if (batch >= nbatch) return;
+    const int k1 = tile * kNttThreads + threadIdx.x;
+    const u64 *in = scratch + (long)batch * L + k1;
+    u64 x[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) x[j] = in[j * N1];
+    dft_regs<64, false>(x);
+    if constexpr (!INV) {
+        u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
+#pragma unroll
+        for (int k2 = 0; k2 < 64; ++k2) dst[k2 * N1] = x[bitrev<64>(k2)];
+    } else {
+        // cuhe/Base.cu:469-490: (x * L^-1 mod P) % p_i -> u32 (L^-1 already in T2)
+        const u32 p = primes[prime0 + batch];
+        const u64 m = pinv[prime0 + batch];
+        u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
+#pragma unroll
+        for (int k2 = 0; k2 < 64; ++k2)
+            if (k2 * N1 + k1 < nstore) dst[k2 * N1] = mod_small(x[bitrev<64>(k2)], p, m);
+    }
+}
+
+}  // namespace cuhe

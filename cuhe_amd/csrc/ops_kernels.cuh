@@ -1,0 +1,317 @@
+// ops_kernels.cuh -- CRT / ICRT / pointwise / polynomial-Barrett / modswitch /
+// relinearisation kernels for gfx950.  Each kernel cites the reference kernel
+// (cuhe/Base.cu) whose results it reproduces bit-for-bit; none of them is a
+// translation: launches are batched over all CRT primes, constants live in
+// HBM/L2 tables instead of 64 KB __constant__/textures, `%` is replaced by
+// reciprocal multiplication and multiword carry chains use v_mad_u64_u32.
+#pragma once
+#include "modp.cuh"
+
+namespace cuhe {
+
+// per-prime constants resident on the device
+struct PrimeTab {
+    const u32 *p;        // [np]           CRT primes                      (const_p,  Base.cu:139)
+    const u64 *pinv;     // [np]           floor(2^64 / p_i)
+    const u32 *e64;      // [np]           2^64 mod p_i
+    const u32 *pow32;    // [np][maxW]     2^(32k) mod p_i
+    int maxW;
+};
+
+// ---------------------------------------------------------------- pointwise mod P
+// z = x (op) y over np*L contiguous u64.  (ntt_mul / ntt_add: Base.cu:1036-1053;
+// barrett_mul_un / barrett_mul_mn: Base.cu:927-949 are the same op with a table)
+template <bool MUL>
+__global__ __launch_bounds__(256)
+void k_ntt_binop(u64 *__restrict__ z, const u64 *__restrict__ x, const u64 *__restrict__ y, long n2) {
+    // n2 = number of u64 pairs
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        ulonglong2 a = reinterpret_cast<const ulonglong2 *>(x)[i];
+        ulonglong2 b = reinterpret_cast<const ulonglong2 *>(y)[i];
+        ulonglong2 r;
+        if (MUL) { r.x = mulp(a.x, b.x); r.y = mulp(a.y, b.y); }
+        else     { r.x = addp(a.x, b.x); r.y = addp(a.y, b.y); }
+        reinterpret_cast<ulonglong2 *>(z)[i] = r;
+    }
+}
+// second operand is ONE polynomial broadcast to every prime (ntt_mul_nx1 / ntt_add_nx1: Base.cu:1054-1075)
+template <bool MUL>
+__global__ __launch_bounds__(256)
+void k_ntt_binop_nx1(u64 *__restrict__ z, const u64 *__restrict__ x, const u64 *__restrict__ s, int np, int L2) {
+    // L2 = L/2 pairs per polynomial; grid.y = prime
+    const int crt = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L2; i += gridDim.x * blockDim.x) {
+        ulonglong2 a = reinterpret_cast<const ulonglong2 *>(x)[(long)crt * L2 + i];
+        ulonglong2 b = reinterpret_cast<const ulonglong2 *>(s)[i];
+        ulonglong2 r;
+        if (MUL) { r.x = mulp(a.x, b.x); r.y = mulp(a.y, b.y); }
+        else     { r.x = addp(a.x, b.x); r.y = addp(a.y, b.y); }
+        reinterpret_cast<ulonglong2 *>(z)[(long)crt * L2 + i] = r;
+    }
+}
+
+// ---------------------------------------------------------------- CRT-domain ops
+// inputs are residues < p_i, so (a+b)%p is one conditional subtract when a,b < p;
+// the reference uses % (Base.cu:1088-1109) which also accepts unreduced inputs --
+// we keep exact % semantics through mod_small.
+__global__ __launch_bounds__(256)
+void k_crt_add(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__restrict__ b,
+               PrimeTab pt, int mlen, int clen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mlen) return;
+    const long o = (long)crt * clen + idx;
+    z[o] = mod_small((u64)a[o] + b[o], pt.p[crt], pt.pinv[crt]);
+}
+__global__ __launch_bounds__(256)
+void k_crt_add_nx1(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__restrict__ s,
+                   PrimeTab pt, int mlen, int clen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mlen) return;
+    const long o = (long)crt * clen + idx;
+    z[o] = mod_small((u64)a[o] + s[idx], pt.p[crt], pt.pinv[crt]);
+}
+// constant term only (Base.cu:1096-1100)
+__global__ void k_crt_add_int(u32 *__restrict__ z, const u32 *__restrict__ x, unsigned a,
+                              PrimeTab pt, int np, int clen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const u32 p = pt.p[i];
+    const u64 m = pt.pinv[i];
+    z[(long)i * clen] = mod_small((u64)x[(long)i * clen] + mod_small(a, p, m), p, m);
+}
+// constant term times an integer (crt_mul_int, Base.cu:1078-1087)
+__global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict__ x, int a,
+                              PrimeTab pt, int np, int clen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    u64 t = (u64)x[(long)i * clen] * (u64)(long)a;        // same wrap-around as the reference's u64 *= int
+    z[(long)i * clen] = mod_small(t, pt.p[i], pt.pinv[i]);
+}
+
+// ---------------------------------------------------------------- modulus switching (Base.cu:1112-1138)
+// grid.y = target prime i < np-1.  dst may alias src (row i only depends on rows i and np-1,
+// and row np-1 is never written).
+__global__ __launch_bounds__(256)
+void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt,
+                 const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg) {
+    const int i = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mlen) return;
+    const u32 ptl = pt.p[np - 1];
+    int dirty = (int)src[(long)(np - 1) * clen + idx];
+    const int ep = dirty % modmsg;
+    if (ep != 0) {
+        if ((u32)dirty > ((ptl - 1) / 2)) dirty -= ep * (int)ptl;
+        else dirty += ep * (int)ptl;
+    }
+    const u32 p = pt.p[i];
+    const u64 m = pt.pinv[i];
+    // (src - dirty) mod p, then times p_t^-1 mod p
+    long long diff = (long long)src[(long)i * clen + idx] - (long long)dirty;   // |diff| < 2^34
+    u32 r;
+    if (diff >= 0) r = mod_small((u64)diff, p, m);
+    else { u32 t = mod_small((u64)(-diff), p, m); r = t ? p - t : 0; }
+    const u32 inv = invp[(np - 1) * (np - 2) / 2 + i];
+    dst[(long)i * clen + idx] = mod_small((u64)r * inv, p, m);
+}
+
+// ---------------------------------------------------------------- polynomial Barrett pieces
+// y[crt][off+idx] = (y - x) mod p for idx < count  (barrett_sub_1: off=mlen,count=mlen; barrett_sub_2: off=0,count=nlen;
+// Base.cu:951-977).  Inputs are residues < p.
+__global__ __launch_bounds__(256)
+void k_barrett_sub(u32 *__restrict__ y, const u32 *__restrict__ x, PrimeTab pt, int off, int count, int nlen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const long o = (long)crt * nlen + off + idx;
+    u32 a = y[o], b = x[o];
+    if (a < b) a += pt.p[crt];
+    y[o] = a - b;
+}
+// barrett_sub_mc (Base.cu:978-1001): if coefficient mlen of row crt is nonzero subtract m (idx < mlen-1)
+__global__ __launch_bounds__(256)
+void k_barrett_sub_mc(u32 *__restrict__ x, const u32 *__restrict__ m_crt, PrimeTab pt, int mlen, int clen, int nlen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mlen - 1) return;
+    if (x[(long)crt * nlen + mlen] == 0) return;
+    u32 d = x[(long)crt * nlen + idx], s = m_crt[(long)crt * clen + idx];
+    if (d < s) d += pt.p[crt];
+    x[(long)crt * nlen + idx] = d - s;
+}
+// zero x[crt][0..count)
+__global__ __launch_bounds__(256)
+void k_zero_rows(u32 *__restrict__ x, int count, int nlen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) x[(long)crt * nlen + idx] = 0;
+}
+// dst[crt][0..clen) = src[crt][0..clen) with row strides nlen -> clen
+__global__ __launch_bounds__(256)
+void k_gather_rows(u32 *__restrict__ dst, const u32 *__restrict__ src, int clen, int nlen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < clen) dst[(long)crt * clen + idx] = src[(long)crt * nlen + idx];
+}
+
+// fast exact reduction when the modulus is x^n + 1 (m = 2n a power of two):
+//   r[i] = f[i] - f[i+n]           (f has degree <= 2n-2)
+// and when m is prime (Phi_m = 1 + x + ... + x^(m-1), n = m-1):
+//   fold mod x^m - 1, then subtract the coefficient of x^(m-1) from every term.
+// Both give the same residues as the NTT-based Barrett of Operations.cu:460-501.
+template <int KIND>   // 0: x^n+1 ; 1: prime m
+__global__ __launch_bounds__(256)
+void k_reduce_special(u32 *__restrict__ dst, const u32 *__restrict__ f, PrimeTab pt, int n, int clen, int nlen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= clen) return;
+    const u32 *row = f + (long)crt * nlen;
+    const u32 p = pt.p[crt];
+    u32 r = 0;
+    if (idx < n) {
+        if (KIND == 0) {
+            u32 a = row[idx], b = row[idx + n];
+            r = a >= b ? a - b : a + p - b;
+        } else {
+            const int m = n + 1;
+            // folded g[i] = f[i] + f[i+m]  (i+m <= 2n-2 = 2m-4  =>  i <= m-4)
+            u32 a = row[idx];
+            if (idx + m <= 2 * n - 2) { a += row[idx + m]; if (a >= p) a -= p; }
+            u32 top = row[m - 1];       // g[m-1] = f[m-1]  (f[2m-1] is beyond the degree bound)
+            r = a >= top ? a - top : a + p - top;
+        }
+    }
+    dst[(long)crt * clen + idx] = r;
+}
+
+// ---------------------------------------------------------------- relinearisation inner product
+// dst[i][idx] = sum_{j<k} c[j][idx] * ek[i][j][idx] mod P   (relinMulAddPerCrt, Base.cu:1024-1033,
+// launched once for ALL primes; keys are device resident instead of streamed over PCIe per call,
+// Relinearization.cu:80-87).  128-bit products are accumulated unreduced in 160 bits and folded once.
+__global__ __launch_bounds__(256)
+void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
+                 int k, long ek_prime_stride, int L) {
+    const int i = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // L is a multiple of 256
+    const u64 *e = ek + (long)i * ek_prime_stride + idx;
+    const u64 *cc = c + idx;
+    u64 lo = 0, hi = 0; u32 top = 0;
+    for (int j = 0; j < k; ++j) {
+        u64 a = cc[(long)j * L], b = e[(long)j * L];
+        u64 pl = a * b, ph = __umul64hi(a, b);
+        u64 nl = lo + pl;
+        u64 cy = nl < lo;
+        lo = nl;
+        u64 nh = hi + ph;
+        u32 c2 = nh < hi;
+        nh += cy;
+        c2 += (nh < cy);
+        hi = nh;
+        top += c2;
+    }
+    // value = lo + hi*2^64 + top*2^128 ; 2^128 = -2^32 (mod P)
+    u64 r = reduce128(lo, hi);
+    u64 t = (u64)top << 32;             // top < 2^8: canonical
+    dst[(long)i * L + idx] = subp(r, t);
+}
+
+// ---------------------------------------------------------------- CRT: raw -> residues (crt, Base.cu:857-879)
+// One wave per 64 coefficients.  Words are staged through LDS (coalesced 64*W-word slab load),
+// residue = (sum_k word_k * (2^(32k) mod p)) mod p with a 96-bit accumulator: W multiply-adds per
+// (coefficient, prime) instead of W 64-bit `%`.
+__global__ __launch_bounds__(64)
+void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W][64]
+    const int lane = threadIdx.x;
+    const long base = (long)blockIdx.x * 64;
+    const int nvalid = (int)min((long)64, (long)mlen - base);
+    const long slab = (long)nvalid * W;
+    for (long e = lane; e < slab; e += 64) {
+        const int ci = (int)(e / W), k = (int)(e % W);
+        sh[k * 64 + ci] = src[base * W + e];
+    }
+    __syncthreads();
+    if (lane >= nvalid) return;
+    for (int i = 0; i < np; ++i) {
+        const u32 *pw = pt.pow32 + (long)i * pt.maxW;
+        u64 lo = 0; u32 hi = 0;
+        for (int k = 0; k < W; ++k) {
+            u64 pr = (u64)sh[k * 64 + lane] * pw[k];
+            u64 nl = lo + pr;
+            hi += (nl < lo);
+            lo = nl;
+        }
+        const u32 p = pt.p[i];
+        const u64 m = pt.pinv[i];
+        u32 r1 = mod_small(lo, p, m);
+        u64 r2 = (u64)hi * pt.e64[i] + r1;
+        dst[(long)i * clen + base + lane] = mod_small(r2, p, m);
+    }
+}
+
+// ---------------------------------------------------------------- ICRT: residues -> raw (icrt, Base.cu:880-924)
+// value = sum_i ((x_i*b_i) mod p_i) * m_i  mod M, in [0, M).  Instead of a conditional multiword
+// subtract after every prime (104-word register array) the quotient q = floor(sum_i t_i/p_i) is
+// estimated in f64, q*M is folded into the column sums, and a single +-M fix-up pass makes the
+// result exact whatever the rounding of the estimate.
+struct IcrtTab {
+    const u32 *M;       // [W]
+    const u32 *mi;      // [np][W]
+    const u32 *bi;      // [np]
+    const double *rp;   // [np] 1/p_i
+};
+__global__ __launch_bounds__(64)
+void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
+            int np, int W, int mlen, int clen) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // tt[np][64] then out[W][64]
+    u32 *tt = sh;
+    u32 *out = sh + (long)np * 64;
+    const int lane = threadIdx.x;
+    const long base = (long)blockIdx.x * 64;
+    const int nvalid = (int)min((long)64, (long)mlen - base);
+    const bool live = lane < nvalid;
+    double alpha = 0.0;
+    for (int i = 0; i < np; ++i) {
+        u32 v = 0;
+        if (live) {
+            const u32 p = pt.p[i];
+            const u64 m = pt.pinv[i];
+            u32 x = mod_small(src[(long)i * clen + base + lane], p, m);
+            v = mod_small((u64)x * it.bi[i], p, m);
+        }
+        tt[i * 64 + lane] = v;
+        alpha += (double)v * it.rp[i];
+    }
+    const u32 q = (u32)alpha;            // floor; may be off by one either way -> fixed below
+    typedef __int128 i128;
+    i128 carry = 0;
+    for (int k = 0; k < W; ++k) {
+        unsigned __int128 col = 0;
+        for (int i = 0; i < np; ++i)
+            col += (u64)tt[i * 64 + lane] * it.mi[(long)i * W + k];
+        i128 total = carry + (i128)col - (i128)((u64)q * it.M[k]);
+        out[k * 64 + lane] = (u32)total;
+        carry = total >> 32;
+    }
+    // carry is now floor((S - q*M) / 2^(32W)): -1 => negative, 0 => in [0, 2^(32W))
+    int fix = 0;                          // +1: add M, -1: subtract M
+    if (carry < 0) fix = 1;
+    else {
+        bool ge = true;                   // out >= M ?
+        for (int k = W - 1; k >= 0; --k) {
+            u32 a = out[k * 64 + lane], b = it.M[k];
+            if (a != b) { ge = a > b; break; }
+        }
+        if (ge) fix = -1;
+    }
+    if (__any(fix != 0)) {
+        long long cy = 0;
+        for (int k = 0; k < W; ++k) {
+            long long t = (long long)out[k * 64 + lane] + (long long)fix * (long long)it.M[k] + cy;
+            out[k * 64 + lane] = (u32)t;
+            cy = t >> 32;
+        }
+    }
+    __syncthreads();
+    const long slab = (long)nvalid * W;
+    for (long e = lane; e < slab; e += 64) {
+        const int ci = (int)(e / W), k = (int)(e % W);
+        dst[base * W + e] = out[k * 64 + ci];
+    }
+}
+
+}  // namespace cuhe

@@ -1,0 +1,159 @@
+/*
+ * cuhe_hip.h -- C ABI of the MI355X (gfx950) large-polynomial backend.
+ *
+ * This is the drop-in boundary underneath cuHE's C++ API.  The reference has no
+ * C ABI (its Operations.h functions are C++-namespaced and CuHE.h carries NTL
+ * types); the functions below are what a `libcuHE` built on this backend binds:
+ * each one replaces the reference function cited next to it (file:line relative
+ * to the vernamlab/cuHE tree) with the same argument meaning (raw device
+ * pointers + logq / dev / stream).  No torch / NTL / C++ types cross this line.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CUHE_E* code otherwise
+ *     and records a message retrievable with cuhe_hip_last_error(); the C++
+ *     shim turns a non-zero status into the reference's "print file:line,
+ *     exit(-1)" behaviour (cuhe/Debug.h:39-46).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     are asynchronous on that stream unless stated; the C++ shim adds the
+ *     reference's per-op hipStreamSynchronize (cuhe/CuHE.cu:98,121,...).
+ *   - layouts: raw  u32[rawLen][W] coefficient-major LE words,
+ *     crt u32[np][crtLen] prime-major, ntt u64[np][nttLen]; level `lvl` uses
+ *     the first numCrtPrime-lvl primes; W = wordsCoeff(lvl).
+ *   - one operation in flight per device (library-owned scratch), exactly the
+ *     reference's contract (cuhe/Operations.cu:171-172,193-195).
+ */
+#ifndef CUHE_HIP_H
+#define CUHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUHE_OK 0
+#define CUHE_EINVAL (-1)   /* bad argument / wrong state */
+#define CUHE_EHIP (-2)     /* HIP runtime failure */
+#define CUHE_ENOTINIT (-3) /* cuhe_hip_init not called */
+
+/* cuhe/Parameters.h:34-62 (GlobalParameters), same field names */
+typedef struct {
+    int mSize, modLen, modLen2, rawLen, crtLen, nttLen;
+    int logCoeffMax, logCoeffMin, logCoeffCut;
+    int depth, modMsg, logMsg, wordsMsg;
+    int logRelin, numEvalKey;
+    int logCrtPrime, numCrtPrime;
+} cuhe_params_t;
+
+const char *cuhe_hip_last_error(void);
+const char *cuhe_hip_version(void);
+
+/* ---- parameters: setParameters / resetParameters (cuhe/CuHE.h:171,174; Parameters.cu:53-105) */
+int cuhe_hip_set_parameters(int d, int p, int w, int min, int cut, int m);
+int cuhe_hip_reset_parameters(void);
+int cuhe_hip_get_parameters(cuhe_params_t *out);
+/* per-level helpers (cuhe/Parameters.cu:107-145) */
+int cuhe_hip_num_crt_prime(int lvl);
+int cuhe_hip_log_coeff(int lvl);
+int cuhe_hip_words_coeff(int lvl);
+int cuhe_hip_num_eval_key(int lvl);
+int cuhe_hip_get_level(int logq);
+
+/* ---- devices: multiGPUs / numGPUs (cuhe/CuHE.h:161-163; DeviceManager.cu:36-45) */
+int cuhe_hip_multi_gpus(int num);
+int cuhe_hip_num_gpus(void);
+/* Bind the single-device context to HIP device `dev` (default 0).  Used by the
+ * one-process-per-GPU launcher so that rank r drives device r as "dev 0". */
+int cuhe_hip_set_device_base(int dev);
+
+/* ---- init: initCuHE (cuhe/CuHE.h:153; CuHE.cu:36-50 = initNtt + initCrt + initBarrett).
+ * modulus: monic integer polynomial, modLen+1 coefficients low-to-high
+ * (NULL => the cyclotomic polynomial Phi_m).  Synchronous. */
+int cuhe_hip_init(const int32_t *modulus, int ncoeffs);
+int cuhe_hip_shutdown(void);
+/* coefficient modulus q_lvl as little-endian bytes (initCuHE's ZZ* output, Operations.cu:157-160) */
+int cuhe_hip_get_coeff_modulus(int lvl, uint8_t *le_bytes, size_t cap, size_t *len);
+int cuhe_hip_get_crt_primes(uint32_t *out, int cap);
+/* which fused poly-reduction the context selected: 0 = generic NTT Barrett, 1 = x^n+1, 2 = prime m */
+int cuhe_hip_reduce_kind(void);
+/* force the generic Barrett path (tests) */
+int cuhe_hip_force_generic_reduce(int on);
+
+/* ---- allocator: startAllocator / stopAllocator (cuhe/CuHE.h:156,159; DeviceManager.cu:50-138) */
+int cuhe_hip_start_allocator(void);
+int cuhe_hip_stop_allocator(void);
+void *cuhe_hip_malloc(int dev, size_t bytes);
+int cuhe_hip_free(int dev, void *ptr);
+int cuhe_hip_memset_async(int dev, void *ptr, int value, size_t bytes, void *stream);
+int cuhe_hip_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes, void *stream);
+int cuhe_hip_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes, void *stream);
+int cuhe_hip_memcpy_d2d(int dev, void *dst, const void *src, size_t bytes, void *stream);
+/* moveTo / copyTo transport (cuhe/CuHE.cu:217-256: cudaMemcpyPeerAsync) */
+int cuhe_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, void *stream);
+int cuhe_hip_stream_sync(int dev, void *stream);
+
+/* ---- operation drivers (cuhe/Operations.h:60-108), same argument order */
+int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *stream);            /* Operations.cu:245 */
+int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *stream);           /* Operations.cu:254 */
+int cuhe_hip_crt_add(uint32_t *sum, const uint32_t *x, const uint32_t *y, int logq, int dev, void *stream);       /* :264 */
+int cuhe_hip_crt_add_int(uint32_t *sum, const uint32_t *x, unsigned a, int logq, int dev, void *stream);          /* :272 */
+int cuhe_hip_crt_add_nx1(uint32_t *sum, const uint32_t *x, const uint32_t *scalar, int logq, int dev, void *stream); /* :280 */
+int cuhe_hip_crt_mul_int(uint32_t *prod, const uint32_t *x, int a, int logq, int dev, void *stream);              /* :288 */
+int cuhe_hip_crt_mod_switch(uint32_t *dst, const uint32_t *src, int logq, int dev, void *stream);                 /* :296 */
+int cuhe_hip_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *stream);                /* Operations.cu:394 */
+int cuhe_hip_nttw(uint64_t *X, const uint32_t *x, int logq, int dev, void *stream);               /* Operations.cu:399 */
+int cuhe_hip_intt(uint32_t *x, const uint64_t *X, int logq, int dev, void *stream);               /* Operations.cu:419 */
+int cuhe_hip_intt_hold(const uint64_t *X, int logq, int dev, void *stream);                        /* Operations.cu:405 */
+int cuhe_hip_intt_double_deg(uint32_t *x, const uint64_t *X, int logq, int dev, void *stream);    /* Operations.cu:412 */
+int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *stream);           /* Operations.cu:429 */
+uint32_t *cuhe_hip_intt_result(int dev);                                                           /* Operations.cu:185 */
+int cuhe_hip_ntt_mul(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *stream);         /* :435 */
+int cuhe_hip_ntt_mul_nx1(uint64_t *z, const uint64_t *x, const uint64_t *scalar, int logq, int dev, void *stream); /* :441 */
+int cuhe_hip_ntt_add(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *stream);         /* :447 */
+int cuhe_hip_ntt_add_nx1(uint64_t *z, const uint64_t *x, const uint64_t *scalar, int logq, int dev, void *stream); /* :453 */
+/* barrett(dst, src, lvl, ...) and barrett(dst, lvl, ...) (Operations.cu:460-504); src = u32[np][nttLen] */
+int cuhe_hip_barrett(uint32_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
+int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *stream);
+
+/* single-polynomial forms _ntt / _nttw / _intt (cuhe/Operations.h:78-81) */
+int cuhe_hip_ntt_one(uint64_t *X, const uint32_t *x, int dev, void *stream);
+int cuhe_hip_nttw_one(uint64_t *X, const uint32_t *x, int coeffwords, int relinIdx, int dev, void *stream);
+int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void *stream);
+
+/* ---- relinearisation (cuhe/Relinearization.h; CuHE.h:178) */
+/* initRelinearization: evalkey = numEvalKey polynomials in raw layout at level 0,
+ * HOST memory u32[numEvalKey][rawLen][W0]; keys are converted once and stay in HBM. */
+int cuhe_hip_init_relin(const uint32_t *evalkey_raw_host);
+/* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst ntt u64[np][nttLen] */
+int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
+
+/* ---- batched transform primitives (the shape tests/test_ntt.cu:67-100 times):
+ * `batch` independent length-`len` transforms, len in {16384, 32768, 65536}. */
+/* forward: src u32[batch][src_stride] (only the first len/2 of each row are read, zero padded),
+ *          dst u64[batch][len], natural order. */
+int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride,
+                             int dev, void *stream);
+/* inverse: src u64[batch][len]; dst u32[batch][dst_stride], first `nstore` outputs of each row;
+ *          row b is reduced modulo primes[prime0 + b] of the initialised context. */
+int cuhe_hip_ntt_inv_batched(uint32_t *dst, const uint64_t *src, int len, int batch, long dst_stride,
+                             int nstore, int prime0, int dev, void *stream);
+/* standalone transform tables (no cuhe_hip_init needed): prepares twiddles + scratch for `len` on `dev` */
+int cuhe_hip_ntt_prepare(int len, int dev);
+/* batch chunk (transforms per launch pair) used to keep the pass-1 -> pass-2 slab cache resident; 0 = default */
+int cuhe_hip_set_ntt_chunk(int chunk);
+/* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
+ * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
+int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,
+                          float *ms_pass1, float *ms_pass2, float *ms_total);
+
+/* ---- field arithmetic test hooks (tests/test_ModP.cu:50-135): elementwise over n u64 */
+int cuhe_hip_modp_add(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *stream);
+int cuhe_hip_modp_sub(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *stream);
+int cuhe_hip_modp_mul(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *stream);
+int cuhe_hip_modp_shl(uint64_t *z, const uint64_t *x, int l, size_t n, int dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUHE_HIP_H */

@@ -13,6 +13,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef unsigned __int128 u128;
 
@@ -98,6 +101,19 @@ void orc_ntt_ext(uint64_t *dst, const uint32_t *src, int len) {
     for (int i = 0; i < len / 2; i++) dst[i] = src[i];
     for (int i = len / 2; i < len; i++) dst[i] = 0;
     fft_inplace(dst, len, root_of_len(len));
+}
+
+/* batch of independent transforms on `threads` host threads (bench.py cpu_baseline leg) */
+int orc_ntt_ext_batch(uint64_t *dst, const uint32_t *src, int len, int batch, int threads) {
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    used = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int b = 0; b < batch; b++)
+        orc_ntt_ext(dst + (size_t)b * len, src + (size_t)b * (len / 2), len);
+    return used;
 }
 
 uint64_t orc_len_inv(int len) { return orc_pow_modP((uint64_t)len, ORC_P - 2); }

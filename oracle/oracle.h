@@ -43,6 +43,8 @@ uint64_t orc_pow_modP(uint64_t x, uint64_t e);
 void orc_ntt_naive(uint64_t *dst, const uint32_t *src, int len);
 /* same values, O(len log len) */
 void orc_ntt_ext(uint64_t *dst, const uint32_t *src, int len);
+/* `batch` independent orc_ntt_ext on `threads` OpenMP threads (0 = all); returns threads used */
+int orc_ntt_ext_batch(uint64_t *dst, const uint32_t *src, int len, int batch, int threads);
 /* full-length forward transform of u64 input (helper) */
 void orc_ntt_full(uint64_t *dst, const uint64_t *src, int len);
 /* x[j] = (len^-1 * sum_i X[i] w^(-ij) mod P) mod p  -- cuhe/Base.cu:438-490 */

@@ -51,6 +51,7 @@ def lib():
         L.orc_len_inv.restype = u64; L.orc_len_inv.argtypes = [i32]
         for f in ("orc_ntt_naive", "orc_ntt_ext", "orc_ntt_full"):
             getattr(L, f).restype = None; getattr(L, f).argtypes = [vp, vp, i32]
+        L.orc_ntt_ext_batch.restype = i32; L.orc_ntt_ext_batch.argtypes = [vp, vp, i32, i32, i32]
         L.orc_intt_modp.restype = None; L.orc_intt_modp.argtypes = [vp, vp, i32, u32]
         L.orc_set_param.restype = i32
         L.orc_set_param.argtypes = [C.POINTER(Params)] + [i32] * 6
@@ -108,6 +109,15 @@ def ntt_ext(x, length):
     out = np.empty(length, dtype=np.uint64)
     lib().orc_ntt_ext(_p(out), _p(x), length)
     return out
+
+
+def ntt_ext_batch(x, length, threads=0):
+    """x: u32[batch][length/2] -> (u64[batch][length], threads used)"""
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    batch = x.shape[0]
+    out = np.empty((batch, length), dtype=np.uint64)
+    used = lib().orc_ntt_ext_batch(_p(out), _p(x), length, batch, threads)
+    return out, used
 
 
 def intt_modp(X, length, p):

@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/cuhe_hip.h declares, and its host-only logic (parameter derivation,
+per-level helpers: cuhe/Parameters.cu:53-145) matches the golden fixtures.
+No compute call is made here (no GPU in this container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as ge
+    from cuhe_amd import build
+    if build.stale():
+        ge.build()
+    from cuhe_amd import capi
+    return capi
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "cuhe_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cuhe_hip_\w+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(capi):
+    syms = declared_symbols()
+    assert len(syms) > 50
+    for s in syms:
+        assert hasattr(capi.lib, s), "missing export: " + s
+        assert s in capi.SIGNATURES, "python binding lacks: " + s
+    assert sorted(capi.SIGNATURES) == syms
+
+
+def test_version_and_error_string(capi):
+    assert b"gfx950" in capi.lib.cuhe_hip_version()
+    assert capi.lib.cuhe_hip_set_parameters(0, 2, 1, 61, 20, 8191) != 0
+    assert b"setParameters" in capi.lib.cuhe_hip_last_error()
+
+
+@pytest.mark.parametrize("name", ["dhs_simple", "prince", "toy1155", "pow2_16384", "c3_65536", "c4_65536"])
+def test_parameter_derivation(capi, golden, name):
+    g = golden("params.json")[name]
+    capi.lib.cuhe_hip_reset_parameters()
+    capi.check(capi.lib.cuhe_hip_set_parameters(*g["args"]))
+    q = capi.get_params()
+    for k, v in g["params"].items():
+        assert getattr(q, k) == v, k
+    for lvl, rec in g["levels"].items():
+        assert capi.lib.cuhe_hip_log_coeff(int(lvl)) == rec["logCoeff"]
+        assert capi.lib.cuhe_hip_words_coeff(int(lvl)) == rec["wordsCoeff"]
+        if "numEvalKey" in rec and q.logRelin:
+            assert capi.lib.cuhe_hip_num_eval_key(int(lvl)) == rec["numEvalKey"]
+            assert capi.lib.cuhe_hip_num_crt_prime(int(lvl)) == rec["numCrtPrime"]
+            assert capi.lib.cuhe_hip_get_level(rec["logCoeff"]) == int(lvl)
+    assert capi.lib.cuhe_hip_get_level(q.logMsg) == -1
+    capi.lib.cuhe_hip_reset_parameters()
+
+
+def test_unsupported_ring_is_rejected(capi):
+    # phi(m) > 32768 would need a 128K-point transform (cuhe/Base.cu:59-62 supports 16K/32K/64K only)
+    assert capi.lib.cuhe_hip_set_parameters(2, 2, 16, 50, 25, 131072) != 0
+    capi.lib.cuhe_hip_reset_parameters()
+
+
+def test_drivers_fail_loudly_without_init(capi):
+    assert capi.lib.cuhe_hip_get_crt_primes(None, 0) != 0
+    assert b"not initialised" in capi.lib.cuhe_hip_last_error()
