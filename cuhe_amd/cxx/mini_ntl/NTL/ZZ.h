@@ -1,0 +1,158 @@
+// mini_ntl/NTL/ZZ.h -- FALLBACK ONLY.  A tiny subset of NTL's ZZ (signed big
+// integer) so that this repository's C++ API layer (cuhe_amd/cxx/CuHE.h) can be
+// compiled and tested on machines without NTL.  When the real NTL is installed
+// its headers are found first (see cuhe_amd/cxx/Makefile) and this directory is
+// not on the include path.  Only what CuHE.h / the tests need is provided.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#define NTL_CLIENT using namespace std; using namespace NTL;
+#define CUHE_MINI_NTL 1
+
+namespace NTL {
+
+class ZZ {
+public:
+    std::vector<uint32_t> m;   // magnitude, little endian, no leading zeros
+    bool neg = false;
+    ZZ() {}
+    ZZ(long v) { set(v); }
+    void set(long v) {
+        m.clear(); neg = v < 0;
+        unsigned long u = neg ? 0UL - (unsigned long)v : (unsigned long)v;
+        while (u) { m.push_back((uint32_t)u); u >>= 32; }
+    }
+    bool zero() const { return m.empty(); }
+    void trim() { while (!m.empty() && m.back() == 0) m.pop_back(); if (m.empty()) neg = false; }
+    static int cmpmag(const ZZ &a, const ZZ &b) {
+        if (a.m.size() != b.m.size()) return a.m.size() < b.m.size() ? -1 : 1;
+        for (size_t i = a.m.size(); i-- > 0;) if (a.m[i] != b.m[i]) return a.m[i] < b.m[i] ? -1 : 1;
+        return 0;
+    }
+    static ZZ addmag(const ZZ &a, const ZZ &b) {
+        ZZ r; uint64_t c = 0; size_t n = std::max(a.m.size(), b.m.size());
+        for (size_t i = 0; i < n; ++i) { c += (i < a.m.size() ? a.m[i] : 0); c += (i < b.m.size() ? b.m[i] : 0); r.m.push_back((uint32_t)c); c >>= 32; }
+        if (c) r.m.push_back((uint32_t)c);
+        return r;
+    }
+    static ZZ submag(const ZZ &a, const ZZ &b) {   // |a| >= |b|
+        ZZ r; int64_t br = 0;
+        for (size_t i = 0; i < a.m.size(); ++i) {
+            int64_t t = (int64_t)a.m[i] - (i < b.m.size() ? b.m[i] : 0) - br;
+            br = t < 0; if (t < 0) t += (1LL << 32);
+            r.m.push_back((uint32_t)t);
+        }
+        r.trim(); return r;
+    }
+    static ZZ add(const ZZ &a, const ZZ &b) {
+        if (a.neg == b.neg) { ZZ r = addmag(a, b); r.neg = a.neg; r.trim(); return r; }
+        int c = cmpmag(a, b);
+        if (c == 0) return ZZ();
+        ZZ r = c > 0 ? submag(a, b) : submag(b, a);
+        r.neg = c > 0 ? a.neg : b.neg; r.trim(); return r;
+    }
+    static ZZ mul(const ZZ &a, const ZZ &b) {
+        ZZ r; if (a.zero() || b.zero()) return r;
+        r.m.assign(a.m.size() + b.m.size(), 0);
+        for (size_t i = 0; i < a.m.size(); ++i) {
+            uint64_t c = 0;
+            for (size_t j = 0; j < b.m.size(); ++j) { uint64_t t = (uint64_t)a.m[i] * b.m[j] + r.m[i + j] + c; r.m[i + j] = (uint32_t)t; c = t >> 32; }
+            r.m[i + b.m.size()] += (uint32_t)c;
+        }
+        r.neg = a.neg != b.neg; r.trim(); return r;
+    }
+    int bits() const { if (m.empty()) return 0; int n = 0; uint32_t t = m.back(); while (t) { ++n; t >>= 1; } return (int)(m.size() - 1) * 32 + n; }
+    bool bit(int i) const { size_t w = (size_t)i / 32; return w < m.size() && ((m[w] >> (i % 32)) & 1); }
+    void shl1() { uint32_t c = 0; for (auto &x : m) { uint32_t n = x >> 31; x = (x << 1) | c; c = n; } if (c) m.push_back(c); }
+    // floor division (NTL semantics: remainder has the sign of the divisor)
+    static void divrem(const ZZ &a, const ZZ &b, ZZ &q, ZZ &r) {
+        ZZ A = a, B = b; A.neg = B.neg = false;
+        q = ZZ(); r = ZZ();
+        q.m.assign(A.m.size(), 0);
+        for (int i = A.bits() - 1; i >= 0; --i) {
+            r.shl1(); if (A.bit(i)) { if (r.m.empty()) r.m.push_back(1); else r.m[0] |= 1; }
+            if (cmpmag(r, B) >= 0) { r = submag(r, B); q.m[i / 32] |= 1u << (i % 32); }
+        }
+        q.trim(); r.trim();
+        if (a.neg != b.neg) {         // truncated -> floor
+            q.neg = !q.zero();
+            if (!r.zero()) { q = add(q, ZZ(-1)); r = submag(B, r); }
+        }
+        if (!r.zero()) r.neg = b.neg;
+    }
+};
+
+inline ZZ operator+(const ZZ &a, const ZZ &b) { return ZZ::add(a, b); }
+inline ZZ operator-(const ZZ &a) { ZZ r = a; if (!r.zero()) r.neg = !r.neg; return r; }
+inline ZZ operator-(const ZZ &a, const ZZ &b) { return ZZ::add(a, -b); }
+inline ZZ operator*(const ZZ &a, const ZZ &b) { return ZZ::mul(a, b); }
+inline ZZ operator/(const ZZ &a, const ZZ &b) { ZZ q, r; ZZ::divrem(a, b, q, r); return q; }
+inline ZZ operator%(const ZZ &a, const ZZ &b) { ZZ q, r; ZZ::divrem(a, b, q, r); return r; }
+inline ZZ &operator+=(ZZ &a, const ZZ &b) { a = a + b; return a; }
+inline ZZ &operator-=(ZZ &a, const ZZ &b) { a = a - b; return a; }
+inline ZZ &operator*=(ZZ &a, const ZZ &b) { a = a * b; return a; }
+inline ZZ &operator%=(ZZ &a, const ZZ &b) { a = a % b; return a; }
+inline ZZ &operator/=(ZZ &a, const ZZ &b) { a = a / b; return a; }
+inline int compare(const ZZ &a, const ZZ &b) {
+    if (a.neg != b.neg) return a.neg ? -1 : 1;
+    int c = ZZ::cmpmag(a, b); return a.neg ? -c : c;
+}
+inline bool operator==(const ZZ &a, const ZZ &b) { return compare(a, b) == 0; }
+inline bool operator!=(const ZZ &a, const ZZ &b) { return compare(a, b) != 0; }
+inline bool operator<(const ZZ &a, const ZZ &b) { return compare(a, b) < 0; }
+inline bool operator>(const ZZ &a, const ZZ &b) { return compare(a, b) > 0; }
+inline bool operator<=(const ZZ &a, const ZZ &b) { return compare(a, b) <= 0; }
+inline bool operator>=(const ZZ &a, const ZZ &b) { return compare(a, b) >= 0; }
+
+inline ZZ to_ZZ(long v) { return ZZ(v); }
+inline ZZ to_ZZ(int v) { return ZZ((long)v); }
+inline ZZ to_ZZ(unsigned v) { return ZZ((long)v); }
+inline ZZ to_ZZ(unsigned long v) { ZZ r; while (v) { r.m.push_back((uint32_t)v); v >>= 32; } return r; }
+inline ZZ to_ZZ(const char *s) {
+    ZZ r; bool neg = false; if (*s == '-') { neg = true; ++s; }
+    for (; *s; ++s) r = r * ZZ(10) + ZZ(*s - '0');
+    if (neg) r = -r; return r;
+}
+inline long to_long(const ZZ &a) { unsigned long v = 0; for (size_t i = a.m.size(); i-- > 0;) v = (v << 32) | a.m[i]; return a.neg ? -(long)v : (long)v; }
+inline void conv(unsigned &x, const ZZ &a) { x = a.m.empty() ? 0u : a.m[0]; }
+inline void conv(long &x, const ZZ &a) { x = to_long(a); }
+inline void conv(ZZ &x, long a) { x = ZZ(a); }
+inline long NumBits(const ZZ &a) { return a.bits(); }
+inline long IsZero(const ZZ &a) { return a.zero(); }
+inline void clear(ZZ &a) { a = ZZ(); }
+inline ZZ power(const ZZ &a, long e) { ZZ r(1), b = a; while (e) { if (e & 1) r = r * b; b = b * b; e >>= 1; } return r; }
+inline ZZ power2_ZZ(long e) { ZZ r; r.m.assign(e / 32 + 1, 0); r.m[e / 32] = 1u << (e % 32); return r; }
+// BytesFromZZ: little-endian bytes of |a|, zero padded / truncated to n (NTL semantics)
+inline void BytesFromZZ(unsigned char *p, const ZZ &a, long n) {
+    for (long i = 0; i < n; ++i) { size_t w = (size_t)i / 4; p[i] = w < a.m.size() ? (unsigned char)(a.m[w] >> (8 * (i % 4))) : 0; }
+}
+inline ZZ ZZFromBytes(const unsigned char *p, long n) {
+    ZZ r; r.m.assign((n + 3) / 4, 0);
+    for (long i = 0; i < n; ++i) r.m[i / 4] |= (uint32_t)p[i] << (8 * (i % 4));
+    r.trim(); return r;
+}
+inline std::ostream &operator<<(std::ostream &os, const ZZ &a) {
+    if (a.zero()) return os << "0";
+    std::string s; ZZ t = a; t.neg = false; ZZ ten(10);
+    while (!t.zero()) { ZZ q, r; ZZ::divrem(t, ten, q, r); s.push_back((char)('0' + (r.m.empty() ? 0 : r.m[0]))); t = q; }
+    if (a.neg) s.push_back('-');
+    std::reverse(s.begin(), s.end());
+    return os << s;
+}
+// deterministic xorshift stream (stand-in for NTL's PRG in tests)
+inline uint64_t &mini_seed() { static uint64_t s = 0x9E3779B97F4A7C15ULL; return s; }
+inline void SetSeed(const ZZ &s) { mini_seed() = (uint64_t)to_long(s) * 2654435761ULL + 1; }
+inline uint64_t mini_next() { uint64_t &s = mini_seed(); s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+inline ZZ RandomBnd(const ZZ &n) {
+    ZZ r; r.m.assign(n.m.size() + 1, 0);
+    for (auto &x : r.m) x = (uint32_t)mini_next();
+    r.trim(); return r % n;
+}
+inline ZZ RandomBits_ZZ(long l) { return RandomBnd(power2_ZZ(l)); }
+
+}  // namespace NTL

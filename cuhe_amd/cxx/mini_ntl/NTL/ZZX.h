@@ -1,0 +1,58 @@
+// mini_ntl/NTL/ZZX.h -- FALLBACK ONLY (see ZZ.h): polynomial over ZZ, low-to-high.
+#pragma once
+#include "ZZ.h"
+
+namespace NTL {
+
+class ZZX {
+public:
+    std::vector<ZZ> rep;
+    void normalize() { while (!rep.empty() && rep.back().zero()) rep.pop_back(); }
+};
+inline long deg(const ZZX &a) { return (long)a.rep.size() - 1; }
+inline const ZZ &coeff(const ZZX &a, long i) { static const ZZ z; return (i < 0 || i >= (long)a.rep.size()) ? z : a.rep[i]; }
+inline void SetCoeff(ZZX &a, long i, const ZZ &v) { if (i >= (long)a.rep.size()) a.rep.resize(i + 1); a.rep[i] = v; a.normalize(); }
+inline void SetCoeff(ZZX &a, long i, long v) { SetCoeff(a, i, ZZ(v)); }
+inline void SetCoeff(ZZX &a, long i) { SetCoeff(a, i, ZZ(1)); }
+inline void clear(ZZX &a) { a.rep.clear(); }
+inline bool operator==(const ZZX &a, const ZZX &b) {
+    if (a.rep.size() != b.rep.size()) return false;
+    for (size_t i = 0; i < a.rep.size(); ++i) if (a.rep[i] != b.rep[i]) return false;
+    return true;
+}
+inline bool operator!=(const ZZX &a, const ZZX &b) { return !(a == b); }
+inline ZZX operator+(const ZZX &a, const ZZX &b) {
+    ZZX r; r.rep.resize(std::max(a.rep.size(), b.rep.size()));
+    for (size_t i = 0; i < r.rep.size(); ++i) r.rep[i] = coeff(a, i) + coeff(b, i);
+    r.normalize(); return r;
+}
+inline ZZX operator-(const ZZX &a, const ZZX &b) {
+    ZZX r; r.rep.resize(std::max(a.rep.size(), b.rep.size()));
+    for (size_t i = 0; i < r.rep.size(); ++i) r.rep[i] = coeff(a, i) - coeff(b, i);
+    r.normalize(); return r;
+}
+inline ZZX operator*(const ZZX &a, const ZZX &b) {       // schoolbook: tests only
+    ZZX r; if (a.rep.empty() || b.rep.empty()) return r;
+    r.rep.assign(a.rep.size() + b.rep.size() - 1, ZZ());
+    for (size_t i = 0; i < a.rep.size(); ++i) if (!a.rep[i].zero())
+        for (size_t j = 0; j < b.rep.size(); ++j) if (!b.rep[j].zero()) r.rep[i + j] += a.rep[i] * b.rep[j];
+    r.normalize(); return r;
+}
+// remainder modulo a MONIC polynomial
+inline ZZX operator%(const ZZX &a, const ZZX &m) {
+    ZZX r = a; long n = deg(m);
+    for (long k = deg(r); k >= n; --k) {
+        ZZ c = coeff(r, k);
+        if (c.zero()) continue;
+        for (long i = 0; i <= n; ++i) if (!m.rep[i].zero()) r.rep[k - n + i] -= c * m.rep[i];
+    }
+    r.normalize(); return r;
+}
+inline ZZX &operator%=(ZZX &a, const ZZX &m) { a = a % m; return a; }
+inline ZZX &operator+=(ZZX &a, const ZZX &b) { a = a + b; return a; }
+inline ZZX &operator*=(ZZX &a, const ZZX &b) { a = a * b; return a; }
+inline std::ostream &operator<<(std::ostream &os, const ZZX &a) {
+    os << "["; for (size_t i = 0; i < a.rep.size(); ++i) os << (i ? " " : "") << a.rep[i]; return os << "]";
+}
+
+}  // namespace NTL
