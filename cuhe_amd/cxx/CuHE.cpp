@@ -1,0 +1,451 @@
+// CuHE.cpp -- host side of the public API (CuHE.h) on top of the C ABI.
+// Restates the behaviour of cuhe/CuHE.cu, cuhe/Operations.cu (driver half),
+// cuhe/Parameters.cu, cuhe/DeviceManager.cu and cuhe/Relinearization.cu of the
+// reference: same state machine, same argument checks and messages, but every
+// device action is a call into libcuhe_hip.so.
+#include "CuHE.h"
+#include "Debug.h"
+#include "DeviceManager.h"
+#include "Operations.h"
+#include "Relinearization.h"
+
+#include <cstring>
+#include <exception>
+#include <vector>
+
+namespace cuHE {
+
+// ------------------------------------------------------------------ parameters
+GlobalParameters param;
+
+static void pullParams() {
+	cuhe_params_t q;
+	CSC(cuhe_hip_get_parameters(&q));
+	param.mSize = q.mSize; param.modLen = q.modLen; param.modLen2 = q.modLen2;
+	param.rawLen = q.rawLen; param.crtLen = q.crtLen; param.nttLen = q.nttLen;
+	param.logCoeffMax = q.logCoeffMax; param.logCoeffMin = q.logCoeffMin; param.logCoeffCut = q.logCoeffCut;
+	param.depth = q.depth; param.modMsg = q.modMsg; param.logMsg = q.logMsg; param.wordsMsg = q.wordsMsg;
+	param.logRelin = q.logRelin; param.numEvalKey = q.numEvalKey;
+	param.logCrtPrime = q.logCrtPrime; param.numCrtPrime = q.numCrtPrime;
+}
+void setParam(int d, int p, int w, int min, int cut, int m) {
+	CSC(cuhe_hip_set_parameters(d, p, w, min, cut, m));
+	pullParams();
+}
+void resetParam() {
+	CSC(cuhe_hip_reset_parameters());
+	pullParams();
+}
+int GlobalParameters::_numCrtPrime(int lvl) {
+	if (lvl != -1 && lvl >= depth) {           // cuhe/Parameters.cu:110-113
+		cout << "Error: numCrtPrime(lvl) has lvl: " << lvl << endl;
+		exit(0);
+	}
+	return cuhe_hip_num_crt_prime(lvl);
+}
+int GlobalParameters::_logCoeff(int lvl) {
+	if (lvl > depth) {                         // cuhe/Parameters.cu:125-128
+		cout << "Error: lvl cannot be more than depth!" << endl;
+		exit(-1);
+	}
+	return cuhe_hip_log_coeff(lvl);
+}
+int GlobalParameters::_wordsCoeff(int lvl) { return cuhe_hip_words_coeff(lvl); }
+int GlobalParameters::_numEvalKey(int lvl) { return cuhe_hip_num_eval_key(lvl); }
+int GlobalParameters::_getLevel(int logq) { return cuhe_hip_get_level(logq); }
+
+// ------------------------------------------------------------------ devices / allocator
+static thread_local int tlsDevice = 0;
+void setNumDevices(int val) { CSC(cuhe_hip_multi_gpus(val)); }
+int numDevices() { return cuhe_hip_num_gpus(); }
+static bool allocatorOn = false;
+void bootDeviceAllocator(size_t, unsigned long) { CSC(cuhe_hip_start_allocator()); allocatorOn = true; }
+void haltDeviceAllocator() { CSC(cuhe_hip_stop_allocator()); allocatorOn = false; }
+bool deviceAllocatorIsOn() { return allocatorOn; }
+void selectDevice(int dev) { tlsDevice = dev; }
+int selectedDevice() { return tlsDevice; }
+void *deviceMalloc(size_t size) {
+	void *p = cuhe_hip_malloc(tlsDevice, size);
+	if (!p) CSC(CUHE_EHIP);
+	return p;
+}
+void deviceFree(void *ptr) { CSC(cuhe_hip_free(tlsDevice, ptr)); }
+
+static void *devAlloc(int dev, size_t bytes) {
+	void *p = cuhe_hip_malloc(dev, bytes);
+	if (!p) CSC(CUHE_EHIP);
+	return p;
+}
+
+// ------------------------------------------------------------------ Operations.h drivers
+static vector<ZZ> coeffModuli;
+void getCoeffModuli(ZZ *dst) { for (int i = 0; i < param.depth; i++) dst[i] = coeffModuli[i]; }
+void initCrt(ZZ *coeffModulus) { getCoeffModuli(coeffModulus); }
+void initNtt() {}
+void initBarrett(ZZX) {}
+void loadIcrtConst(int, int, cudaStream_t) {}   // every level's constants stay resident (no re-upload, no sync)
+void genCrtPrimes() {}
+void genCoeffModuli() {}
+void genCrtInvPrimes() {}
+void genIcrtByLevel(int) {}
+void genIcrt() {}
+void setPolyModulus(ZZX) {}
+void createBarrettTemporySpace() {}
+uint32 *inttResult(int dev) { return cuhe_hip_intt_result(dev); }
+
+#define U64P(p) ((uint64_t *)(p))
+void crt(uint32 *dst, uint32 *src, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt(dst, src, logq, dev, st)); }
+void icrt(uint32 *dst, uint32 *src, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_icrt(dst, src, logq, dev, st)); }
+void crtAdd(uint32 *sum, uint32 *x, uint32 *y, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt_add(sum, x, y, logq, dev, st)); }
+void crtAddInt(uint32 *sum, uint32 *x, unsigned a, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt_add_int(sum, x, a, logq, dev, st)); }
+void crtAddNX1(uint32 *sum, uint32 *x, uint32 *s, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt_add_nx1(sum, x, s, logq, dev, st)); }
+void crtMulInt(uint32 *prod, uint32 *x, int a, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt_mul_int(prod, x, a, logq, dev, st)); }
+void crtModSwitch(uint32 *dst, uint32 *src, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt_mod_switch(dst, src, logq, dev, st)); }
+void _ntt(uint64 *X, uint32 *x, int dev, cudaStream_t st) { CSC(cuhe_hip_ntt_one(U64P(X), x, dev, st)); }
+void _nttw(uint64 *X, uint32 *x, int coeffwords, int relinIdx, int dev, cudaStream_t st) { CSC(cuhe_hip_nttw_one(U64P(X), x, coeffwords, relinIdx, dev, st)); }
+void _intt(uint32 *x, uint64 *X, int crtidx, int dev, cudaStream_t st) { CSC(cuhe_hip_intt_one(x, U64P(X), crtidx, dev, st)); }
+void ntt(uint64 *X, uint32 *x, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_ntt(U64P(X), x, logq, dev, st)); }
+void nttw(uint64 *X, uint32 *x, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_nttw(U64P(X), x, logq, dev, st)); }
+void intt(uint32 *x, uint64 *X, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_intt(x, U64P(X), logq, dev, st)); }
+void inttHold(uint64 *X, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_intt_hold(U64P(X), logq, dev, st)); }
+void inttDoubleDeg(uint32 *x, uint64 *X, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_intt_double_deg(x, U64P(X), logq, dev, st)); }
+void inttMod(uint32 *x, uint64 *X, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_intt_mod(x, U64P(X), logq, dev, st)); }
+void nttMul(uint64 *z, uint64 *y, uint64 *x, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_ntt_mul(U64P(z), U64P(y), U64P(x), logq, dev, st)); }
+void nttMulNX1(uint64 *z, uint64 *x, uint64 *s, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_ntt_mul_nx1(U64P(z), U64P(x), U64P(s), logq, dev, st)); }
+void nttAdd(uint64 *z, uint64 *y, uint64 *x, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_ntt_add(U64P(z), U64P(y), U64P(x), logq, dev, st)); }
+void nttAddNX1(uint64 *z, uint64 *x, uint64 *s, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_ntt_add_nx1(U64P(z), U64P(x), U64P(s), logq, dev, st)); }
+void barrett(uint32 *dst, uint32 *src, int lvl, int dev, cudaStream_t st) { CSC(cuhe_hip_barrett(dst, src, lvl, dev, st)); }
+void barrett(uint32 *dst, int lvl, int dev, cudaStream_t st) { CSC(cuhe_hip_barrett_hold(dst, lvl, dev, st)); }
+
+// ------------------------------------------------------------------ relinearisation
+void initRelin(ZZX *evalkey) {
+	// raw layout at level 0: u32[numEvalKey][rawLen][W0], little-endian words (cuhe/CuHE.cu:324-326)
+	const int W0 = param._wordsCoeff(0);
+	vector<uint32> host((size_t)param.numEvalKey * param.rawLen * W0, 0);
+	for (int k = 0; k < param.numEvalKey; k++)
+		for (int i = 0; i < param.rawLen; i++)
+			BytesFromZZ((uint8 *)&host[((size_t)k * param.rawLen + i) * W0], coeff(evalkey[k], i), W0 * sizeof(uint32));
+	CSC(cuhe_hip_init_relin(host.data()));
+}
+void relinearization(uint64 *dst, uint32 *src, int lvl, int dev, cudaStream_t st) {
+	CSC(cuhe_hip_relinearization(U64P(dst), src, lvl, dev, st));
+}
+
+// ------------------------------------------------------------------ library init
+void setParameters(int d, int p, int w, int min, int cut, int m) { setParam(d, p, w, min, cut, m); }
+void resetParameters() { resetParam(); }
+void multiGPUs(int num) { setNumDevices(num); }
+int numGPUs() { return numDevices(); }
+void startAllocator() { bootDeviceAllocator((size_t)param.numCrtPrime * param.nttLen * sizeof(uint64)); }
+void stopAllocator() { haltDeviceAllocator(); }
+void initRelinearization(ZZX *evalkey) { initRelin(evalkey); }
+
+void initCuHE(ZZ *coeffMod_, ZZX modulus) {
+	// polynomial modulus as small signed integers, low to high, monic of degree modLen
+	vector<int32_t> mod(param.modLen + 1, 0);
+	for (int i = 0; i <= param.modLen; i++) {
+		ZZ c = coeff(modulus, i);
+		long v; conv(v, c);
+		mod[i] = (int32_t)v;
+	}
+	CSC(cuhe_hip_init(mod.data(), (int)mod.size()));
+	coeffModuli.assign(param.depth, ZZ());
+	vector<uint8> buf(4096);
+	for (int lvl = 0; lvl < param.depth; lvl++) {
+		size_t n = 0;
+		CSC(cuhe_hip_get_coeff_modulus(lvl, buf.data(), buf.size(), &n));
+		coeffModuli[lvl] = ZZFromBytes(buf.data(), (long)n);
+	}
+	initCrt(coeffMod_);
+}
+
+// ------------------------------------------------------------------ CuPolynomial
+static void misuse(const char *msg) { cout << msg << endl; terminate(); }
+
+CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), rRep_(NULL), cRep_(NULL), nRep_(NULL) { clear(zRep_); }
+CuPolynomial::~CuPolynomial() { reset(); }
+void CuPolynomial::reset() {
+	clear(zRep_);
+	if (rRep_ != NULL) rRepFree();
+	if (cRep_ != NULL) cRepFree();
+	if (nRep_ != NULL) nRepFree();
+	isProd_ = false; logq_ = -1; domain_ = -1; device_ = -1;
+}
+void CuPolynomial::logq(int val) { logq_ = val; }
+void CuPolynomial::domain(int val) { domain_ = val; }
+void CuPolynomial::device(int val) { device_ = val; }
+void CuPolynomial::isProd(bool val) { isProd_ = val; }
+void CuPolynomial::zRep(ZZX val) { zRep_ = val; }
+void CuPolynomial::rRep(uint32 *val) { rRep_ = val; }
+void CuPolynomial::cRep(uint32 *val) { cRep_ = val; }
+void CuPolynomial::nRep(uint64 *val) { nRep_ = val; }
+int CuPolynomial::logq() { return logq_; }
+int CuPolynomial::domain() { return domain_; }
+int CuPolynomial::device() { return device_; }
+bool CuPolynomial::isProd() { return isProd_; }
+ZZX CuPolynomial::zRep() { return zRep_; }
+uint32 *CuPolynomial::rRep() { return rRep_; }
+uint32 *CuPolynomial::cRep() { return cRep_; }
+uint64 *CuPolynomial::nRep() { return nRep_; }
+int CuPolynomial::coeffWords() { return (logq_ + 31) / 32; }
+size_t CuPolynomial::rRepSize() { return (size_t)param.rawLen * coeffWords() * sizeof(uint32); }
+
+// with the pooled allocator every representation is one fixed-size block (cuhe/CuHE.cu:469,477,485)
+static size_t poolBlock() { return (size_t)param.numCrtPrime * param.nttLen * sizeof(uint64); }
+void CuPolynomial::rRepCreate(cudaStream_t st) {
+	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
+	CSC(cuhe_hip_memset_async(device_, rRep_, 0, rRepSize(), st));
+}
+void CuPolynomial::cRepCreate(cudaStream_t st) {
+	cRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : cRepSize());
+	CSC(cuhe_hip_memset_async(device_, cRep_, 0, cRepSize(), st));
+}
+void CuPolynomial::nRepCreate(cudaStream_t st) {
+	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize());
+	CSC(cuhe_hip_memset_async(device_, nRep_, 0, nRepSize(), st));
+}
+void CuPolynomial::rRepFree() { CSC(cuhe_hip_free(device_, rRep_)); rRep_ = NULL; }
+void CuPolynomial::cRepFree() { CSC(cuhe_hip_free(device_, cRep_)); cRep_ = NULL; }
+void CuPolynomial::nRepFree() { CSC(cuhe_hip_free(device_, nRep_)); nRep_ = NULL; }
+
+void CuPolynomial::z2r(cudaStream_t st) {
+	if (domain_ != 0) { printf("Error: Not in domain ZZX!\n"); terminate(); }
+	rRepCreate(st);
+	const int W = coeffWords();
+	vector<uint32> host((size_t)param.rawLen * W, 0);
+	const long top = deg(zRep_);
+	for (long i = 0; i <= top && i < param.rawLen; i++)      // BytesFromZZ takes |coeff|: inputs are non-negative (CuHE.cu:325)
+		BytesFromZZ((uint8 *)&host[(size_t)i * W], coeff(zRep_, i), W * sizeof(uint32));
+	CSC(cuhe_hip_memcpy_h2d(device_, rRep_, host.data(), rRepSize(), st));
+	CSC(cuhe_hip_stream_sync(device_, st));
+	clear(zRep_);
+	domain_ = 1;
+}
+void CuPolynomial::r2z(cudaStream_t st) {
+	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }
+	const int W = coeffWords();
+	vector<uint32> host((size_t)param.rawLen * W);
+	CSC(cuhe_hip_memcpy_d2h(device_, host.data(), rRep_, rRepSize(), st));
+	CSC(cuhe_hip_stream_sync(device_, st));
+	clear(zRep_);
+	for (int i = param.modLen - 1; i >= 0; i--)               // high to low: one resize
+		SetCoeff(zRep_, i, ZZFromBytes((uint8 *)&host[(size_t)i * W], W * sizeof(uint32)));
+	rRepFree();
+	domain_ = 0;
+}
+void CuPolynomial::r2c(cudaStream_t st) {
+	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }
+	if (logq_ > param.logCrtPrime) {
+		cRepCreate(st);
+		crt(cRep_, rRep_, logq_, device_, st);
+		CSC(cuhe_hip_stream_sync(device_, st));
+		rRepFree();
+	} else {                                                   // one word per coefficient: RAW and CRT coincide
+		cRep_ = rRep_; rRep_ = NULL;
+	}
+	domain_ = 2;
+}
+void CuPolynomial::c2r(cudaStream_t st) {
+	if (domain_ != 2) { printf("Error: Not in domain CRT!\n"); terminate(); }
+	if (logq_ > param.logCrtPrime) {
+		rRepCreate(st);
+		icrt(rRep_, cRep_, logq_, device_, st);
+		CSC(cuhe_hip_stream_sync(device_, st));
+		cRepFree();
+	} else {
+		rRep_ = cRep_; cRep_ = NULL;
+	}
+	domain_ = 1;
+}
+void CuPolynomial::c2n(cudaStream_t st) {
+	if (domain_ != 2) { printf("Error: Not in domain CRT!\n"); terminate(); }
+	nRepCreate(st);
+	ntt(nRep_, cRep_, logq_, device_, st);
+	CSC(cuhe_hip_stream_sync(device_, st));
+	cRepFree();
+	domain_ = 3;
+}
+void CuPolynomial::n2c(cudaStream_t st) {
+	if (domain_ != 3) { printf("Error: Not in domain NTT!\n"); terminate(); }
+	cRepCreate(st);
+	if (isProd_) inttMod(cRep_, nRep_, logq_, device_, st);
+	else intt(cRep_, nRep_, logq_, device_, st);
+	CSC(cuhe_hip_stream_sync(device_, st));
+	isProd_ = false;
+	nRepFree();
+	domain_ = 2;
+}
+void CuPolynomial::x2z(cudaStream_t st) {
+	if (domain_ == 3) n2c(st);
+	if (domain_ == 2) c2r(st);
+	if (domain_ == 1) r2z(st);
+}
+void CuPolynomial::x2r(cudaStream_t st) {
+	if (domain_ == 0) z2r(st);
+	else { if (domain_ == 3) n2c(st); if (domain_ == 2) c2r(st); }
+}
+void CuPolynomial::x2c(cudaStream_t st) {
+	if (domain_ == 3) { n2c(st); return; }
+	if (domain_ == 0) z2r(st);
+	if (domain_ == 1) r2c(st);
+}
+void CuPolynomial::x2n(cudaStream_t st) {
+	if (domain_ == 0) z2r(st);
+	if (domain_ == 1) r2c(st);
+	if (domain_ == 2) c2n(st);
+}
+
+// ------------------------------------------------------------------ CuCtxt / CuPtxt
+static void createRep(CuPolynomial &p, int domain, cudaStream_t st) {
+	if (domain == 1) p.rRepCreate(st);
+	else if (domain == 2) p.cRepCreate(st);
+	else if (domain == 3) p.nRepCreate(st);
+}
+void CuCtxt::setLevel(int lvl, int domain, int device, cudaStream_t st) {
+	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
+	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
+}
+void CuCtxt::setLevel(int lvl, int device, ZZX val) {
+	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = 0; device_ = device; zRep_ = val;
+}
+int CuCtxt::level() { return level_; }
+size_t CuCtxt::cRepSize() { return (size_t)param._numCrtPrime(level_) * param.crtLen * sizeof(uint32); }
+size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * param.nttLen * sizeof(uint64); }
+void CuCtxt::modSwitch(cudaStream_t st) {
+	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
+	x2c();
+	crtModSwitch(cRep_, cRep_, logq_, device_, st);
+	CSC(cuhe_hip_stream_sync(device_, st));
+	logq_ -= param.logCoeffCut;
+	level_++;
+}
+void CuCtxt::modSwitch(int lvl, cudaStream_t st) {
+	if (lvl < level_ || lvl >= param.depth) { printf("Error: ModSwitch to unavailable level!\n"); terminate(); }
+	while (level_ < lvl) modSwitch(st);       // (the reference's loop never advances level_: SURVEY A.7)
+}
+void CuCtxt::relin(cudaStream_t st) {
+	x2r();
+	nRepCreate(st);
+	relinearization(nRep_, rRep_, level_, device_, st);
+	CSC(cuhe_hip_stream_sync(device_, st));
+	rRepFree();
+	isProd_ = true;
+	domain_ = 3;
+	n2c();
+	CSC(cuhe_hip_stream_sync(device_, st));
+}
+void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
+	logq_ = logq; domain_ = domain; device_ = device;
+	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
+}
+void CuPtxt::setLogq(int logq, int device, ZZX val) { logq_ = logq; domain_ = 0; device_ = device; zRep_ = val; }
+size_t CuPtxt::cRepSize() { return (size_t)param.crtLen * sizeof(uint32); }
+size_t CuPtxt::nRepSize() { return (size_t)param.nttLen * sizeof(uint64); }
+
+// ------------------------------------------------------------------ gates
+void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
+	if (&dst == &src) return;
+	dst.reset();
+	dst.setLevel(src.level(), src.domain(), src.device(), st);
+	dst.isProd(src.isProd());
+	const int dev = dst.device();
+	if (dst.domain() == 0) dst.zRep(src.zRep());
+	else if (dst.domain() == 1) CSC(cuhe_hip_memcpy_d2d(dev, dst.rRep(), src.rRep(), dst.rRepSize(), st));
+	else if (dst.domain() == 2) CSC(cuhe_hip_memcpy_d2d(dev, dst.cRep(), src.cRep(), dst.cRepSize(), st));
+	else if (dst.domain() == 3) CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(), src.nRep(), dst.nRepSize(), st));
+	if (dev >= 0) CSC(cuhe_hip_stream_sync(dev, st));
+}
+static void prepareOut(CuCtxt &out, CuCtxt &like, int domain, cudaStream_t st) {
+	if (&out != &like) { out.reset(); out.setLevel(like.level(), domain, like.device(), st); }
+}
+void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
+	if (in0.device() != in1.device()) misuse("Error: Multiplication of different devices!");
+	if (in0.domain() != 3 || in1.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
+	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
+	prepareOut(out, in0, 3, st);
+	nttMul(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
+	out.isProd(true);
+	CSC(cuhe_hip_stream_sync(out.device(), st));
+}
+void cAnd(CuCtxt &out, CuCtxt &inc, CuPtxt &inp, cudaStream_t st) {
+	if (inc.device() != inp.device()) misuse("Error: Multiplication of different devices!");
+	if (inc.domain() != 3 || inp.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
+	prepareOut(out, inc, 3, st);
+	nttMulNX1(out.nRep(), inc.nRep(), inp.nRep(), out.logq(), out.device(), st);
+	out.isProd(true);
+	CSC(cuhe_hip_stream_sync(out.device(), st));
+}
+void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
+	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
+	if (in0.logq() != in1.logq()) misuse("Error: Addition of different levels!");
+	if (in0.domain() == 2 && in1.domain() == 2) {
+		prepareOut(out, in0, 2, st);
+		crtAdd(out.cRep(), in0.cRep(), in1.cRep(), out.logq(), out.device(), st);
+	} else if (in0.domain() == 3 && in1.domain() == 3) {
+		const bool prod = in0.isProd() || in1.isProd();
+		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
+		nttAdd(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
+	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
+	CSC(cuhe_hip_stream_sync(out.device(), st));
+}
+void cXor(CuCtxt &out, CuCtxt &in0, CuPtxt &in1, cudaStream_t st) {
+	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
+	if (in0.domain() == 2 && in1.domain() == 2) {
+		prepareOut(out, in0, 2, st);
+		crtAddNX1(out.cRep(), in0.cRep(), in1.cRep(), out.logq(), out.device(), st);
+	} else if (in0.domain() == 3 && in1.domain() == 3) {
+		const bool prod = in0.isProd() || in1.isProd();
+		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
+		nttAddNX1(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
+	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
+	CSC(cuhe_hip_stream_sync(out.device(), st));
+}
+void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
+	if (in.domain() != 2) misuse("Error: cNot of non-CRT domain!");
+	if (&out != &in) {
+		// the reference allocates a zeroed result and only writes the constant term (crt_add_int,
+		// cuhe/Base.cu:1096): a value-preserving NOT needs the other coefficients too
+		copy(out, in, st);
+	}
+	crtAddInt(out.cRep(), in.cRep(), (unsigned)param.modMsg - 1, out.logq(), out.device(), st);
+	CSC(cuhe_hip_stream_sync(out.device(), st));
+}
+void moveTo(CuCtxt &tar, int dstDev, cudaStream_t st) {
+	if (dstDev == tar.device()) return;
+	const int srcDev = tar.device();
+	if (tar.domain() == 1) {
+		void *p = devAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.rRepSize());
+		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.rRep(), srcDev, tar.rRepSize(), st));
+		CSC(cuhe_hip_stream_sync(srcDev, st));
+		tar.rRepFree(); tar.rRep((uint32 *)p);
+	} else if (tar.domain() == 2) {
+		void *p = devAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.cRepSize());
+		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.cRep(), srcDev, tar.cRepSize(), st));
+		CSC(cuhe_hip_stream_sync(srcDev, st));
+		tar.cRepFree(); tar.cRep((uint32 *)p);
+	} else if (tar.domain() == 3) {
+		void *p = devAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.nRepSize());
+		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.nRep(), srcDev, tar.nRepSize(), st));
+		CSC(cuhe_hip_stream_sync(srcDev, st));
+		tar.nRepFree(); tar.nRep((uint64 *)p);
+	}
+	tar.device(dstDev);
+}
+void copyTo(CuCtxt &dst, CuCtxt &src, int dstDev, cudaStream_t st) {
+	copy(dst, src, st);
+	moveTo(dst, dstDev, st);
+}
+
+// ------------------------------------------------------------------ NTL interface
+void mulZZX(ZZX &out, ZZX in0, ZZX in1, int lvl, int dev, cudaStream_t st) {
+	CuCtxt a, b;
+	a.setLevel(lvl, dev, in0);
+	b.setLevel(lvl, dev, in1);
+	a.x2n(st);
+	b.x2n(st);
+	cAnd(a, a, b, st);
+	a.x2z(st);
+	out = a.zRep();
+}
+
+} // namespace cuHE

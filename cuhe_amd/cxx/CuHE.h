@@ -1,0 +1,133 @@
+// CuHE.h -- public API of the library, source compatible with cuhe/CuHE.h:41-210
+// of vernamlab/cuHE: the DHS / Prince example sources include this header and
+// call exactly these symbols.  Implementation: CuHE.cpp on top of the C ABI in
+// include/cuhe_hip.h (MI355X / gfx950 kernels); no CUDA headers are needed --
+// cudaStream_t is an opaque handle that carries a hipStream_t.
+#pragma once
+#include "Parameters.h"
+#include <NTL/ZZ.h>
+#include <NTL/ZZX.h>
+NTL_CLIENT
+
+#ifndef CUHE_STREAM_T
+#define CUHE_STREAM_T
+typedef void *cudaStream_t;
+#endif
+
+typedef unsigned char uint8;
+typedef unsigned int uint32;
+typedef unsigned long int uint64;
+
+namespace cuHE {
+
+// A polynomial living in exactly one of four domains:
+//   0 = ZZX (host), 1 = RAW (device, big coefficients), 2 = CRT (device,
+//   residues per prime), 3 = NTT (device, transform per prime).
+// It owns at most one device representation at a time; conversions create the
+// target representation and release the source one.
+class CuPolynomial {
+public:
+	CuPolynomial();
+	~CuPolynomial();
+	void reset();                    // idempotent; safe after an explicit destructor call
+	// setters (pointer setters copy the pointer, not the data)
+	void logq(int val);
+	void domain(int val);
+	void device(int val);
+	void isProd(bool val);
+	void zRep(ZZX val);
+	void rRep(uint32 *val);
+	void cRep(uint32 *val);
+	void nRep(uint64 *val);
+	// getters
+	int logq();
+	int domain();
+	int device();
+	bool isProd();
+	ZZX zRep();
+	uint32 *rRep();
+	uint32 *cRep();
+	uint64 *nRep();
+	// any domain -> the named domain
+	void x2z(cudaStream_t st = 0);
+	void x2r(cudaStream_t st = 0);
+	void x2c(cudaStream_t st = 0);
+	void x2n(cudaStream_t st = 0);
+	// storage
+	void rRepCreate(cudaStream_t st = 0);
+	void cRepCreate(cudaStream_t st = 0);
+	void nRepCreate(cudaStream_t st = 0);
+	void rRepFree();
+	void cRepFree();
+	void nRepFree();
+	int coeffWords();
+	size_t rRepSize();
+	virtual size_t cRepSize() = 0;
+	virtual size_t nRepSize() = 0;
+protected:
+	void z2r(cudaStream_t st = 0);   // ZZX -> RAW
+	void r2z(cudaStream_t st = 0);   // RAW -> ZZX
+	void r2c(cudaStream_t st = 0);   // CRT
+	void c2r(cudaStream_t st = 0);   // ICRT
+	void c2n(cudaStream_t st = 0);   // NTT
+	void n2c(cudaStream_t st = 0);   // INTT (+ reduction mod the polynomial modulus for products)
+	int logq_;
+	int domain_;
+	int device_;
+	bool isProd_;
+	ZZX zRep_;
+	uint32 *rRep_;
+	uint32 *cRep_;
+	uint64 *nRep_;
+};
+
+// ciphertext: a polynomial per CRT prime of its level
+class CuCtxt : public CuPolynomial {
+public:
+	CuCtxt() : CuPolynomial() { level_ = -1; }
+	void setLevel(int lvl, int dom, int dev, cudaStream_t st = 0);   // allocate, no value
+	void setLevel(int lvl, int dev, ZZX val);                        // host value
+	int level();
+	void modSwitch(cudaStream_t st = 0);           // one level down
+	void modSwitch(int lvl, cudaStream_t st = 0);  // down to level lvl
+	void relin(cudaStream_t st = 0);
+	size_t cRepSize();
+	size_t nRepSize();
+protected:
+	int level_;
+};
+
+// batched plaintext: a single polynomial
+class CuPtxt : public CuPolynomial {
+public:
+	void setLogq(int logq, int dom, int dev, cudaStream_t st = 0);
+	void setLogq(int logq, int dev, ZZX val);
+	size_t cRepSize();
+	size_t nRepSize();
+};
+
+// initialisation: setParameters first, then (optionally) multiGPUs, then initCuHE.
+// initCuHE writes the `depth` coefficient moduli into coeffMod_.
+void initCuHE(ZZ *coeffMod_, ZZX modulus);
+void startAllocator();
+void stopAllocator();
+void multiGPUs(int num);
+int numGPUs();
+void setParameters(int d, int p, int w, int min, int cut, int m);
+void resetParameters();
+void initRelinearization(ZZX *evalkey);
+
+// x = a * b mod (polynomial modulus, q_lvl), host in / host out
+void mulZZX(ZZX &x, ZZX a, ZZX b, int lvl, int dev, cudaStream_t st = 0);
+
+// gates
+void copy(CuCtxt &x, CuCtxt &a, cudaStream_t st = 0);
+void cAnd(CuCtxt &x, CuCtxt &a, CuCtxt &b, cudaStream_t st = 0);
+void cAnd(CuCtxt &x, CuCtxt &c, CuPtxt &p, cudaStream_t st = 0);
+void cXor(CuCtxt &x, CuCtxt &a, CuCtxt &b, cudaStream_t st = 0);
+void cXor(CuCtxt &x, CuCtxt &c, CuPtxt &p, cudaStream_t st = 0);
+void cNot(CuCtxt &x, CuCtxt &a, cudaStream_t st = 0);
+void moveTo(CuCtxt &x, int dstDev, cudaStream_t st = 0);
+void copyTo(CuCtxt &dst, CuCtxt &src, int dstDev, cudaStream_t st = 0);
+
+} // namespace cuHE

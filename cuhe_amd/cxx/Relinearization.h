@@ -1,0 +1,10 @@
+// Relinearization.h -- API of cuhe/Relinearization.h.
+#pragma once
+#include "Operations.h"
+
+namespace cuHE {
+// converts every evaluation key to the NTT domain ONCE; keys stay resident in HBM
+void initRelin(ZZX *evalkey);
+// dst (NTT domain) = sum_j NTT(window_j(src)) * EK_j for every CRT prime of `lvl`
+void relinearization(uint64 *dst, uint32 *src, int lvl, int dev, cudaStream_t st = 0);
+} // namespace cuHE

@@ -7,6 +7,12 @@ namespace NTL {
 class ZZX {
 public:
     std::vector<ZZ> rep;
+    ZZX() {}
+    ZZX(const ZZX &o) : rep(o.rep) {}
+    ZZX &operator=(const ZZX &o) { rep = o.rep; return *this; }
+    // releases the buffer and leaves a valid empty vector behind, so that the explicit-destructor-then-scope-exit
+    // pattern of the reference's examples (Prince.cu:298-319) stays harmless with this fallback type too
+    ~ZZX() { std::vector<ZZ>().swap(rep); }
     void normalize() { while (!rep.empty() && rep.back().zero()) rep.pop_back(); }
 };
 inline long deg(const ZZX &a) { return (long)a.rep.size() - 1; }
@@ -14,7 +20,7 @@ inline const ZZ &coeff(const ZZX &a, long i) { static const ZZ z; return (i < 0 
 inline void SetCoeff(ZZX &a, long i, const ZZ &v) { if (i >= (long)a.rep.size()) a.rep.resize(i + 1); a.rep[i] = v; a.normalize(); }
 inline void SetCoeff(ZZX &a, long i, long v) { SetCoeff(a, i, ZZ(v)); }
 inline void SetCoeff(ZZX &a, long i) { SetCoeff(a, i, ZZ(1)); }
-inline void clear(ZZX &a) { a.rep.clear(); }
+inline void clear(ZZX &a) { std::vector<ZZ>().swap(a.rep); }
 inline bool operator==(const ZZX &a, const ZZX &b) {
     if (a.rep.size() != b.rep.size()) return false;
     for (size_t i = 0; i < a.rep.size(); ++i) if (a.rep[i] != b.rep[i]) return false;

@@ -1,0 +1,132 @@
+// test_cuhe_api.cpp -- exercises the C++ drop-in API (cuhe_amd/cxx/CuHE.h) the way the
+// reference's DHS example does (examples/DHS/simple_DHS.cu:49-211, DHS.cu:212-252), against
+// host ZZX arithmetic: t = a*b; t %= Phi_m; coefficients % q  (examples/DHS/DHS.cu:219-221).
+// Runs on a GPU box; exit code 0 = all checks passed.
+#include "CuHE.h"
+#include <cstdio>
+#include <vector>
+using namespace cuHE;
+
+static int failures = 0;
+#define CHECK(cond, what) do { if (!(cond)) { printf("FAIL: %s (%s:%d)\n", what, __FILE__, __LINE__); ++failures; } else printf("ok: %s\n", what); } while (0)
+
+static ZZX cyclotomic(int m) {
+	auto mu = [](int n) { int r = 1; for (int p = 2; p * p <= n; ++p) if (n % p == 0) { n /= p; if (n % p == 0) return 0; r = -r; } if (n > 1) r = -r; return r; };
+	std::vector<long long> a(2 * m + 2, 0); int len = 1; a[0] = 1;
+	for (int d = 1; d <= m; ++d) if (m % d == 0 && mu(m / d) == 1) { for (int i = len - 1; i >= 0; --i) { a[i + d] += a[i]; a[i] = -a[i]; } len += d; }
+	for (int d = 1; d <= m; ++d) if (m % d == 0 && mu(m / d) == -1) { for (int i = 0; i < len - d; ++i) a[i] = (i >= d ? a[i - d] : 0) - a[i]; len -= d; }
+	ZZX r; for (int i = 0; i < len; ++i) SetCoeff(r, i, to_ZZ((long)a[i])); return r;
+}
+static ZZX randomPoly(int n, const ZZ &q) { ZZX r; for (int i = n - 1; i >= 0; --i) SetCoeff(r, i, RandomBnd(q)); return r; }
+static ZZX reduceCoeffs(const ZZX &a, const ZZ &q, int n) { ZZX r; for (int i = n - 1; i >= 0; --i) SetCoeff(r, i, coeff(a, i) % q); return r; }
+static ZZX hostMul(const ZZX &a, const ZZX &b, const ZZX &phi, const ZZ &q, int n) { ZZX t = a * b; t %= phi; return reduceCoeffs(t, q, n); }
+
+int main() {
+	SetSeed(to_ZZ(20260926));
+	const int d = 3, p = 2, w = 8, mn = 40, cut = 20, m = 1155;
+	setParameters(d, p, w, mn, cut, m);
+	CHECK(param.modLen == 480 && param.nttLen == 16384 && param.numCrtPrime == 4 && param.numEvalKey == 10, "setParameters derives the reference's values");
+	ZZX phi = cyclotomic(m);
+	CHECK(deg(phi) == param.modLen, "cyclotomic degree");
+	std::vector<ZZ> q(d);
+	initCuHE(q.data(), phi);
+	const int n = param.modLen;
+	bool chain = true;
+	for (int i = 0; i < d; ++i) chain = chain && NumBits(q[i]) <= param._logCoeff(i) && (i == 0 || (q[i - 1] % q[i] == to_ZZ(0) && q[i] < q[i - 1]));
+	CHECK(chain, "initCuHE returns a decreasing divisor chain of coefficient moduli");
+
+	// ---- mulZZX (DHS.cu:218) at two levels
+	for (int lvl : {0, 2}) {
+		ZZX a = randomPoly(n, q[lvl]), b = randomPoly(n, q[lvl]), c;
+		mulZZX(c, a, b, lvl, 0);
+		CHECK(c == hostMul(a, b, phi, q[lvl], n), lvl == 0 ? "mulZZX level 0" : "mulZZX level 2");
+	}
+	// ---- domain conversions round trip + cXor in CRT and NTT domains (simple_DHS.cu checkXor)
+	{
+		ZZX a = randomPoly(n, q[0]), b = randomPoly(n, q[0]);
+		CuCtxt ca, cb, cz;
+		ca.setLevel(0, 0, a); cb.setLevel(0, 0, b);
+		ca.x2c(); cb.x2c();
+		cXor(cz, ca, cb);
+		cz.x2z();
+		CHECK(cz.zRep() == reduceCoeffs(a + b, q[0], n), "cXor in the CRT domain");
+		ca.x2n(); cb.x2n();
+		CuCtxt cy;
+		cXor(cy, ca, cb);
+		cy.x2z();
+		CHECK(cy.zRep() == reduceCoeffs(a + b, q[0], n), "cXor in the NTT domain");
+		ca.x2z();
+		CHECK(ca.zRep() == a, "ZZX -> RAW -> CRT -> NTT -> CRT -> RAW -> ZZX round trip");
+	}
+	// ---- cNot (simple_DHS.cu:98) : adds modMsg-1 to the constant term
+	{
+		ZZX a = randomPoly(n, q[0]);
+		CuCtxt ca; ca.setLevel(0, 0, a); ca.x2c();
+		cNot(ca, ca);
+		ca.x2z();
+		ZZX want = a; SetCoeff(want, 0, (coeff(a, 0) + to_ZZ(param.modMsg - 1)) % q[0]);
+		CHECK(ca.zRep() == want, "cNot");
+	}
+	// ---- cAnd with a plaintext polynomial (CuPtxt, nttMulNX1)
+	{
+		ZZX a = randomPoly(n, q[0]), pt;
+		for (int i = n - 1; i >= 0; --i) SetCoeff(pt, i, RandomBnd(to_ZZ(2)));
+		CuCtxt ca; ca.setLevel(0, 0, a); ca.x2n();
+		CuPtxt cp; cp.setLogq(param.logMsg, 0, pt); cp.x2n();
+		CuCtxt cz; cAnd(cz, ca, cp);
+		cz.x2z();
+		CHECK(cz.zRep() == hostMul(a, pt, phi, q[0], n), "cAnd(ciphertext, plaintext)");
+	}
+	// ---- cAnd + relin + modSwitch (simple_DHS.cu checkAnd: cAnd; relin; modSwitch)
+	{
+		std::vector<ZZX> ek(param.numEvalKey);
+		for (auto &e : ek) e = randomPoly(n, q[0]);
+		initRelinearization(ek.data());
+		ZZX a = randomPoly(n, q[0]), b = randomPoly(n, q[0]);
+		CuCtxt ca, cb, cz;
+		ca.setLevel(0, 0, a); cb.setLevel(0, 0, b);
+		ca.x2n(); cb.x2n();
+		cAnd(cz, ca, cb);
+		cz.relin();
+		CHECK(cz.domain() == 2 && cz.level() == 0, "relin leaves a CRT-domain ciphertext at the same level");
+		// expected: sum_j window_j(a*b) * ek_j  mod Phi, mod q0
+		ZZX prod = hostMul(a, b, phi, q[0], n), acc;
+		const ZZ base = power2_ZZ(param.logRelin);
+		for (int j = 0; j < param._numEvalKey(0); ++j) {
+			ZZX win; ZZ sh = power(base, j);
+			for (int i = n - 1; i >= 0; --i) SetCoeff(win, i, (coeff(prod, i) / sh) % base);
+			acc += win * ek[j];
+		}
+		acc %= phi;
+		ZZX want = reduceCoeffs(acc, q[0], n);
+		CuCtxt keep; copy(keep, cz);
+		cz.x2z();
+		CHECK(cz.zRep() == want, "cAnd + relin equals the windowed key-switch sum");
+		// modSwitch on the relinearised ciphertext
+		keep.modSwitch();
+		CHECK(keep.level() == 1 && keep.logq() == param._logCoeff(1), "modSwitch advances the level");
+		keep.x2z();
+		const ZZ pt = q[0] / q[1];
+		ZZX ms;
+		for (int i = n - 1; i >= 0; --i) {
+			ZZ v = coeff(want, i), dl = v % pt;
+			if (dl % to_ZZ(2) != to_ZZ(0)) dl = (dl > (pt - to_ZZ(1)) / to_ZZ(2)) ? dl - pt : dl + pt;
+			SetCoeff(ms, i, ((v - dl) / pt) % q[1]);
+		}
+		CHECK(keep.zRep() == ms, "modSwitch = (c - delta)/p_t with delta = c mod p_t made even");
+	}
+	// ---- ownership rules the examples rely on (Prince.cu:298-319: explicit destructor, then scope exit)
+	{
+		startAllocator();
+		ZZX a = randomPoly(n, q[0]);
+		CuCtxt ca; ca.setLevel(0, 0, a); ca.x2n();
+		CuCtxt cb; copy(cb, ca);
+		moveTo(cb, 0);
+		ca.~CuCtxt();
+		cb.x2z();
+		CHECK(cb.zRep() == a, "copy / moveTo(same device) / explicit destructor with the pooled allocator");
+		stopAllocator();
+	}
+	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+	return failures ? 1 : 0;
+}
