@@ -5,7 +5,7 @@ import os
 
 from . import build as _build
 
-LIB_PATH = _build.LIB
+LIB_PATH = os.environ.get("CUHE_HIP_LIB", _build.LIB)   # override: A/B builds of the same ABI (tools/ab_bench.sh)
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "cuhe_amd: %s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -83,6 +83,7 @@ SIGNATURES = {
     "cuhe_hip_ntt_inv_batched": (i32, [vp, vp, i32, i32, lng, i32, i32, i32, vp]),
     "cuhe_hip_ntt_prepare": (i32, [i32, i32]),
     "cuhe_hip_set_ntt_chunk": (i32, [i32]),
+    "cuhe_hip_set_ntt_overlap": (i32, [i32]),
     "cuhe_hip_time_ntt_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp] + [C.POINTER(C.c_float)] * 3),
     "cuhe_hip_modp_add": (i32, [vp, vp, vp, sz, i32, vp]),
     "cuhe_hip_modp_sub": (i32, [vp, vp, vp, sz, i32, vp]),

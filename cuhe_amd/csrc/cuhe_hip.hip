@@ -47,7 +47,8 @@ int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------ state
 struct NttTab {
-    u64 *T1 = nullptr, *T2 = nullptr, *T2inv = nullptr, *scratch = nullptr;
+    u64 *T1 = nullptr, *T2 = nullptr, *T2inv = nullptr;
+    u64 *scratch[2] = {nullptr, nullptr};      // two slabs: pass 2 of chunk c overlaps pass 1 of chunk c+1
     int scratch_batch = 0;
 };
 struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0; };
@@ -67,6 +68,9 @@ struct DevCtx {
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *relin = nullptr, *ek = nullptr;
     // allocator (cuhe/DeviceManager.cu:98-138)
+    // helper streams/events for the pass-1 / pass-2 software pipeline
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipEvent_t ev_start = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     std::multimap<size_t, void *> freeBlocks;
     std::map<void *, size_t> allocated;
 };
@@ -82,6 +86,7 @@ struct Global {
     bool force_generic = false;
     bool allocator_on = false;
     int ntt_chunk = 0;
+    bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
     std::mutex mu;
 } G_;
@@ -137,14 +142,27 @@ int ensure_ntt(int dev, int len, int batch_hint) {
         else if (li == 1) CHK(make_ntt_tables<15>(tab));
         else CHK(make_ntt_tables<16>(tab));
     }
-    int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (64 << 20) / (len * 8);   // 64 MiB slab: MALL resident
+    // transforms per launch pair: 128 MiB slabs by default (profiles/r01_chunk_sweep.txt)
+    int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (128 << 20) / (len * 8);
     if (chunk < 8) chunk = 8;
     chunk = (chunk + 7) & ~7;
     int want = std::min(chunk, (std::max(batch_hint, 1) + 7) & ~7);
     if (tab.scratch_batch < want) {
-        if (tab.scratch) HIPCHK(hipFree(tab.scratch));
-        HIPCHK(hipMalloc((void **)&tab.scratch, (size_t)want * len * sizeof(u64)));
+        for (auto &sl : tab.scratch) {
+            if (sl) HIPCHK(hipFree(sl));
+            HIPCHK(hipMalloc((void **)&sl, (size_t)want * len * sizeof(u64)));
+        }
         tab.scratch_batch = want;
+    }
+    DevCtx &D = G_.dev[dev];
+    if (!D.s1) {
+        HIPCHK(hipStreamCreateWithFlags(&D.s1, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&D.s2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&D.ev_start, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&D.ev_p1[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&D.ev_p2[i], hipEventDisableTiming));
+        }
     }
     return CUHE_OK;
 }
@@ -164,19 +182,19 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, lon
     }
     const int tiles = 64 / Gm::NC;
     const int grid = ((nb + 7) / 8) * 8 * tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNttThreads), NttLds<LG>::bytes, st, src, scratch, tab.T1,
-                       inv ? tab.T2inv : tab.T2, src_stride, nb, wa);
+    (void)inv;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNttThreads), NttLds<LG>::bytes, st, src, scratch, tab.T1, src_stride, nb, wa);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
 template <int LG, bool INV>
-int launch_pass2(void *dst, const u64 *scratch, long dst_stride, int nb, int nstore, const u32 *primes,
+int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
                  const u64 *pinv, int prime0, hipStream_t st) {
     constexpr int N1 = (1 << LG) / 64;
     const int tiles = N1 / kNttThreads;
     const int grid = ((nb + 7) / 8) * 8 * tiles;
-    hipLaunchKernelGGL((ntt_pass2<LG, INV>), dim3(grid), dim3(kNttThreads), 0, st, dst, scratch, dst_stride, nb,
-                       nstore, primes, pinv, prime0);
+    hipLaunchKernelGGL((ntt_pass2<LG, INV>), dim3(grid), dim3(kNttThreads), 0, st, dst, scratch, INV ? tab.T2inv : tab.T2,
+                       dst_stride, nb, nstore, primes, pinv, prime0);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -193,29 +211,45 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
     constexpr int L = 1 << LG;
     NttTab &tab = D.ntt[LG - 14];
     const int chunk = tab.scratch_batch;
-    for (int b0 = 0; b0 < batch; b0 += chunk) {
+    // Two-stage software pipeline over chunks: pass 1 (VALU/LDS bound) of chunk c+1 runs on stream s1 while
+    // pass 2 (load/store heavy, 1 wave/SIMD fits beside pass 1's 2) of chunk c runs on s2.
+    const bool pipe = G_.ntt_overlap && !(tm && tm->on) && batch > chunk;
+    hipStream_t q1 = pipe ? D.s1 : st, q2 = pipe ? D.s2 : st;
+    if (pipe) {
+        HIPCHK(hipEventRecord(D.ev_start, st));
+        HIPCHK(hipStreamWaitEvent(D.s1, D.ev_start, 0));
+        HIPCHK(hipStreamWaitEvent(D.s2, D.ev_start, 0));
+    }
+    int c = 0, last = 0;
+    for (int b0 = 0; b0 < batch; b0 += chunk, ++c) {
         const int nb = std::min(chunk, batch - b0);
+        const int sl = pipe ? (c & 1) : 0;
+        u64 *slab = tab.scratch[sl];
+        if (pipe && c >= 2) HIPCHK(hipStreamWaitEvent(q1, D.ev_p2[sl], 0));       // slab free again
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU32Ext) {
             const u32 *s = (const u32 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU32Ext>(s, tab.scratch, tab, false, src_stride, nb, wa, st)));
+            CHK((launch_pass1<LG, kSrcU32Ext>(s, slab, tab, false, src_stride, nb, wa, q1)));
         } else if (mode == kSrcWindow) {
             WindowArgs w2 = wa; w2.wid0 += b0;
-            CHK((launch_pass1<LG, kSrcWindow>(src, tab.scratch, tab, false, 0, nb, w2, st)));
+            CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, false, 0, nb, w2, q1)));
         } else {
             const u64 *s = (const u64 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU64Neg>(s, tab.scratch, tab, true, src_stride, nb, wa, st)));
+            CHK((launch_pass1<LG, kSrcU64Neg>(s, slab, tab, true, src_stride, nb, wa, q1)));
         }
+        if (pipe) { HIPCHK(hipEventRecord(D.ev_p1[sl], q1)); HIPCHK(hipStreamWaitEvent(q2, D.ev_p1[sl], 0)); }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU64Neg) {
             u32 *d = (u32 *)dst + (long)b0 * dst_stride;
-            CHK((launch_pass2<LG, true>(d, tab.scratch, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, st)));
+            CHK((launch_pass2<LG, true>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            CHK((launch_pass2<LG, false>(d, tab.scratch, dst_stride, nb, nstore, nullptr, nullptr, 0, st)));
+            CHK((launch_pass2<LG, false>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
         }
+        if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
     }
+    if (pipe) HIPCHK(hipStreamWaitEvent(st, D.ev_p2[last], 0));
     return CUHE_OK;
 }
 
@@ -474,7 +508,8 @@ int cuhe_hip_shutdown(void) {
     for (int d = 0; d < (int)G_.dev.size(); ++d) {
         hipSetDevice(G_.dev_base + d);
         DevCtx &D = G_.dev[d];
-        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch); t = NttTab(); }
+        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch[0]); hipFree(t.scratch[1]); t = NttTab(); }
+        if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.b_ntt, D.m_crt, D.b_src, D.b_crt,
                         D.hold, D.relin, D.ek};
         for (void *p : ptrs) if (p) hipFree(p);
@@ -772,9 +807,10 @@ int cuhe_hip_ntt_prepare(int len, int dev) {
 }
 int cuhe_hip_set_ntt_chunk(int chunk) {
     G_.ntt_chunk = chunk;
-    for (auto &D : G_.dev) for (auto &t : D.ntt) if (t.scratch) { hipFree(t.scratch); t.scratch = nullptr; t.scratch_batch = 0; }
+    for (auto &D : G_.dev) for (auto &t : D.ntt) for (auto &sl : t.scratch) if (sl) { hipFree(sl); sl = nullptr; t.scratch_batch = 0; }
     return CUHE_OK;
 }
+int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {
     CHK(set_dev(dev));
     if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);
@@ -803,8 +839,17 @@ int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch
         hipEventElapsedTime(&t2, tm.ev[i + 1], tm.ev[i + 2]);
         a += t1; b += t2;
     }
-    if (!tm.ev.empty()) hipEventElapsedTime(&tot, tm.ev.front(), tm.ev.back());
     for (auto e : tm.ev) hipEventDestroy(e);
+    // whole pipelined region (pass 1 / pass 2 overlapped as in production), bracketed on the launch stream
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, S(st)));
+    for (int it = 0; it < iters; ++it)
+        CHK(run_ntt(len, kSrcU32Ext, dst, src, batch, len / 2, len, len, 0, WindowArgs{0, 0, 0}, dev, S(st), nullptr));
+    HIPCHK(hipEventRecord(t1, S(st)));
+    HIPCHK(hipEventSynchronize(t1));
+    hipEventElapsedTime(&tot, t0, t1);
+    hipEventDestroy(t0); hipEventDestroy(t1);
     if (ms1) *ms1 = a;
     if (ms2) *ms2 = b;
     if (mst) *mst = tot;

@@ -10,10 +10,10 @@
 //       adjacent columns.  Each thread does R1-point DFTs in registers
 //       (compile-time power-of-two twiddles: shifts only), multiplies by the
 //       inner twiddle w_N1^(b*c) (LDS table), exchanges through LDS, does
-//       R2-point DFTs in registers, multiplies by the outer twiddle
-//       w_L^(j2*k1) and writes scratch[j2][k1] (coalesced, L2/MALL resident).
+//       R2-point DFTs in registers and writes scratch[j2][k1] (coalesced).
 //   pass 2 (ntt_pass2):  one thread per k1 loads the 64 values scratch[.][k1]
-//       (512 B contiguous per wave-load), does a 64-point DFT entirely in
+//       (512 B contiguous per wave-load), multiplies them by the outer twiddle
+//       w_L^(j2*k1) (same layout, L2 resident), does a 64-point DFT entirely in
 //       registers (w_64 = 8: shifts only, no LDS, no barrier) and stores
 //       X[k1 + N1*k2] (512 B contiguous per wave-store) in natural order.
 //
@@ -84,8 +84,7 @@ __device__ __forceinline__ void dft_regs(u64 (&x)[N]) {
 template <int LG, int MODE>
 __global__ __launch_bounds__(kNttThreads, 2)
 void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
-               const u64 *__restrict__ T1, const u64 *__restrict__ T2,
-               long src_stride, int nbatch, WindowArgs wa) {
+               const u64 *__restrict__ T1, long src_stride, int nbatch, WindowArgs wa) {
     using G = NttGeom<LG>;
     using S = NttLds<LG>;
     constexpr int L = 1 << LG, N1 = L / 64, R1 = G::R1, R2 = G::R2, NC = G::NC;
@@ -155,15 +154,14 @@ void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
         const int j2 = col0 + col;
 #pragma unroll
         for (int d = 0; d < R2; ++d) {
-            const int o = j2 * N1 + c + R1 * d;
-            out[o] = mulp(y[bitrev<R2>(d)], T2[o]);
+            out[j2 * N1 + c + R1 * d] = y[bitrev<R2>(d)];
         }
     }
 }
 
 template <int LG, bool INV>
 __global__ __launch_bounds__(kNttThreads, 2)
-void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch,
+void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
                long dst_stride, int nbatch, int nstore,
                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
     constexpr int L = 1 << LG, N1 = L / 64;
@@ -172,9 +170,16 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch,
     if (batch >= nbatch) return;
     const int k1 = tile * kNttThreads + threadIdx.x;
     const u64 *in = scratch + (long)batch * L + k1;
+    const u64 *tw = T2 + k1;
     u64 x[64];
+    // outer twiddle w_L^(j2*k1) (times L^-1 for the inverse) applied here, on the bandwidth-bound side of the
+    // pair: pass 1 is issue-bound, pass 2 has VALU slack under its loads/stores (profiles/r01_chunk_sweep.txt)
 #pragma unroll
-    for (int j = 0; j < 64; ++j) x[j] = in[j * N1];
+    for (int j = 0; j < 64; ++j) {
+        u64 v = in[j * N1];
+        if (INV || j != 0) v = mulp(v, tw[j * N1]);
+        x[j] = v;
+    }
     dft_regs<64, false>(x);
     if constexpr (!INV) {
         u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
