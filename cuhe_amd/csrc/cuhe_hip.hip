@@ -609,8 +609,18 @@ int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *s
     const Params &q = G_.prm;
     const IcrtLevel &I = D.icrt[lvl];
     IcrtTab it{I.M, I.mi, I.bi, I.rp};
-    hipLaunchKernelGGL(k_icrt, dim3((q.modLen + 63) / 64), dim3(64), (size_t)(np + W) * 64 * 4, S(st), dst, src,
-                       prime_tab(D), it, np, W, q.modLen, q.crtLen);
+    const size_t lds = icrt_lds_bytes(np, W);
+    if (lds > 64 * 1024) {
+        static bool attr_done[64] = {false};
+        int cur = 0;
+        HIPCHK(hipGetDevice(&cur));
+        if (!attr_done[cur & 63]) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done[cur & 63] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef), dim3(kIcrtCoef * kIcrtGroups), lds, S(st), dst,
+                       src, prime_tab(D), it, np, W, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -794,8 +804,9 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
     DevCtx &D = G_.dev[dev];
     const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = q.nttLen;
     CHK(cuhe_hip_nttw((uint64_t *)D.relin, src, q.logCoeff(lvl), dev, st));
-    hipLaunchKernelGGL(k_relin_mac, dim3(L / 256, np), dim3(256), 0, S(st), (u64 *)dst, D.relin, D.ek, k,
-                       (long)q.numEvalKey * L, L);
+    constexpr int PB = 4;
+    hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (np + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, D.relin, D.ek, k,
+                       (long)q.numEvalKey * L, L, np);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }

@@ -190,9 +190,10 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u
         const u32 p = primes[prime0 + batch];
         const u64 m = pinv[prime0 + batch];
         u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
+        const int k2full = nstore / N1, rem = nstore % N1;     // wave-uniform row limit
 #pragma unroll
         for (int k2 = 0; k2 < 64; ++k2)
-            if (k2 * N1 + k1 < nstore) dst[k2 * N1] = mod_small(x[bitrev<64>(k2)], p, m);
+            if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[k2 * N1] = mod_small(x[bitrev<64>(k2)], p, m);
     }
 }
 

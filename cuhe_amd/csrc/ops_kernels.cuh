@@ -182,31 +182,64 @@ void k_reduce_special(u32 *__restrict__ dst, const u32 *__restrict__ f, PrimeTab
 // dst[i][idx] = sum_{j<k} c[j][idx] * ek[i][j][idx] mod P   (relinMulAddPerCrt, Base.cu:1024-1033,
 // launched once for ALL primes; keys are device resident instead of streamed over PCIe per call,
 // Relinearization.cu:80-87).  128-bit products are accumulated unreduced in 160 bits and folded once.
-__global__ __launch_bounds__(256)
-void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
-                 int k, long ek_prime_stride, int L) {
-    const int i = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // L is a multiple of 256
-    const u64 *e = ek + (long)i * ek_prime_stride + idx;
-    const u64 *cc = c + idx;
-    u64 lo = 0, hi = 0; u32 top = 0;
-    for (int j = 0; j < k; ++j) {
-        u64 a = cc[(long)j * L], b = e[(long)j * L];
-        u64 pl = a * b, ph = __umul64hi(a, b);
-        u64 nl = lo + pl;
-        u64 cy = nl < lo;
-        lo = nl;
-        u64 nh = hi + ph;
-        u32 c2 = nh < hi;
-        nh += cy;
-        c2 += (nh < cy);
-        hi = nh;
-        top += c2;
-    }
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+// 128-bit accumulate of a*b into (lo, hi, top)
+__device__ __forceinline__ void mac192(u64 a, u64 b, u64 &lo, u64 &hi, u32 &top) {
+    u64 pl = a * b, ph = __umul64hi(a, b);
+    u64 nl = lo + pl;
+    u64 cy = nl < lo;
+    lo = nl;
+    u64 nh = hi + ph;
+    u32 c2 = nh < hi;
+    nh += cy;
+    c2 += (nh < cy);
+    hi = nh;
+    top += c2;
+}
+__device__ __forceinline__ u64 fold192(u64 lo, u64 hi, u32 top) {
     // value = lo + hi*2^64 + top*2^128 ; 2^128 = -2^32 (mod P)
     u64 r = reduce128(lo, hi);
     u64 t = (u64)top << 32;             // top < 2^8: canonical
-    dst[(long)i * L + idx] = subp(r, t);
+    return subp(r, t);
+}
+// Two adjacent coefficients per thread (16 B/lane loads) and PB primes per block: every window value c[j][idx]
+// fetched once serves PB key streams, so the cache-resident operand costs 1/PB of the HBM key traffic
+// (8*k*L key bytes per prime are the algorithmic bytes of this kernel).
+template <int PB>
+__global__ __launch_bounds__(256)
+void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
+                 int k, long ek_prime_stride, int L, int np) {
+    const int i0 = blockIdx.y * PB;
+    const int idx2 = blockIdx.x * blockDim.x + threadIdx.x;    // pair index; L/2 is a multiple of 256
+    const long L2 = L / 2;
+    const u64x2 *cc = reinterpret_cast<const u64x2 *>(c) + idx2;
+    const u64x2 *e[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int i = min(i0 + q, np - 1);                     // clamp: tail block recomputes the last prime
+        e[q] = reinterpret_cast<const u64x2 *>(ek + (long)i * ek_prime_stride) + idx2;
+    }
+    u64 lo0[PB], hi0[PB], lo1[PB], hi1[PB]; u32 top0[PB], top1[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) { lo0[q] = hi0[q] = lo1[q] = hi1[q] = 0; top0[q] = top1[q] = 0; }
+    for (int j = 0; j < k; ++j) {
+        const u64x2 a = cc[(long)j * L2];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const u64x2 b = __builtin_nontemporal_load(&e[q][(long)j * L2]);
+            mac192(a.x, b.x, lo0[q], hi0[q], top0[q]);
+            mac192(a.y, b.y, lo1[q], hi1[q], top1[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        if (i0 + q < np) {
+            u64x2 r;
+            r.x = fold192(lo0[q], hi0[q], top0[q]);
+            r.y = fold192(lo1[q], hi1[q], top1[q]);
+            reinterpret_cast<u64x2 *>(dst + (long)(i0 + q) * L)[idx2] = r;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- CRT: raw -> residues (crt, Base.cu:857-879)
@@ -254,63 +287,94 @@ struct IcrtTab {
     const u32 *bi;      // [np]
     const double *rp;   // [np] 1/p_i
 };
-__global__ __launch_bounds__(64)
+// Work decomposition: a 256-thread block owns 32 coefficients; thread (g, ci) = (tid/32, tid%32) computes the
+// residue products t_i for primes i = g mod 8 and the 96-bit column sums for output words k = g mod 8 (np
+// multiply-adds each); the 32 threads with g == 0 then ripple the carries, apply the +-M fix-up and the block
+// stores its 32*W-word slab coalesced.  (The reference runs one thread per coefficient with a 104-word
+// register array, Base.cu:884.)
+static constexpr int kIcrtCoef = 32, kIcrtGroups = 8;
+static inline size_t icrt_lds_bytes(int np, int W) {
+    return (size_t)kIcrtCoef * ((size_t)np * 4 + (size_t)W * 16 + kIcrtGroups * 8);
+}
+__global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
             int np, int W, int mlen, int clen) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // tt[np][64] then out[W][64]
-    u32 *tt = sh;
-    u32 *out = sh + (long)np * 64;
-    const int lane = threadIdx.x;
-    const long base = (long)blockIdx.x * 64;
-    const int nvalid = (int)min((long)64, (long)mlen - base);
-    const bool live = lane < nvalid;
-    double alpha = 0.0;
-    for (int i = 0; i < np; ++i) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char shraw[];
+    constexpr int CB = kIcrtCoef, NG = kIcrtGroups;
+    u64 *colLo = reinterpret_cast<u64 *>(shraw);                         // [W][CB]
+    double *alphaP = reinterpret_cast<double *>(colLo + (size_t)W * CB); // [NG][CB]
+    int *colHi = reinterpret_cast<int *>(alphaP + NG * CB);              // [W][CB]
+    u32 *tt = reinterpret_cast<u32 *>(colHi + (size_t)W * CB);           // [np][CB]
+    const int ci = threadIdx.x % CB, g = threadIdx.x / CB;
+    const long base = (long)blockIdx.x * CB;
+    const int nvalid = (int)min((long)CB, (long)mlen - base);
+    const bool live = ci < nvalid;
+    double a = 0.0;
+    for (int i = g; i < np; i += NG) {
         u32 v = 0;
         if (live) {
             const u32 p = pt.p[i];
             const u64 m = pt.pinv[i];
-            u32 x = mod_small(src[(long)i * clen + base + lane], p, m);
+            u32 x = mod_small(src[(long)i * clen + base + ci], p, m);
             v = mod_small((u64)x * it.bi[i], p, m);
         }
-        tt[i * 64 + lane] = v;
-        alpha += (double)v * it.rp[i];
+        tt[i * CB + ci] = v;
+        a += (double)v * it.rp[i];
     }
+    alphaP[g * CB + ci] = a;
+    __syncthreads();
+    double alpha = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < NG; ++gg) alpha += alphaP[gg * CB + ci];
     const u32 q = (u32)alpha;            // floor; may be off by one either way -> fixed below
-    typedef __int128 i128;
-    i128 carry = 0;
-    for (int k = 0; k < W; ++k) {
-        unsigned __int128 col = 0;
-        for (int i = 0; i < np; ++i)
-            col += (u64)tt[i * 64 + lane] * it.mi[(long)i * W + k];
-        i128 total = carry + (i128)col - (i128)((u64)q * it.M[k]);
-        out[k * 64 + lane] = (u32)total;
-        carry = total >> 32;
-    }
-    // carry is now floor((S - q*M) / 2^(32W)): -1 => negative, 0 => in [0, 2^(32W))
-    int fix = 0;                          // +1: add M, -1: subtract M
-    if (carry < 0) fix = 1;
-    else {
-        bool ge = true;                   // out >= M ?
-        for (int k = W - 1; k >= 0; --k) {
-            u32 a = out[k * 64 + lane], b = it.M[k];
-            if (a != b) { ge = a > b; break; }
+    for (int k = g; k < W; k += NG) {
+        u64 lo = 0; u32 hi = 0;
+        for (int i = 0; i < np; ++i) {
+            u64 pr = (u64)tt[i * CB + ci] * it.mi[(long)i * W + k];
+            u64 nl = lo + pr;
+            hi += (nl < lo);
+            lo = nl;
         }
-        if (ge) fix = -1;
+        const u64 qm = (u64)q * it.M[k];
+        int h = (int)hi - (lo < qm);
+        colLo[k * CB + ci] = lo - qm;
+        colHi[k * CB + ci] = h;          // column value = lo + h * 2^64, h may be -1
     }
-    if (__any(fix != 0)) {
-        long long cy = 0;
+    __syncthreads();
+    u32 *out = tt + (size_t)np * CB;               // [W][CB] result words
+    if (g == 0) {
+        typedef __int128 i128;
+        i128 carry = 0;
         for (int k = 0; k < W; ++k) {
-            long long t = (long long)out[k * 64 + lane] + (long long)fix * (long long)it.M[k] + cy;
-            out[k * 64 + lane] = (u32)t;
-            cy = t >> 32;
+            i128 total = carry + (i128)(unsigned __int128)colLo[k * CB + ci] + ((i128)colHi[k * CB + ci] << 64);
+            out[k * CB + ci] = (u32)total;
+            carry = total >> 32;
+        }
+        // carry = floor((S - q*M) / 2^(32W)): -1 => negative, 0 => in [0, 2^(32W))
+        int fix = 0;                          // +1: add M, -1: subtract M
+        if (carry < 0) fix = 1;
+        else {
+            bool ge = true;                   // out >= M ?
+            for (int k = W - 1; k >= 0; --k) {
+                u32 x = out[k * CB + ci], y = it.M[k];
+                if (x != y) { ge = x > y; break; }
+            }
+            if (ge) fix = -1;
+        }
+        if (fix != 0) {
+            long long cy = 0;
+            for (int k = 0; k < W; ++k) {
+                long long t = (long long)out[k * CB + ci] + (long long)fix * (long long)it.M[k] + cy;
+                out[k * CB + ci] = (u32)t;
+                cy = t >> 32;
+            }
         }
     }
     __syncthreads();
     const long slab = (long)nvalid * W;
-    for (long e = lane; e < slab; e += 64) {
-        const int ci = (int)(e / W), k = (int)(e % W);
-        dst[base * W + e] = out[k * 64 + ci];
+    for (long e = threadIdx.x; e < slab; e += CB * NG) {
+        const int c2 = (int)(e / W), k = (int)(e % W);
+        dst[base * W + e] = out[k * CB + c2];
     }
 }
 
