@@ -94,6 +94,15 @@ def main():
         dt = float(t.item())
     ntt_per_s = world * B * args.steps / dt
 
+    # ---- second figure at N > 1: one ciphertext multiply+relinearise with its CRT primes sharded over the ranks
+    sharded = None
+    if world > 1 and not args.no_mulrelin:
+        try:
+            sharded = bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world)
+        except Exception as ex:                      # never lose the headline line to the secondary figure
+            sharded = {"error": repr(ex)[:300]}
+        ck(lib.cuhe_hip_ntt_prepare(L, 0))
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel pair, timed live with hipEvents on the launch stream
@@ -152,13 +161,51 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
                                          "source": "doc/Perf_NTT.txt:14 (bundle 512)"},
-            "mul_relin": mulrelin,
+            "mul_relin": mulrelin, "mul_relin_sharded": sharded,
         }
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
+    """primes of ONE ciphertext sharded over the ranks, a single RCCL all-gather (CRT rows before ICRT)
+    per multiply+relinearise; value = multiplies per second of the whole job (max time over ranks)."""
+    from cuhe_amd import capi
+    from cuhe_amd.sharded import HipBackend, ShardedMulRelin
+    d, p, w, mn, cut, m = 25, 2, 16, 576, 24, 65536
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
+    ck(lib.cuhe_hip_init(None, 0))
+    q = capi.get_params()
+    K, W = q.numEvalKey, lib.cuhe_hip_words_coeff(0)
+    ek = np.random.default_rng(7).integers(0, 1 << 32, (K, q.rawLen, W), dtype=np.uint32)
+    ek[:, :, W - 1] &= 0x7FFF
+    ck(lib.cuhe_hip_init_relin(ek.ctypes.data_as(C.c_void_p)))
+    hb = HipBackend()
+    sh = ShardedMulRelin(hb, 0, rank, world)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    a = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    b = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    na = hb.ntt_rows(sh.own(a).contiguous()); nb = hb.ntt_rows(sh.own(b).contiguous())
+    for _ in range(3):
+        sh.mul_relin(na, nb)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sh.mul_relin(na, nb)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s (one ciphertext, primes sharded)", "ms": round(dt * 1e3, 3),
+            "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "nttLen": q.nttLen,
+            "collective": "1 all-gather of %d B per rank per multiply (RCCL)" % (sh.count * q.crtLen * 4)}
 
 
 def bench_mulrelin(lib, ck, torch, np, dev, args):

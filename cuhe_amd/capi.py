@@ -79,6 +79,11 @@ SIGNATURES = {
     "cuhe_hip_intt_one": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_init_relin": (i32, [vp]),
     "cuhe_hip_relinearization": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt_rows": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_ntt_mul_rows": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_intt_mod_range": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "cuhe_hip_relin_range": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "cuhe_hip_crt_range": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "cuhe_hip_ntt_fwd_batched": (i32, [vp, vp, i32, i32, lng, i32, vp]),
     "cuhe_hip_ntt_inv_batched": (i32, [vp, vp, i32, i32, lng, i32, i32, i32, vp]),
     "cuhe_hip_ntt_prepare": (i32, [i32, i32]),

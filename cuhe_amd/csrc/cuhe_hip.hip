@@ -283,11 +283,17 @@ int level_of(int logq, int *lvl, int *np, int *W) {
     return CUHE_OK;
 }
 
-int barrett_impl(u32 *dst, const u32 *src, int lvl, int dev, hipStream_t st) {
+// PrimeTab whose row 0 is prime `prime0` (CRT-prime-sharded calls address their own rows from 0)
+PrimeTab prime_tab_at(const DevCtx &D, int prime0) {
+    return PrimeTab{D.p + prime0, D.pinv + prime0, D.e64 + prime0, D.pow32 + (size_t)prime0 * D.maxW, D.maxW};
+}
+
+// reduction modulo the polynomial modulus of rows belonging to primes [prime0, prime0+np)
+int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStream_t st) {
     const Params &q = G_.prm;
     DevCtx &D = G_.dev[dev];
-    const int np = q.numCrtPrimeAt(lvl), n = q.modLen, L = q.nttLen, cl = q.crtLen;
-    PrimeTab pt = prime_tab(D);
+    const int n = q.modLen, L = q.nttLen, cl = q.crtLen;
+    PrimeTab pt = prime_tab_at(D, prime0);
     const int kind = G_.force_generic ? 0 : G_.reduce_kind;
     if (kind == 1) {
         hipLaunchKernelGGL((k_reduce_special<0>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L);
@@ -303,18 +309,20 @@ int barrett_impl(u32 *dst, const u32 *src, int lvl, int dev, hipStream_t st) {
     const size_t rows = (size_t)np * L;
     const long pairs = (long)rows / 2;
     const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
+    const u64 *u_ntt = D.u_ntt + (size_t)prime0 * L, *m_ntt = D.m_ntt + (size_t)prime0 * L;
+    const u32 *m_crt = D.m_crt + (size_t)prime0 * cl;
     WindowArgs wa{0, 0, 0};
     if (src != D.b_src) HIPCHK(hipMemcpyAsync(D.b_src, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
     CHK(run_ntt(L, kSrcU32Ext, D.b_ntt, D.b_src + (n - 1), np, L, L, L, 0, wa, dev, st));            // f >> (n-1)
-    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, D.u_ntt, pairs);
-    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, 0, wa, dev, st));                      // u * (f>>(n-1))
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, u_ntt, pairs);
+    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // u * (f>>(n-1))
     hipLaunchKernelGGL(k_zero_rows, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_crt, n, L);
     CHK(run_ntt(L, kSrcU32Ext, D.b_ntt, D.b_crt + n, np, L, L, L, 0, wa, dev, st));                  // q = (..)>>n
-    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, D.m_ntt, pairs);
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, m_ntt, pairs);
     hipLaunchKernelGGL(k_barrett_sub, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, D.b_crt, pt, n, n, L);
-    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, 0, wa, dev, st));                      // (m - x^n) * q
+    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // (m - x^n) * q
     hipLaunchKernelGGL(k_barrett_sub, dim3((L + 255) / 256, np), dim3(256), 0, st, D.b_src, D.b_crt, pt, 0, L, L);
-    hipLaunchKernelGGL(k_barrett_sub_mc, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, D.m_crt, pt, n, cl, L);
+    hipLaunchKernelGGL(k_barrett_sub_mc, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, m_crt, pt, n, cl, L);
     hipLaunchKernelGGL(k_gather_rows, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, D.b_src, cl, L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
@@ -706,7 +714,7 @@ int cuhe_hip_intt_double_deg(uint32_t *x, const uint64_t *X, int logq, int dev, 
 int cuhe_hip_barrett(uint32_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
     CHK(need_init(dev));
     if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
-    return barrett_impl(dst, src, lvl, dev, S(st));
+    return barrett_impl(dst, src, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st));
 }
 int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *st) {
     CHK(need_init(dev));
@@ -716,7 +724,7 @@ int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *s
     CHK(cuhe_hip_intt_hold(X, logq, dev, st));
     int lvl = G_.prm.getLevel(logq);
     if (lvl < 0) return fail(CUHE_EINVAL, "inttMod below level 0");
-    return barrett_impl(x, G_.dev[dev].hold, lvl, dev, S(st));
+    return barrett_impl(x, G_.dev[dev].hold, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st));
 }
 uint32_t *cuhe_hip_intt_result(int dev) {
     if (!G_.inited || dev < 0 || dev >= (int)G_.dev.size()) return nullptr;
@@ -796,17 +804,59 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
     G_.relin_ready = true;
     return CUHE_OK;
 }
-int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
+static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, int count, int dev, void *st) {
     CHK(need_init(dev));
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
     const Params &q = G_.prm;
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
-    DevCtx &D = G_.dev[dev];
     const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = q.nttLen;
+    if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d) at level %d", prime0, prime0 + count, lvl);
+    DevCtx &D = G_.dev[dev];
     CHK(cuhe_hip_nttw((uint64_t *)D.relin, src, q.logCoeff(lvl), dev, st));
     constexpr int PB = 4;
-    hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (np + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, D.relin, D.ek, k,
-                       (long)q.numEvalKey * L, L, np);
+    hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (count + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, D.relin,
+                       D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
+    return relin_range(dst, src, lvl, 0, G_.prm.numCrtPrimeAt(lvl < 0 ? 0 : lvl), dev, st);
+}
+
+// ---------------------------------------------------------------- CRT-prime-sharded variants
+int cuhe_hip_relin_range(uint64_t *dst, const uint32_t *raw, int lvl, int prime0, int count, int dev, void *st) {
+    return relin_range(dst, raw, lvl, prime0, count, dev, st);
+}
+int cuhe_hip_ntt_rows(uint64_t *X, const uint32_t *x, int count, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    return run_ntt(q.nttLen, kSrcU32Ext, X, x, count, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
+}
+int cuhe_hip_ntt_mul_rows(uint64_t *z, const uint64_t *y, const uint64_t *x, int count, int dev, void *st) {
+    CHK(need_init(dev));
+    const long pairs = (long)count * G_.prm.nttLen / 2;
+    const int grid = (int)std::min<long>((pairs + 255) / 256, 8192);
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)y, (const u64 *)x, pairs);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int cuhe_hip_intt_mod_range(uint32_t *x, const uint64_t *X, int lvl, int prime0, int count, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (prime0 < 0 || count < 1 || prime0 + count > q.numCrtPrimeAt(lvl)) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
+    DevCtx &D = G_.dev[dev];
+    CHK(run_ntt(q.nttLen, kSrcU64Neg, D.hold, X, count, q.nttLen, q.nttLen, q.nttLen, prime0, WindowArgs{0, 0, 0}, dev, S(st)));
+    return barrett_impl(x, D.hold, prime0, count, dev, S(st));
+}
+int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0, int count, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
+    DevCtx &D = G_.dev[dev];
+    const Params &q = G_.prm;
+    hipLaunchKernelGGL(k_crt, dim3((q.modLen + 63) / 64), dim3(64), (size_t)W * 64 * 4, S(st), dst, src, prime_tab_at(D, prime0),
+                       count, W, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }

@@ -128,6 +128,15 @@ int cuhe_hip_init_relin(const uint32_t *evalkey_raw_host);
 /* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst ntt u64[np][nttLen] */
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
 
+/* ---- CRT-prime-sharded variants (new): one rank owns primes [prime0, prime0+count) of level
+ * `lvl`; row pointers address the shard's own rows (row 0 = prime0).  Per-prime stages need no communication;
+ * the only exchange of a sharded multiply+relinearise is the all-gather of CRT rows before cuhe_hip_icrt. */
+int cuhe_hip_ntt_rows(uint64_t *X, const uint32_t *x, int count, int dev, void *stream);
+int cuhe_hip_ntt_mul_rows(uint64_t *z, const uint64_t *y, const uint64_t *x, int count, int dev, void *stream);
+int cuhe_hip_intt_mod_range(uint32_t *x, const uint64_t *X, int lvl, int prime0, int count, int dev, void *stream);
+int cuhe_hip_relin_range(uint64_t *dst, const uint32_t *raw, int lvl, int prime0, int count, int dev, void *stream);
+int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0, int count, int dev, void *stream);
+
 /* ---- batched transform primitives (the shape tests/test_ntt.cu:67-100 times):
  * `batch` independent length-`len` transforms, len in {16384, 32768, 65536}. */
 /* forward: src u32[batch][src_stride] (only the first len/2 of each row are read, zero padded),

@@ -326,3 +326,54 @@ def test_config3_full_size_properties(gu):
         assert lhs == [(x + y) % M for x, y in zip(r1, r2)]
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("name", ["toy1155", "prince_small"])
+def test_prime_range_entry_points(gu, name):
+    """CRT-prime-sharded entry points (cuhe_hip_*_range / *_rows): two shards computed one after the other on one
+    GPU and reassembled must equal the unsharded oracle result (the collective itself is covered by
+    tests/test_sharded_gloo.py)."""
+    import torch
+    import oracle_lib as O
+    from cuhe_amd.sharded import HipBackend, ShardedMulRelin, shard_bounds
+    args = PSETS[name]
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE000 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        g.init_relin(ek_raw)
+        hb = HipBackend()
+        for lvl in (0, 1):
+            npr = o.np_(lvl)
+            a, b = _rand_crt(o, npr, 41), _rand_crt(o, npr, 42)
+            want = o.mul_relin_crt(a, b, lvl, ek)
+            # crt_range on raw input
+            W, M = o.words(lvl), o.coeff_modulus(lvl)
+            raw, _ = O.random_raw(q.rawLen, q.modLen, W, M, 99 + lvl)
+            crt_full = o.crt(raw, lvl)
+            world = 2
+            na = hb.ntt_rows(gu.to_dev(a)); nb = hb.ntt_rows(gu.to_dev(b))
+            assert np.array_equal(gu.host_u64(na), o.ntt(a))
+            # stage 1 per shard, then emulate the all-gather by concatenation
+            crt_rows = []
+            for r in range(world):
+                f, c = shard_bounds(npr, world, r)
+                prod = hb.ntt_mul_rows(na[f:f + c].contiguous(), nb[f:f + c].contiguous())
+                crt_rows.append(hb.intt_mod_range(prod, lvl, f, c))
+                d = gu.empty_u32(c, q.crtLen)
+                gu.ck(gu.lib.cuhe_hip_crt_range(d.data_ptr(), gu.to_dev(raw).data_ptr(), o.logq(lvl), f, c, 0, None))
+                assert np.array_equal(gu.host_u32(d), crt_full[f:f + c])
+            crt_all = torch.cat(crt_rows)
+            rawp = hb.icrt(crt_all, lvl)
+            outs = []
+            for r in range(world):
+                f, c = shard_bounds(npr, world, r)
+                outs.append(hb.intt_mod_range(hb.relin_range(rawp, lvl, f, c), lvl, f, c))
+            assert np.array_equal(gu.host_u32(torch.cat(outs)), want)
+            # and the driver object with world == 1
+            sh = ShardedMulRelin(hb, lvl, 0, 1)
+            assert np.array_equal(gu.host_u32(sh.mul_relin(na, nb)), want)
+    finally:
+        g.close(); o.close()
