@@ -604,7 +604,7 @@ int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st
     DevCtx &D = G_.dev[dev];
     if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
     const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt, dim3((q.modLen + 63) / 64), dim3(64), (size_t)W * 64 * 4, S(st), dst, src, prime_tab(D),
+    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)W * kCrtCoef * 4, S(st), dst, src, prime_tab(D),
                        np, W, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
@@ -855,7 +855,7 @@ int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0,
     if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
     DevCtx &D = G_.dev[dev];
     const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt, dim3((q.modLen + 63) / 64), dim3(64), (size_t)W * 64 * 4, S(st), dst, src, prime_tab_at(D, prime0),
+    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)W * kCrtCoef * 4, S(st), dst, src, prime_tab_at(D, prime0),
                        count, W, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;

@@ -243,27 +243,30 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
 }
 
 // ---------------------------------------------------------------- CRT: raw -> residues (crt, Base.cu:857-879)
-// One wave per 64 coefficients.  Words are staged through LDS (coalesced 64*W-word slab load),
-// residue = (sum_k word_k * (2^(32k) mod p)) mod p with a 96-bit accumulator: W multiply-adds per
-// (coefficient, prime) instead of W 64-bit `%`.
-__global__ __launch_bounds__(64)
+// A 256-thread block owns 32 coefficients: their W words are staged through LDS (coalesced 32*W-word slab
+// load), thread (g, ci) = (tid/32, tid%32) produces the residues of coefficient ci for primes i = g mod 8:
+// residue = (sum_k word_k * (2^(32k) mod p)) mod p with a 96-bit accumulator, i.e. W multiply-adds per
+// (coefficient, prime) instead of W 64-bit `%` (the reference's Horner loop, Base.cu:866-875).
+static constexpr int kCrtCoef = 32, kCrtGroups = 8;
+__global__ __launch_bounds__(kCrtCoef * kCrtGroups)
 void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W][64]
-    const int lane = threadIdx.x;
-    const long base = (long)blockIdx.x * 64;
-    const int nvalid = (int)min((long)64, (long)mlen - base);
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W][32]
+    constexpr int CB = kCrtCoef, NG = kCrtGroups;
+    const int ci = threadIdx.x % CB, g = threadIdx.x / CB;
+    const long base = (long)blockIdx.x * CB;
+    const int nvalid = (int)min((long)CB, (long)mlen - base);
     const long slab = (long)nvalid * W;
-    for (long e = lane; e < slab; e += 64) {
-        const int ci = (int)(e / W), k = (int)(e % W);
-        sh[k * 64 + ci] = src[base * W + e];
+    for (long e = threadIdx.x; e < slab; e += CB * NG) {
+        const int c2 = (int)(e / W), k = (int)(e % W);
+        sh[k * CB + c2] = src[base * W + e];
     }
     __syncthreads();
-    if (lane >= nvalid) return;
-    for (int i = 0; i < np; ++i) {
+    if (ci >= nvalid) return;
+    for (int i = g; i < np; i += NG) {
         const u32 *pw = pt.pow32 + (long)i * pt.maxW;
         u64 lo = 0; u32 hi = 0;
         for (int k = 0; k < W; ++k) {
-            u64 pr = (u64)sh[k * 64 + lane] * pw[k];
+            u64 pr = (u64)sh[k * CB + ci] * pw[k];
             u64 nl = lo + pr;
             hi += (nl < lo);
             lo = nl;
@@ -272,7 +275,7 @@ void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int 
         const u64 m = pt.pinv[i];
         u32 r1 = mod_small(lo, p, m);
         u64 r2 = (u64)hi * pt.e64[i] + r1;
-        dst[(long)i * clen + base + lane] = mod_small(r2, p, m);
+        dst[(long)i * clen + base + ci] = mod_small(r2, p, m);
     }
 }
 

@@ -377,3 +377,63 @@ def test_prime_range_entry_points(gu, name):
             assert np.array_equal(gu.host_u32(sh.mul_relin(na, nb)), want)
     finally:
         g.close(); o.close()
+
+
+def test_remaining_entry_points_and_ragged_cases(gu):
+    """single-polynomial drivers (_ntt/_nttw/_intt, cuhe/Operations.h:78-81), inttHold + inttResult + barrett(dst,lvl),
+    crtMulInt, an inverse batch with a prime offset and a store count that is not a multiple of the tile, and empty batches."""
+    import ctypes as C
+    import oracle_lib as O
+    args = PSETS["dhs_simple"]                   # modLen = 8190 < crtLen = 8192: ragged rows
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q, lib, ck = o.prm, gu.lib, gu.ck
+        L, cl = q.nttLen, q.crtLen
+        npr = q.numCrtPrime
+        a = _rand_crt(o, npr, 77)
+        assert not a[:, q.modLen:].any()
+        # _ntt on one row, _intt with an explicit prime index
+        dx, dX = gu.to_dev(a[3]), gu.empty_u64(L)
+        ck(lib.cuhe_hip_ntt_one(dX.data_ptr(), dx.data_ptr(), 0, None))
+        X3 = gu.host_u64(dX)
+        assert np.array_equal(X3, O.ntt_ext(a[3], L))
+        dback = gu.empty_u32(L)
+        ck(lib.cuhe_hip_intt_one(dback.data_ptr(), dX.data_ptr(), 3, 0, None))
+        assert np.array_equal(gu.host_u32(dback), O.intt_modp(X3, L, int(o.primes[3])))
+        # _nttw: window 5 of a raw polynomial
+        W = o.words(0)
+        raw, _ = O.random_raw(q.rawLen, q.modLen, W, o.coeff_modulus(0), 5)
+        dW = gu.empty_u64(L)
+        ck(lib.cuhe_hip_nttw_one(dW.data_ptr(), gu.to_dev(raw).data_ptr(), W, 5, 0, None))
+        assert np.array_equal(gu.host_u64(dW), o.nttw(raw, 0)[5])
+        # inverse batch: rows 2..5 reduced modulo primes 2..5, only the first 5000 outputs stored
+        X = o.ntt(a)
+        nst = 5000
+        d = gu.empty_u32(4, L)
+        ck(lib.cuhe_hip_ntt_inv_batched(d.data_ptr(), gu.to_dev(X[2:6]).data_ptr(), L, 4, L, nst, 2, 0, None))
+        got = gu.host_u32(d)
+        for r in range(4):
+            want = O.intt_modp(X[2 + r], L, int(o.primes[2 + r]))
+            assert np.array_equal(got[r, :nst], want[:nst]) and not got[r, nst:].any()
+        # empty batches are no-ops
+        ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), dx.data_ptr(), L, 0, L // 2, 0, None))
+        ck(lib.cuhe_hip_ntt_inv_batched(d.data_ptr(), dX.data_ptr(), L, 0, L, L, 0, 0, None))
+        assert lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), dx.data_ptr(), 12345, 1, 8192, 0, None) != 0    # bad length
+        # inttHold -> inttResult -> barrett(dst, lvl)
+        b = _rand_crt(o, npr, 78)
+        P = o.ntt_mul(X, o.ntt(b))
+        ck(lib.cuhe_hip_intt_hold(gu.to_dev(P).data_ptr(), o.logq(0), 0, None))
+        hold = lib.cuhe_hip_intt_result(0)
+        assert hold
+        dr = gu.empty_u32(npr, cl)
+        ck(lib.cuhe_hip_barrett_hold(dr.data_ptr(), 0, 0, None))
+        assert np.array_equal(gu.host_u32(dr), o.intt_mod(P))
+        # crtMulInt: constant term times an integer (cuhe/Base.cu:1078-1087)
+        da = gu.to_dev(a)
+        ck(lib.cuhe_hip_crt_mul_int(da.data_ptr(), da.data_ptr(), 12345, o.logq(0), 0, None))
+        got = gu.host_u32(da)
+        want = a.copy()
+        want[:, 0] = (a[:, 0].astype(np.uint64) * 12345 % o.primes.astype(np.uint64)).astype(np.uint32)
+        assert np.array_equal(got, want)
+    finally:
+        g.close(); o.close()
