@@ -21,17 +21,27 @@ typedef unsigned int u32;
 static constexpr u64 kP = 0xffffffff00000001ULL;
 static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
 
-// canonical -> canonical
-__device__ __forceinline__ u64 addp(u64 a, u64 b) {
-    u64 s = a + b;
-    u64 t = s + kEps;            // s - P (mod 2^64)
-    bool carry = s < a;          // true sum >= 2^64
-    bool ge = t < s;             // s >= P
-    return (carry | ge) ? t : s;
-}
+// canonical -> canonical.  Instruction selection was chosen by measurement (tools/ubench_modp.hip,
+// profiles/r01_ubench_modp.txt): the add is done as a - (P - b) with a mask-and-subtract fix-up, which
+// needs one compare instead of two compares + s_or.
 __device__ __forceinline__ u64 subp(u64 a, u64 b) {
     u64 d = a - b;
     return (a < b) ? d - kEps : d;     // + P
+}
+#ifndef CUHE_ADDP_VARIANT
+#define CUHE_ADDP_VARIANT 0      /* measured best (profiles/r01_dft_variants.txt) */
+#endif
+__device__ __forceinline__ u64 addp(u64 a, u64 b) {
+#if CUHE_ADDP_VARIANT == 1
+    u64 nb = kP - b;                   // in (0, P]; a - nb = a + b - P
+    u64 d = a - nb;
+    u64 m = (u64)0 - (u64)(a < nb);    // all ones on borrow
+    return d - (m & kEps);             // + P on borrow
+#else
+    u64 s = a + b;
+    u64 t = s + kEps;                  // s - P (mod 2^64)
+    return ((s < a) | (t < s)) ? t : s;    // carried, or s >= P
+#endif
 }
 __device__ __forceinline__ u64 negp(u64 a) { return a ? kP - a : 0; }
 
@@ -41,15 +51,33 @@ __device__ __forceinline__ u64 canon(u64 r) {
     return (t < r) ? t : r;
 }
 
+// lo + m*eps for a 32-bit m, canonical result: ONE correction, because "the 64-bit sum carried" and
+// "the sum is >= P" exclude each other and both call for + eps.  (m*eps + lo is one v_mad_u64_u32.)
+#ifndef CUHE_SHLMID_VARIANT
+#define CUHE_SHLMID_VARIANT 0
+#endif
+#ifndef CUHE_MADEPS_VARIANT
+#define CUHE_MADEPS_VARIANT 1
+#endif
+__device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
+#if CUHE_MADEPS_VARIANT == 1
+    u64 r = (u64)m * 0xffffffffu + lo;
+    u64 t = r + kEps;
+    return ((r < lo) | (t < r)) ? t : r;
+#else
+    u64 t1 = ((u64)m << 32) - m;
+    u64 r = lo + t1;
+    if (r < lo) r += kEps;
+    return canon(r);
+#endif
+}
+
 // 128-bit (hi:lo) -> canonical; hi = hh:hl.  lo + hl*(phi-1) - hh
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= kEps;                       // borrowed 2^64 = eps
-    u64 t1 = ((u64)hl << 32) - hl;                 // hl * eps  (< P)
-    u64 r = t0 + t1;
-    if (r < t0) r += kEps;
-    return canon(r);
+    u64 r = mad_eps(hl, lo);
+    u64 d = r - hh;
+    return (r < hh) ? d - kEps : d;
 }
 
 // canonical x canonical -> canonical
@@ -69,11 +97,7 @@ __device__ __forceinline__ u64 mulp_u32(u64 a, u32 b) {
     u64 t = (u64)a0 * b;
     u64 u = (u64)a1 * b + (t >> 32);
     u64 lo = (u << 32) | (u32)t;
-    u32 mid = (u32)(u >> 32);                      // bits 64..95
-    u64 t1 = ((u64)mid << 32) - mid;
-    u64 r = lo + t1;
-    if (r < lo) r += kEps;
-    return canon(r);
+    return mad_eps((u32)(u >> 32), lo);            // bits 64..95 fold with eps
 }
 
 // x * 2^K mod P for a compile-time K in [0, 96); x canonical.
@@ -84,28 +108,16 @@ __device__ __forceinline__ u64 shlp(u64 x) {
     if constexpr (K == 0) {
         return x;
     } else if constexpr (K < 32) {
-        u64 lo = x << K;
-        u32 mid = (u32)(x >> (64 - K));
-        u64 t1 = ((u64)mid << 32) - mid;
-        u64 r = lo + t1;
-        if (r < lo) r += kEps;
-        return canon(r);
+        return mad_eps((u32)(x >> (64 - K)), x << K);
     } else if constexpr (K == 32) {
-        u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-        u64 lo = (u64)x0 << 32;
-        u64 t1 = ((u64)x1 << 32) - x1;
-        u64 r = lo + t1;
-        if (r < lo) r += kEps;
-        return canon(r);
+        return mad_eps((u32)(x >> 32), (u64)(u32)x << 32);         // x0*phi + x1*(phi-1)
     } else if constexpr (K < 64) {
-        u64 lo = x << K;                           // low 64 bits
-        u32 mid = (u32)(x >> (64 - K));            // bits 64..95
-        u64 hi = x >> (96 - K);                    // bits 96.. (< 2^(K-32))
-        u64 t1 = ((u64)mid << 32) - mid;
-        u64 r = lo + t1;
-        if (r < lo) r += kEps;
-        r = canon(r);
-        return subp(r, hi);
+#if CUHE_SHLMID_VARIANT == 1
+        return shlp<32>(shlp<K - 32>(x));
+#else
+        u64 r = mad_eps((u32)(x >> (64 - K)), x << K);      // bits 0..95
+        return subp(r, x >> (96 - K));                       // minus bits 96.. (2^96 = -1)
+#endif
     } else if constexpr (K == 64) {
         u32 x0 = (u32)x, x1 = (u32)(x >> 32);
         u64 t1 = ((u64)x0 << 32) - x0;             // x0 * eps

@@ -49,6 +49,42 @@ __device__ __forceinline__ u64 subp_m(u64 a, u64 b) {
 }
 __device__ __forceinline__ u64 addp_m(u64 a, u64 b) { return subp_m(a, kP - b); }
 
+// ---- candidate shift: one correction for (carry of lo + mid*eps) and (result >= P), which exclude each other
+template <int K>
+__device__ __forceinline__ u64 shlp_v2(u64 x) {
+    static_assert(K > 0 && K < 32, "");
+    u64 lo = x << K;
+    u32 mid = (u32)(x >> (64 - K));
+    u64 r = (u64)mid * 0xffffffffu + lo;       // one v_mad_u64_u32
+    u64 t = r + kEps;
+    return ((r < lo) | (t < r)) ? t : r;
+}
+__device__ __forceinline__ u64 shl32_v2(u64 y) {    // y * 2^32 = y0*phi + y1*(phi-1)
+    u32 y0 = (u32)y, y1 = (u32)(y >> 32);
+    u64 lo = (u64)y0 << 32;
+    u64 r = (u64)y1 * 0xffffffffu + lo;
+    u64 t = r + kEps;
+    return ((r < lo) | (t < r)) ? t : r;
+}
+template <int K>
+__device__ __forceinline__ u64 shlp_v2_mid(u64 x) { return shl32_v2(shlp_v2<K - 32>(x)); }
+// mul with merged corrections
+__device__ __forceinline__ u64 mulp_v2(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 t = (u64)a0 * b0;
+    u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v = (u64)a1 * b0 + (u32)u;
+    u64 w = (u64)a1 * b1 + (u >> 32) + (v >> 32);
+    u64 lo = (v << 32) | (u32)t;
+    u32 hh = (u32)(w >> 32), hl = (u32)w;
+    // lo + hl*eps - hh  ==  lo + hl*eps + (P - hh) - P ; P - hh = (eps - hh... ) keep it simple: two steps
+    u64 r = (u64)hl * 0xffffffffu + lo;
+    u64 t1 = r + kEps;
+    r = ((r < lo) | (t1 < r)) ? t1 : r;        // canonical lo + hl*eps
+    u64 d = r - hh;
+    return (r < hh) ? d - kEps : d;
+}
+enum { OP_SHL7_V2 = 100, OP_SHL45_V2, OP_MUL_V2 };
 enum { OP_ADD, OP_SUB, OP_MUL, OP_SHL7, OP_SHL45, OP_SHL72, OP_ADD_CC, OP_SUB_CC, OP_ADD_M, OP_SUB_M, OP_BFLY, OP_BFLY_CC, OP_MODSMALL };
 
 template <int OP>
@@ -70,6 +106,9 @@ __global__ __launch_bounds__(256) void kern(u64 *out, u64 seed) {
             else if (OP == OP_SUB_M) x[i] = subp_m(x[i], y[i]);
             else if (OP == OP_BFLY) { u64 u = x[i], v = y[i]; x[i] = addp(u, v); y[i] = subp(u, v); }
             else if (OP == OP_BFLY_CC) { u64 u = x[i], v = y[i]; x[i] = addp_cc(u, v); y[i] = subp_cc(u, v); }
+            else if (OP == OP_SHL7_V2) x[i] = shlp_v2<7>(x[i]);
+            else if (OP == OP_SHL45_V2) x[i] = shlp_v2_mid<45>(x[i]);
+            else if (OP == OP_MUL_V2) x[i] = mulp_v2(x[i], y[i]);
             else if (OP == OP_MODSMALL) x[i] = x[i] * 3 + mod_small(x[i], 16777213u, 0x10000030000ULL);
         }
     }
@@ -98,7 +137,7 @@ int main() {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
     u64 *out; hipMalloc(&out, (size_t)cus * 8 * 256 * 8);
-    for (int occ : {2, 8}) {
+    for (int occ : {2}) {
         run<OP_ADD>("addp", out, cus, occ, 1);
         run<OP_SUB>("subp", out, cus, occ, 1);
         run<OP_ADD_CC>("addp_cc", out, cus, occ, 1);
@@ -111,6 +150,9 @@ int main() {
         run<OP_SHL7>("shlp<7>", out, cus, occ, 1);
         run<OP_SHL45>("shlp<45>", out, cus, occ, 1);
         run<OP_SHL72>("shlp<72>", out, cus, occ, 1);
+        run<OP_SHL7_V2>("shlp_v2<7>", out, cus, occ, 1);
+        run<OP_SHL45_V2>("shlp_v2<45>", out, cus, occ, 1);
+        run<OP_MUL_V2>("mulp_v2", out, cus, occ, 1);
         run<OP_MODSMALL>("mod_small", out, cus, occ, 1);
     }
     return 0;
