@@ -154,7 +154,7 @@ void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
         const int j2 = col0 + col;
 #pragma unroll
         for (int d = 0; d < R2; ++d) {
-            out[j2 * N1 + c + R1 * d] = y[bitrev<R2>(d)];
+            out[j2 * N1 + c + R1 * d] = y[bitrev<R2>(d)];        // plain store: pass 2 re-reads it from cache
         }
     }
 }
@@ -176,7 +176,7 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u
     // pair: pass 1 is issue-bound, pass 2 has VALU slack under its loads/stores (profiles/r01_chunk_sweep.txt)
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        u64 v = in[j * N1];
+        u64 v = __builtin_nontemporal_load(&in[j * N1]);      // slab is read exactly once
         if (INV || j != 0) v = mulp(v, tw[j * N1]);
         x[j] = v;
     }
@@ -184,7 +184,7 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u
     if constexpr (!INV) {
         u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
 #pragma unroll
-        for (int k2 = 0; k2 < 64; ++k2) dst[k2 * N1] = x[bitrev<64>(k2)];
+        for (int k2 = 0; k2 < 64; ++k2) __builtin_nontemporal_store(x[bitrev<64>(k2)], &dst[k2 * N1]);
     } else {
         // cuhe/Base.cu:469-490: (x * L^-1 mod P) % p_i -> u32 (L^-1 already in T2)
         const u32 p = primes[prime0 + batch];
