@@ -191,9 +191,9 @@ template <int LG, bool INV>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
                  const u64 *pinv, int prime0, hipStream_t st) {
     constexpr int N1 = (1 << LG) / 64;
-    const int tiles = N1 / kNttThreads;
+    const int tiles = N1 / p2_threads<LG>();
     const int grid = ((nb + 7) / 8) * 8 * tiles;
-    hipLaunchKernelGGL((ntt_pass2<LG, INV>), dim3(grid), dim3(kNttThreads), 0, st, dst, scratch, INV ? tab.T2inv : tab.T2,
+    hipLaunchKernelGGL((ntt_pass2<LG, INV>), dim3(grid), dim3(p2_threads<LG>()), 0, st, dst, scratch, INV ? tab.T2inv : tab.T2,
                        dst_stride, nb, nstore, primes, pinv, prime0);
     HIPCHK(hipGetLastError());
     return CUHE_OK;

@@ -38,6 +38,11 @@ template <> struct NttGeom<15> { static constexpr int R1 = 16, R2 = 32, NC = 16;
 template <> struct NttGeom<16> { static constexpr int R1 = 32, R2 = 32, NC = 8; };
 
 static constexpr int kNttThreads = 256;
+#ifndef CUHE_P2_THREADS
+#define CUHE_P2_THREADS 256
+#endif
+// pass-2 workgroup size: one thread per k1, a workgroup covers p2_threads<LG>() adjacent k1
+template <int LG> constexpr int p2_threads() { return ((1 << LG) / 64 < CUHE_P2_THREADS) ? (1 << LG) / 64 : CUHE_P2_THREADS; }
 
 template <int LG>
 struct NttLds {
@@ -160,15 +165,15 @@ void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
 }
 
 template <int LG, bool INV>
-__global__ __launch_bounds__(kNttThreads, 2)
+__global__ __launch_bounds__(p2_threads<LG>(), (p2_threads<LG>() >= 512 ? 2 : 2))
 void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
                long dst_stride, int nbatch, int nstore,
                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
     constexpr int L = 1 << LG, N1 = L / 64;
     int batch, tile;
-    xcd_map(N1 / kNttThreads, batch, tile);
+    xcd_map(N1 / p2_threads<LG>(), batch, tile);
     if (batch >= nbatch) return;
-    const int k1 = tile * kNttThreads + threadIdx.x;
+    const int k1 = tile * p2_threads<LG>() + threadIdx.x;
     const u64 *in = scratch + (long)batch * L + k1;
     const u64 *tw = T2 + k1;
     u64 x[64];
