@@ -437,3 +437,33 @@ def test_remaining_entry_points_and_ragged_cases(gu):
         assert np.array_equal(got, want)
     finally:
         g.close(); o.close()
+
+
+def test_prince_full_size_properties(gu):
+    """BASELINE config 5 parameters (examples/Prince/Prince.cu:48-49): n = 16384, L = 32768, 25 primes, composite
+    m = 21845, generic NTT Barrett.  Size-independent properties of exact arithmetic in Z_q[x]/Phi_m:
+    x^m = 1, so (a * x^k) * x^(m-k) == a;  a * 1 == a;  bilinearity;  CRT->ICRT round trip."""
+    import oracle_lib as O
+    g = gu.GpuCtx(25, 2, 16, 25, 25, 21845)
+    try:
+        q = g.prm
+        assert (q.modLen, q.nttLen, q.numCrtPrime, q.numEvalKey) == (16384, 32768, 25, 40)
+        assert gu.lib.cuhe_hip_reduce_kind() == 0
+        m, n = q.mSize, q.modLen
+        for lvl in (0, 24):
+            W, M = g.words(lvl), g.coeff_modulus(lvl)
+            a, av = O.random_raw(q.rawLen, n, W, M, 11 + lvl)
+            b, bv = O.random_raw(q.rawLen, n, W, M, 12 + lvl)
+            c, cv = O.random_raw(q.rawLen, n, W, M, 13 + lvl)
+            assert np.array_equal(g.icrt(g.crt(a, lvl), lvl), a)
+            assert np.array_equal(g.mul_raw(a, O.ints_to_raw([1], q.rawLen, W), lvl), a)
+            k = 10000
+            xk = O.ints_to_raw([0] * k + [1], q.rawLen, W)
+            xmk = O.ints_to_raw([0] * (m - k) + [1], q.rawLen, W)
+            assert np.array_equal(g.mul_raw(g.mul_raw(a, xk, lvl), xmk, lvl), a)
+            ab = O.ints_to_raw([(x + y) % M for x, y in zip(av, bv)], q.rawLen, W)
+            lhs = O.raw_to_ints(g.mul_raw(ab, c, lvl), n)
+            r1, r2 = O.raw_to_ints(g.mul_raw(a, c, lvl), n), O.raw_to_ints(g.mul_raw(b, c, lvl), n)
+            assert lhs == [(x + y) % M for x, y in zip(r1, r2)]
+    finally:
+        g.close()
