@@ -187,17 +187,19 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, lon
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
-template <int LG, bool INV>
+template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
                  const u64 *pinv, int prime0, hipStream_t st) {
     constexpr int N1 = (1 << LG) / 64;
     const int tiles = N1 / p2_threads<LG>();
     const int grid = ((nb + 7) / 8) * 8 * tiles;
-    hipLaunchKernelGGL((ntt_pass2<LG, INV>), dim3(grid), dim3(p2_threads<LG>()), 0, st, dst, scratch, INV ? tab.T2inv : tab.T2,
+    hipLaunchKernelGGL((ntt_pass2<LG, OUT>), dim3(grid), dim3(p2_threads<LG>()), 0, st, dst, scratch, OUT != kOutU64 ? tab.T2inv : tab.T2,
                        dst_stride, nb, nstore, primes, pinv, prime0);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
+
+constexpr int kFoldXn1 = -1;     // nstore sentinel: inverse transform fused with the reduction mod x^(L/2)+1
 
 struct EvTimer {                 // optional per-pass hipEvent timing (bench)
     std::vector<hipEvent_t> ev;
@@ -241,10 +243,11 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU64Neg) {
             u32 *d = (u32 *)dst + (long)b0 * dst_stride;
-            CHK((launch_pass2<LG, true>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2)));
+            if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2)));
+            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            CHK((launch_pass2<LG, false>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
+            CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
@@ -720,7 +723,17 @@ int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *st) {
     CHK(need_init(dev));
     return cuhe_hip_barrett(dst, G_.dev[dev].hold, lvl, dev, st);
 }
+static bool fused_xn1() {
+    return !G_.force_generic && G_.reduce_kind == 1 && G_.prm.modLen * 2 == G_.prm.nttLen && G_.prm.crtLen == G_.prm.modLen;
+}
 int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
+    if (fused_xn1()) {          // Phi_m = x^n + 1 with n = L/2: INTT, mod p_i and the reduction in one pass-2 epilogue
+        CHK(need_init(dev));
+        int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+        if (lvl < 0) return fail(CUHE_EINVAL, "inttMod below level 0");
+        const Params &q = G_.prm;
+        return run_ntt(q.nttLen, kSrcU64Neg, x, X, np, q.nttLen, q.crtLen, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, S(st));
+    }
     CHK(cuhe_hip_intt_hold(X, logq, dev, st));
     int lvl = G_.prm.getLevel(logq);
     if (lvl < 0) return fail(CUHE_EINVAL, "inttMod below level 0");
@@ -846,6 +859,8 @@ int cuhe_hip_intt_mod_range(uint32_t *x, const uint64_t *X, int lvl, int prime0,
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     if (prime0 < 0 || count < 1 || prime0 + count > q.numCrtPrimeAt(lvl)) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
     DevCtx &D = G_.dev[dev];
+    if (fused_xn1())
+        return run_ntt(q.nttLen, kSrcU64Neg, x, X, count, q.nttLen, q.crtLen, kFoldXn1, prime0, WindowArgs{0, 0, 0}, dev, S(st));
     CHK(run_ntt(q.nttLen, kSrcU64Neg, D.hold, X, count, q.nttLen, q.nttLen, q.nttLen, prime0, WindowArgs{0, 0, 0}, dev, S(st)));
     return barrett_impl(x, D.hold, prime0, count, dev, S(st));
 }

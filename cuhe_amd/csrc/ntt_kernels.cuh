@@ -164,12 +164,15 @@ void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
     }
 }
 
-template <int LG, bool INV>
-__global__ __launch_bounds__(p2_threads<LG>(), (p2_threads<LG>() >= 512 ? 2 : 2))
+enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2 };
+
+template <int LG, int OUT>
+__global__ __launch_bounds__(p2_threads<LG>(), 2)
 void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
                long dst_stride, int nbatch, int nstore,
                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
     constexpr int L = 1 << LG, N1 = L / 64;
+    constexpr bool INV = OUT != kOutU64;
     int batch, tile;
     xcd_map(N1 / p2_threads<LG>(), batch, tile);
     if (batch >= nbatch) return;
@@ -186,11 +189,11 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u
         x[j] = v;
     }
     dft_regs<64, false>(x);
-    if constexpr (!INV) {
+    if constexpr (OUT == kOutU64) {
         u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
 #pragma unroll
         for (int k2 = 0; k2 < 64; ++k2) __builtin_nontemporal_store(x[bitrev<64>(k2)], &dst[k2 * N1]);
-    } else {
+    } else if constexpr (OUT == kOutModP) {
         // cuhe/Base.cu:469-490: (x * L^-1 mod P) % p_i -> u32 (L^-1 already in T2)
         const u32 p = primes[prime0 + batch];
         const u64 m = pinv[prime0 + batch];
@@ -199,6 +202,20 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u
 #pragma unroll
         for (int k2 = 0; k2 < 64; ++k2)
             if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[k2 * N1] = mod_small(x[bitrev<64>(k2)], p, m);
+    } else {
+        // inverse transform of a product fused with the reduction modulo x^(L/2) + 1 (inttMod when Phi_m = x^n + 1,
+        // n = L/2): the thread owns f[i] (k2) and f[i + n] (k2 + 32); r[i] = (f[i] - f[i+n]) mod p_i.  The values are
+        // the exact integer coefficients (< P), so the signed difference is reduced once instead of both terms.
+        const u32 p = primes[prime0 + batch];
+        const u64 m = pinv[prime0 + batch];
+        u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) {
+            const u64 a = x[bitrev<64>(k2)], b = x[bitrev<64>(k2 + 32)];
+            const bool neg = a < b;
+            const u32 r = mod_small(neg ? b - a : a - b, p, m);
+            dst[k2 * N1] = (neg && r) ? p - r : r;
+        }
     }
 }
 
