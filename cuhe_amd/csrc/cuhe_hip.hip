@@ -67,6 +67,7 @@ struct DevCtx {
     u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *relin = nullptr, *ek = nullptr;
+    u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows of the ciphertext being relinearised
     // allocator (cuhe/DeviceManager.cu:98-138)
     // helper streams/events for the pass-1 / pass-2 software pipeline
     hipStream_t s1 = nullptr, s2 = nullptr;
@@ -522,7 +523,7 @@ int cuhe_hip_shutdown(void) {
         for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch[0]); hipFree(t.scratch[1]); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.b_ntt, D.m_crt, D.b_src, D.b_crt,
-                        D.hold, D.relin, D.ek};
+                        D.hold, D.relin, D.ek, D.win};
         for (void *p : ptrs) if (p) hipFree(p);
         for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
         for (auto &kv : D.freeBlocks) hipFree(kv.second);
@@ -798,6 +799,8 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
         if (D.relin) { hipFree(D.relin); D.relin = nullptr; }
         HIPCHK(hipMalloc((void **)&D.ek, (size_t)np * K * L * sizeof(u64)));
         HIPCHK(hipMalloc((void **)&D.relin, (size_t)K * L * sizeof(u64)));
+        if (D.win) { hipFree(D.win); D.win = nullptr; }
+        HIPCHK(hipMalloc((void **)&D.win, (size_t)K * q.crtLen * sizeof(u32)));
         u32 *raw = nullptr, *crt = nullptr; u64 *ntt = nullptr;
         HIPCHK(hipMalloc((void **)&raw, rawBytes));
         HIPCHK(hipMalloc((void **)&crt, (size_t)np * q.crtLen * 4));
@@ -825,7 +828,12 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = q.nttLen;
     if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d) at level %d", prime0, prime0 + count, lvl);
     DevCtx &D = G_.dev[dev];
-    CHK(cuhe_hip_nttw((uint64_t *)D.relin, src, q.logCoeff(lvl), dev, st));
+    // window rows once (coalesced), then k plain zero-padded transforms (replaces k strided window loads)
+    const int W = q.wordsCoeff(lvl);
+    hipLaunchKernelGGL(k_extract_windows, dim3((q.crtLen + kWinCoef - 1) / kWinCoef), dim3(kWinCoef * kWinGroups),
+                       (size_t)W * kWinCoef * 4, S(st), D.win, src, W, q.logRelin, k, q.crtLen, q.crtLen);
+    HIPCHK(hipGetLastError());
+    CHK(run_ntt(L, kSrcU32Ext, D.relin, D.win, k, q.crtLen, L, L, 0, WindowArgs{0, 0, 0}, dev, S(st)));
     constexpr int PB = 4;
     hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (count + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, D.relin,
                        D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count);

@@ -242,6 +242,34 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
     }
 }
 
+// ---------------------------------------------------------------- relinearisation windows
+// win[j][idx] = bits [w*j, w*j + w) of coefficient idx (cuhe/Base.cu:361-371), for all j < k: the raw slab is read
+// ONCE, coalesced, through LDS and every window row is written coalesced, so that the k window transforms run on a
+// compact u32 array (the reference re-reads the W-word coefficients with stride W for every window).
+static constexpr int kWinCoef = 64, kWinGroups = 4;
+__global__ __launch_bounds__(kWinCoef * kWinGroups)
+void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W, int w, int k, int ncoef, int clen) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W][64]
+    constexpr int CB = kWinCoef, NG = kWinGroups;
+    const int ci = threadIdx.x % CB, g = threadIdx.x / CB;
+    const long base = (long)blockIdx.x * CB;
+    const int nvalid = (int)min((long)CB, (long)ncoef - base);
+    const long slab = (long)nvalid * W;
+    for (long e = threadIdx.x; e < slab; e += CB * NG) {
+        const int c2 = (int)(e / W), kk = (int)(e % W);
+        sh[kk * CB + c2] = raw[base * W + e];
+    }
+    __syncthreads();
+    if (ci >= nvalid) return;
+    const u32 mask = (u32)((1u << w) - 1u);
+    for (int j = g; j < k; j += NG) {
+        const int bit = w * j, wi = bit >> 5;
+        u64 s = sh[wi * CB + ci];
+        if (wi + 1 < W) s |= (u64)sh[(wi + 1) * CB + ci] << 32;
+        win[(long)j * clen + base + ci] = (u32)(s >> (bit & 31)) & mask;
+    }
+}
+
 // ---------------------------------------------------------------- CRT: raw -> residues (crt, Base.cu:857-879)
 // A 256-thread block owns 32 coefficients: their W words are staged through LDS (coalesced 32*W-word slab
 // load), thread (g, ci) = (tid/32, tid%32) produces the residues of coefficient ci for primes i = g mod 8:
