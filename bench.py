@@ -123,8 +123,19 @@ def main():
         # bracket the pipelined region on the launch stream; the serial per-pass durations are reported beside it.
         pair_s = mst.value * 1e-3
         achieved = n_tr * alg_bytes / pair_s / 1e9
+        # traffic: corrected FETCH_SIZE + WRITE_SIZE per launch pair from the committed rocprofv3 PMC passes of this
+        # same command (profiles/traffic_r*.json); PMC collection cannot run inside the timed process.
+        traffic = None
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+            if tf and L == 65536:
+                traffic = json.load(open(tf[-1]))["bytes_per_launch_pair"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_note": "HBM-side bytes per launch pair (256 transforms) from profiles/traffic_r*.json; algorithmic = 167772160",
                     "kernel": "ntt_pass1<16,0> + ntt_pass2<16,false> (one transform = one launch pair)",
                     "algorithmic_bytes_per_transform": alg_bytes,
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),
