@@ -24,9 +24,18 @@ static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
 // canonical -> canonical.  Instruction selection was chosen by measurement (tools/ubench_modp.hip,
 // profiles/r01_ubench_modp.txt): the add is done as a - (P - b) with a mask-and-subtract fix-up, which
 // needs one compare instead of two compares + s_or.
+#ifndef CUHE_SUBP_VARIANT
+#define CUHE_SUBP_VARIANT 1
+#endif
 __device__ __forceinline__ u64 subp(u64 a, u64 b) {
+#if CUHE_SUBP_VARIANT == 1
+    u64 d;
+    const bool borrow = __builtin_usubll_overflow(a, b, &d);   // reuse the borrow of v_sub_co/v_subb_co
+    return borrow ? d - kEps : d;      // + P
+#else
     u64 d = a - b;
     return (a < b) ? d - kEps : d;     // + P
+#endif
 }
 #ifndef CUHE_ADDP_VARIANT
 #define CUHE_ADDP_VARIANT 0      /* measured best (profiles/r01_dft_variants.txt) */
