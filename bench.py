@@ -162,9 +162,10 @@ def main():
                    "sample": "%d 64K-point forward transforms, oracle radix-2 NTT (u128 %% P), OpenMP over transforms, %.1f s"
                              % (sample, cdt)}
 
-        mulrelin = None
+        mulrelin = mulfull = None
         if not args.no_mulrelin and world == 1:
             mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args)
+            mulfull = bench_mul_full(lib, ck, torch, np, dev)
 
         out = {
             "metric": "64K-point fwd NTT/s (u32[32768] -> u64[65536] over P=2^64-2^32+1)",
@@ -178,7 +179,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
                                          "source": "doc/Perf_NTT.txt:14 (bundle 512)"},
-            "mul_relin": mulrelin, "mul_relin_sharded": sharded,
+            "mul_relin": mulrelin, "mul_relin_sharded": sharded, "mul_full": mulfull,
         }
     if world > 1:
         dist.barrier()
@@ -223,6 +224,47 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s (one ciphertext, primes sharded)", "ms": round(dt * 1e3, 3),
             "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "nttLen": q.nttLen,
             "collective": "1 all-gather of %d B per rank per multiply (RCCL)" % (sh.count * q.crtLen * 4)}
+
+
+def bench_mul_full(lib, ck, torch, np, dev):
+    """BASELINE config 3: N = 2^15 (64K-point transforms), 32 CRT primes, full multiply of two raw polynomials
+    CRT -> NTT -> pointwise -> INTT (+ reduction mod x^n+1) -> ICRT, device resident (mulZZX without the ZZX<->raw staging)."""
+    from cuhe_amd import capi
+    d, p, w, mn, cut, m = 9, 2, 16, 576, 24, 65536
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
+    ck(lib.cuhe_hip_init(None, 0))
+    q = capi.get_params()
+    npn, L, W, logq = q.numCrtPrime, q.nttLen, lib.cuhe_hip_words_coeff(0), lib.cuhe_hip_log_coeff(0)
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    ra = torch.randint(-(1 << 31), (1 << 31) - 1, (q.rawLen, W), dtype=torch.int32, device=dev, generator=gen)
+    rb = torch.randint(-(1 << 31), (1 << 31) - 1, (q.rawLen, W), dtype=torch.int32, device=dev, generator=gen)
+    ca = torch.zeros((npn, q.crtLen), dtype=torch.int32, device=dev); cb = torch.zeros_like(ca)
+    na = torch.empty((npn, L), dtype=torch.int64, device=dev); nb = torch.empty_like(na)
+    out = torch.zeros((q.rawLen, W), dtype=torch.int32, device=dev)
+
+    def one():
+        ck(lib.cuhe_hip_crt(ca.data_ptr(), ra.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_crt(cb.data_ptr(), rb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ntt_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_intt_mod(ca.data_ptr(), na.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_icrt(out.data_ptr(), ca.data_ptr(), logq, 0, None))
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    return {"value": round(1.0 / dt, 1), "unit": "full multiplies/s (raw -> raw)", "ms": round(dt * 1e3, 4),
+            "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "nttLen": L, "coeff_words": W},
+            "transforms_per_multiply": 3 * npn}
 
 
 def bench_mulrelin(lib, ck, torch, np, dev, args):
