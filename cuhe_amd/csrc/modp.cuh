@@ -38,7 +38,7 @@ __device__ __forceinline__ u64 subp(u64 a, u64 b) {
 #endif
 }
 #ifndef CUHE_ADDP_VARIANT
-#define CUHE_ADDP_VARIANT 0      /* measured best (profiles/r01_dft_variants.txt) */
+#define CUHE_ADDP_VARIANT 2      /* measured best (profiles/r01_dft_variants.txt) */
 #endif
 __device__ __forceinline__ u64 addp(u64 a, u64 b) {
 #if CUHE_ADDP_VARIANT == 1
@@ -46,6 +46,10 @@ __device__ __forceinline__ u64 addp(u64 a, u64 b) {
     u64 d = a - nb;
     u64 m = (u64)0 - (u64)(a < nb);    // all ones on borrow
     return d - (m & kEps);             // + P on borrow
+#elif CUHE_ADDP_VARIANT == 2
+    u64 s = a + b;
+    const u32 f = ((s < a) | (s >= kP)) ? 1u : 0u;     // carried, or s >= P: add eps once
+    return (u64)f * 0xffffffffu + s;                   // one v_mad_u64_u32
 #else
     u64 s = a + b;
     u64 t = s + kEps;                  // s - P (mod 2^64)
@@ -66,10 +70,14 @@ __device__ __forceinline__ u64 canon(u64 r) {
 #define CUHE_SHLMID_VARIANT 0
 #endif
 #ifndef CUHE_MADEPS_VARIANT
-#define CUHE_MADEPS_VARIANT 1
+#define CUHE_MADEPS_VARIANT 2
 #endif
 __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
-#if CUHE_MADEPS_VARIANT == 1
+#if CUHE_MADEPS_VARIANT == 2
+    u64 r = (u64)m * 0xffffffffu + lo;
+    const u32 f = ((r < lo) | (r >= kP)) ? 1u : 0u;
+    return (u64)f * 0xffffffffu + r;
+#elif CUHE_MADEPS_VARIANT == 1
     u64 r = (u64)m * 0xffffffffu + lo;
     u64 t = r + kEps;
     return ((r < lo) | (t < r)) ? t : r;
