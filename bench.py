@@ -165,7 +165,7 @@ def main():
         mulrelin = mulfull = None
         if not args.no_mulrelin and world == 1:
             mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args)
-            mulfull = bench_mul_full(lib, ck, torch, np, dev)
+            mulfull = bench_mul_full(lib, ck, torch, np, dev, with_cpu=not args.no_cpu)
 
         out = {
             "metric": "64K-point fwd NTT/s (u32[32768] -> u64[65536] over P=2^64-2^32+1)",
@@ -228,7 +228,7 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
             "collective": "1 all-gather of %d B per rank per multiply (RCCL)" % (sh.count * q.crtLen * 4)}
 
 
-def bench_mul_full(lib, ck, torch, np, dev):
+def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True):
     """BASELINE config 3: N = 2^15 (64K-point transforms), 32 CRT primes, full multiply of two raw polynomials
     CRT -> NTT -> pointwise -> INTT (+ reduction mod x^n+1) -> ICRT, device resident (mulZZX without the ZZX<->raw staging)."""
     from cuhe_amd import capi
@@ -263,10 +263,25 @@ def bench_mul_full(lib, ck, torch, np, dev):
         one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    got = out.cpu().numpy().view(np.uint32)
+    ha, hb = ra.cpu().numpy().view(np.uint32), rb.cpu().numpy().view(np.uint32)
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
-    return {"value": round(1.0 / dt, 1), "unit": "full multiplies/s (raw -> raw)", "ms": round(dt * 1e3, 4),
-            "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "nttLen": L, "coeff_words": W},
-            "transforms_per_multiply": 3 * npn}
+    res = {"value": round(1.0 / dt, 1), "unit": "full multiplies/s (raw -> raw)", "ms": round(dt * 1e3, 4),
+           "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "nttLen": L, "coeff_words": W},
+           "transforms_per_multiply": 3 * npn}
+    if with_cpu:
+        # the same multiply on ONE host core through the oracle (checker + reported CPU baseline, never the product path)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        o = O.Ctx(d, p, w, mn, cut, m)
+        t1 = time.perf_counter()
+        want = o.mul_raw(ha, hb, 0)
+        cdt = time.perf_counter() - t1
+        o.close()
+        assert np.array_equal(got, want), "GPU full multiply differs from the oracle"
+        res["cpu_baseline"] = {"value": round(1.0 / cdt, 3), "unit": "full multiplies/s", "cores": 1, "kind": "port",
+                               "sample": "1 multiply (N=2^15, 32 primes) through oracle/oracle.c, %.1f s" % cdt}
+    return res
 
 
 def bench_mulrelin(lib, ck, torch, np, dev, args):
