@@ -188,14 +188,21 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, lon
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
+int g_pass2_form = 1;        // 0: 64 values per thread (ntt_pass2), 1: wave-split 16 x 4 (ntt_pass2w)
 template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
                  const u64 *pinv, int prime0, hipStream_t st) {
     constexpr int N1 = (1 << LG) / 64;
-    const int tiles = N1 / p2_threads<LG>();
-    const int grid = ((nb + 7) / 8) * 8 * tiles;
-    hipLaunchKernelGGL((ntt_pass2<LG, OUT>), dim3(grid), dim3(p2_threads<LG>()), 0, st, dst, scratch, OUT != kOutU64 ? tab.T2inv : tab.T2,
-                       dst_stride, nb, nstore, primes, pinv, prime0);
+    if (g_pass2_form == 1) {
+        const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
+        hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
+                           OUT != kOutU64 ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0);
+    } else {
+        const int tiles = N1 / p2_threads<LG>();
+        const int grid = ((nb + 7) / 8) * 8 * tiles;
+        hipLaunchKernelGGL((ntt_pass2<LG, OUT>), dim3(grid), dim3(p2_threads<LG>()), 0, st, dst, scratch,
+                           OUT != kOutU64 ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0);
+    }
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -895,6 +902,7 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     return CUHE_OK;
 }
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
+int cuhe_hip_set_pass2_form(int form) { if (form < 0 || form > 1) return fail(CUHE_EINVAL, "pass-2 form %d", form); g_pass2_form = form; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {
     CHK(set_dev(dev));
     if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);

@@ -219,4 +219,101 @@ void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pass 2, wave-split form (ntt_pass2w): the 64-point DFT over j2 is done as 16 x 4 by FOUR waves of a 256-thread
+// workgroup that owns 64 adjacent k1.  Wave r loads the 16 samples j2 = 4a + r (outer twiddle applied on load), does
+// a 16-point DFT in registers, multiplies by w_64^(r*b) = 2^(3rb) -- r is wave-uniform, so each wave runs ONE
+// specialised, divergence-free code path with compile-time shifts -- and writes A_r[b] to LDS.  After one barrier wave
+// w reads, for its four b = 4i + w, the four A_r[b] and finishes with 4-point DFTs (w_4 = 2^48), storing
+// X[k1 + N1*(b + 16c)].  A thread carries 16 values instead of 64: ~4x shorter critical path per wave, ~3x more
+// resident waves (about 64 VGPRs, 32 KiB LDS per workgroup), which is what small batches (np <= 103 transforms per
+// API call) and the load/store phases need; the arithmetic per point is about the same as the 64-in-registers form.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kP2wCols = 64;                      // k1 per workgroup
+static constexpr size_t kP2wLdsBytes = (size_t)64 * kP2wCols * sizeof(u64);
+
+template <int R, int B>
+struct TwShift {                                         // v * 2^(3*R*B) mod P, compile-time R, B
+    static __device__ __forceinline__ u64 run(u64 v) {
+        constexpr int K = (3 * R * B) % 192;
+        if constexpr (K >= 96) return negp(shlp<K - 96>(v));
+        else return shlp<K>(v);
+    }
+};
+template <int R, int B>
+struct StepAWrite {
+    static __device__ __forceinline__ void run(const u64 (&x)[16], u64 *xch, int lane) {
+        xch[(B * 4 + R) * kP2wCols + lane] = TwShift<R, B>::run(x[bitrev<16>(B)]);
+        if constexpr (B + 1 < 16) StepAWrite<R, B + 1>::run(x, xch, lane);
+    }
+};
+
+template <int LG, int OUT>
+__global__ __launch_bounds__(256, 4)
+void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
+                long dst_stride, int nbatch, int nstore,
+                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
+    constexpr int L = 1 << LG, N1 = L / 64;
+    constexpr bool INV = OUT != kOutU64;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    int batch, tile;
+    xcd_map(N1 / kP2wCols, batch, tile);
+    if (batch >= nbatch) return;
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index: uniform
+    const int k1 = tile * kP2wCols + lane;
+    const u64 *in = scratch + (long)batch * L + k1;
+    const u64 *tw = T2 + k1;
+    {
+        u64 x[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const int j2 = 4 * a + r;
+            u64 v = __builtin_nontemporal_load(&in[j2 * N1]);
+            if (INV || j2 != 0) v = mulp(v, tw[j2 * N1]);
+            x[a] = v;
+        }
+        dft_regs<16, false>(x);
+        if (r == 0) StepAWrite<0, 0>::run(x, lds, lane);
+        else if (r == 1) StepAWrite<1, 0>::run(x, lds, lane);
+        else if (r == 2) StepAWrite<2, 0>::run(x, lds, lane);
+        else StepAWrite<3, 0>::run(x, lds, lane);
+    }
+    __syncthreads();
+    const int w = r;
+    u32 p = 0; u64 m = 0;
+    if constexpr (INV) { p = primes[prime0 + batch]; m = pinv[prime0 + batch]; }
+    const int k2full = INV ? nstore / N1 : 64, rem = INV ? nstore % N1 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = 4 * i + w;
+        u64 y[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) y[rr] = lds[(b * 4 + rr) * kP2wCols + lane];
+        dft_regs<4, false>(y);                                           // y[bitrev4(c)] = X[b + 16c]
+        if constexpr (OUT == kOutU64) {
+            u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(y[bitrev<4>(c)], &dst[(long)(b + 16 * c) * N1]);
+        } else if constexpr (OUT == kOutModP) {
+            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k2 = b + 16 * c;
+                if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[(long)k2 * N1] = mod_small(y[bitrev<4>(c)], p, m);
+            }
+        } else {
+            // fused reduction modulo x^(L/2)+1: pairs (k2, k2 + 32) = (c, c + 2), see ntt_pass2
+            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u64 a = y[bitrev<4>(c)], bb = y[bitrev<4>(c + 2)];
+                const bool neg = a < bb;
+                const u32 rr = mod_small(neg ? bb - a : a - bb, p, m);
+                dst[(long)(b + 16 * c) * N1] = (neg && rr) ? p - rr : rr;
+            }
+        }
+    }
+}
+
 }  // namespace cuhe
