@@ -47,7 +47,7 @@ int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------ state
 struct NttTab {
-    u64 *T1 = nullptr, *T2 = nullptr, *T2inv = nullptr;
+    u64 *T1 = nullptr, *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of the wave-split pass 1
     u64 *scratch[2] = {nullptr, nullptr};      // two slabs: pass 2 of chunk c overlaps pass 1 of chunk c+1
     int scratch_batch = 0;
 };
@@ -128,6 +128,12 @@ int make_ntt_tables(NttTab &tab) {
             t2[(size_t)j2 * N1 + k1] = v;
             t2i[(size_t)j2 * N1 + k1] = host::mulP(v, linv);
         }
+    // wave-split pass 1: N1 = RA x 64, t1w[c*64 + b] = w_N1^(b*c), b < 64, c < RA
+    constexpr int RA = N1 / 64;
+    std::vector<u64> t1w((size_t)N1);
+    for (int c = 0; c < RA; ++c)
+        for (int b = 0; b < 64; ++b) t1w[(size_t)c * 64 + b] = r[(64L * b * c) % L];
+    CHK(upload(&tab.T1w, t1w));
     CHK(upload(&tab.T1, t1));
     CHK(upload(&tab.T2, t2));
     CHK(upload(&tab.T2inv, t2i));
@@ -168,23 +174,36 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     return CUHE_OK;
 }
 
+int g_pass1_form = 1;        // 0: 32 values per thread (ntt_pass1), 1: wave-split RA x 16 x 4 (ntt_pass1w)
 template <int LG, int MODE>
 int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, long src_stride, int nb,
                  WindowArgs wa, hipStream_t st) {
-    using Gm = NttGeom<LG>;
-    static bool attr_done[64] = {false};
-    auto kern = ntt_pass1<LG, MODE>;
+    (void)inv;
     int cur = 0;
     HIPCHK(hipGetDevice(&cur));
-    if (!attr_done[cur & 63]) {
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)NttLds<LG>::bytes));
-        attr_done[cur & 63] = true;
+    if (g_pass1_form == 1) {
+        using Gw = P1wGeom<LG>;
+        static bool attr_done[64] = {false};
+        auto kern = ntt_pass1w<LG, MODE>;
+        if (!attr_done[cur & 63]) {
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gw::bytes));
+            attr_done[cur & 63] = true;
+        }
+        const int grid = ((nb + 7) / 8) * 8 * (64 / Gw::NC);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa);
+    } else {
+        using Gm = NttGeom<LG>;
+        static bool attr_done[64] = {false};
+        auto kern = ntt_pass1<LG, MODE>;
+        if (!attr_done[cur & 63]) {
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)NttLds<LG>::bytes));
+            attr_done[cur & 63] = true;
+        }
+        const int tiles = 64 / Gm::NC;
+        const int grid = ((nb + 7) / 8) * 8 * tiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNttThreads), NttLds<LG>::bytes, st, src, scratch, tab.T1, src_stride, nb, wa);
     }
-    const int tiles = 64 / Gm::NC;
-    const int grid = ((nb + 7) / 8) * 8 * tiles;
-    (void)inv;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNttThreads), NttLds<LG>::bytes, st, src, scratch, tab.T1, src_stride, nb, wa);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -527,7 +546,7 @@ int cuhe_hip_shutdown(void) {
     for (int d = 0; d < (int)G_.dev.size(); ++d) {
         hipSetDevice(G_.dev_base + d);
         DevCtx &D = G_.dev[d];
-        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch[0]); hipFree(t.scratch[1]); t = NttTab(); }
+        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch[0]); hipFree(t.scratch[1]); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.b_ntt, D.m_crt, D.b_src, D.b_crt,
                         D.hold, D.relin, D.ek, D.win};
@@ -902,6 +921,7 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     return CUHE_OK;
 }
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
+int cuhe_hip_set_pass1_form(int form) { if (form < 0 || form > 1) return fail(CUHE_EINVAL, "pass-1 form %d", form); g_pass1_form = form; return CUHE_OK; }
 int cuhe_hip_set_pass2_form(int form) { if (form < 0 || form > 1) return fail(CUHE_EINVAL, "pass-2 form %d", form); g_pass2_form = form; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {
     CHK(set_dev(dev));

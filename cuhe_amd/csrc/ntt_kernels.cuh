@@ -316,4 +316,120 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pass 1, wave-split form (ntt_pass1w): the N1-point column DFT is done as RA x 64 (RA = N1/64 = 4/8/16) and the
+// 64-point stage again as 16 x 4 over wave-uniform quarters, so that every thread of the 512-thread workgroup
+// carries 16 values in each of the three register stages (instead of 32 in two):
+//   A   : item (col, b), b < 64: RA-point DFT over a (samples x[64*(64a + b) + j2], zero-padded half folded in),
+//         times the inner twiddle w_N1^(b*c) (the only general multiplication of this pass), -> LDS [col][c][b]
+//   B-A : thread (r, col, c): 16-point DFT over a' of the b = 4a' + r, times 2^(3*r*b'') (r is wave-uniform: one
+//         specialised code path per wave, compile-time shifts), -> LDS [col][c][b''][r]   (same buffer, re-used)
+//   B-B : thread (w, col, c): for b'' = 4i + w a 4-point DFT over r -> k1 = c + RA*(b'' + 16c''), stored to the slab.
+// Same arithmetic per point as ntt_pass1, half the critical path per wave, twice the resident waves.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kP1wThreads = 512;
+template <int LG>
+struct P1wGeom {
+    static constexpr int N1 = (1 << LG) / 64, RA = N1 / 64, NC = 128 / RA;       // 128 (col, c) pairs per workgroup
+    static constexpr int RS = 65;                         // row stride (u64) of both exchange layouts
+    static constexpr int CS = RA * RS + 2;                // column stride, == 2 (mod 16) u64: conflict-free column lanes
+    static constexpr int XCH = NC * CS;
+    static constexpr int T1N = N1;
+    static constexpr size_t bytes = (size_t)(XCH + T1N) * sizeof(u64);
+};
+
+template <int R, int B>
+struct StepBWrite {
+    static __device__ __forceinline__ void run(const u64 (&x)[16], u64 *row) {
+        row[B * 4 + R] = TwShift<R, B>::run(x[bitrev<16>(B)]);
+        if constexpr (B + 1 < 16) StepBWrite<R, B + 1>::run(x, row);
+    }
+};
+
+template <int LG, int MODE>
+__global__ __launch_bounds__(kP1wThreads, 2)
+void ntt_pass1w(const void *__restrict__ src_, u64 *__restrict__ scratch,
+                const u64 *__restrict__ T1, long src_stride, int nbatch, WindowArgs wa) {
+    using G = P1wGeom<LG>;
+    constexpr int L = 1 << LG, N1 = G::N1, RA = G::RA, NC = G::NC, T = kP1wThreads;
+    constexpr int IA = NC * 64 / T;                       // stage-A items per thread (1 / 2 / 4), RA values each
+    constexpr bool EXT = (MODE != kSrcU64Neg);
+    constexpr int NA = EXT ? RA / 2 : RA;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 *xch = lds;
+    u64 *t1 = lds + G::XCH;                               // t1[c*64 + b] = w_N1^(b*c)
+
+    int batch, tile;
+    xcd_map(64 / NC, batch, tile);
+    if (batch >= nbatch) return;
+    const int t = threadIdx.x;
+    const int col0 = tile * NC;
+    for (int i = t; i < G::T1N; i += T) t1[i] = T1[i];
+    __syncthreads();
+
+    // ---- stage A
+#pragma unroll
+    for (int it = 0; it < IA; ++it) {
+        const int e = t + T * it;
+        const int col = e % NC, b = e / NC;
+        u64 x[RA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int idx = (a * 64 + b) * 64 + col0 + col;
+            if constexpr (MODE == kSrcU32Ext) {
+                const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
+                x[a] = src[idx];
+            } else if constexpr (MODE == kSrcWindow) {
+                const u32 *co = (const u32 *)src_ + (long)idx * wa.words;
+                const int bit = wa.w * (wa.wid0 + batch);
+                const int wi = bit >> 5;
+                u64 sv = co[wi];
+                if (wi + 1 < wa.words) sv |= (u64)co[wi + 1] << 32;
+                sv >>= (bit & 31);
+                x[a] = sv & (u64)((1u << wa.w) - 1u);
+            } else {
+                const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
+                x[a] = src[(L - idx) & (L - 1)];
+            }
+        }
+        dft_regs<RA, EXT>(x);
+#pragma unroll
+        for (int c = 0; c < RA; ++c) {
+            u64 v = x[bitrev<RA>(c)];
+            if (c != 0) v = mulp(v, t1[c * 64 + b]);
+            xch[col * G::CS + c * G::RS + b] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage B-A: (r, col, c) with r wave-uniform
+    const int r = __builtin_amdgcn_readfirstlane(t >> 7);
+    const int u = t & 127;
+    const int c = u % RA, col = u / RA;
+    u64 *row = xch + col * G::CS + c * G::RS;
+    u64 y[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) y[a] = row[4 * a + r];
+    dft_regs<16, false>(y);
+    __syncthreads();                                      // every read of the first layout done before it is overwritten
+    if (r == 0) StepBWrite<0, 0>::run(y, row);
+    else if (r == 1) StepBWrite<1, 0>::run(y, row);
+    else if (r == 2) StepBWrite<2, 0>::run(y, row);
+    else StepBWrite<3, 0>::run(y, row);
+    __syncthreads();
+
+    // ---- stage B-B
+    u64 *out = scratch + (long)batch * L + (long)(col0 + col) * N1 + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int bb = 4 * i + r;
+        u64 z[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) z[rr] = row[bb * 4 + rr];
+        dft_regs<4, false>(z);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) out[RA * (bb + 16 * cc)] = z[bitrev<4>(cc)];
+    }
+}
+
 }  // namespace cuhe

@@ -156,6 +156,7 @@ int cuhe_hip_set_ntt_chunk(int chunk);
 int cuhe_hip_set_ntt_overlap(int on);
 /* pass-2 kernel form: 1 (default) = wave-split 16 x 4 through LDS, 0 = one thread per 64-point DFT (tuning / A-B tests) */
 int cuhe_hip_set_pass2_form(int form);
+int cuhe_hip_set_pass1_form(int form);    /* 1 (default) = wave-split RA x 16 x 4, 0 = 32 values per thread */
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,
