@@ -3,30 +3,26 @@
 //
 // Replaces the reference's 3-pass 64x64x{4,8,16} scheme, one prime per launch,
 // 64-thread blocks (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398) with a
-// 2-pass "four-step" split  L = N1 x 64,  N1 = L/64 = R1 x R2:
+// 2-pass "four-step" split  L = N1 x 64:
 //
-//   pass 1 (ntt_pass1):  for every column j2 < 64, an N1-point DFT over the
-//       stride-64 samples x[64*j1 + j2].  A 256-thread workgroup owns NC
-//       adjacent columns.  Each thread does R1-point DFTs in registers
-//       (compile-time power-of-two twiddles: shifts only), multiplies by the
-//       inner twiddle w_N1^(b*c) (LDS table), exchanges through LDS, does
-//       R2-point DFTs in registers and writes scratch[j2][k1] (coalesced).
-//   pass 2 (ntt_pass2):  one thread per k1 loads the 64 values scratch[.][k1]
-//       (512 B contiguous per wave-load), multiplies them by the outer twiddle
-//       w_L^(j2*k1) (same layout, L2 resident), does a 64-point DFT entirely in
-//       registers (w_64 = 8: shifts only, no LDS, no barrier) and stores
-//       X[k1 + N1*k2] (512 B contiguous per wave-store) in natural order.
+//   pass 1:  for every column j2 < 64, an N1-point DFT over the stride-64 samples
+//       x[64*j1 + j2], written to scratch[j2][k1] (coalesced).
+//   pass 2:  for every k1, a 64-point DFT over j2 of scratch[.][k1] times the outer
+//       twiddle w_L^(j2*k1), stored as X[k1 + N1*k2] in natural order.
 //
-// Exactly two general modular multiplications per point; everything else is
-// add/sub/shift.  HBM traffic per transform is the algorithmic 4*(L/2) + 8*L
-// bytes when the scratch slab stays cache resident (the host driver chunks the
-// batch to make it so).
+// Every sub-transform of <= 64 points is shift-only (8 = 2^3 is a 64-th root of unity
+// mod P); exactly two general modular multiplications per point remain.  The DEFAULT
+// kernels are the "wave-split" forms at the end of this file (ntt_pass1w / ntt_pass2w:
+// 16 values per thread in every register stage, 64-point stages done as 16 x 4 over
+// wave-uniform quarters through LDS).  The first two kernels below (ntt_pass1: 32 values
+// per thread in two stages; ntt_pass2: a whole 64-point DFT per thread, no LDS) are the
+// earlier register-heavy forms, kept selectable for A/B measurements.
 //
 // The inverse transform reuses the same passes on index-negated input
 // (cuhe/Base.cu:454,622,799) with L^-1 folded into the outer twiddle table and
-// `mod p_i` + u64->u32 narrowing fused into the pass-2 store
-// (cuhe/Base.cu:469-490).  The relinearisation window extraction
-// (cuhe/Base.cu:345-372) is fused into the pass-1 load.
+// `mod p_i` + u64->u32 narrowing (and the reduction mod x^(L/2)+1 when it applies) fused
+// into the pass-2 store (cuhe/Base.cu:469-490).  The relinearisation window extraction
+// (cuhe/Base.cu:345-372) can be fused into the pass-1 load.
 #pragma once
 #include "modp.cuh"
 
