@@ -202,20 +202,32 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
     from cuhe_amd import capi
     from cuhe_amd.sharded import HipBackend, ShardedMulRelin
     d, p, w, mn, cut, m = 25, 2, 16, 576, 24, 65536
-    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
-    ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
-    ck(lib.cuhe_hip_init(None, 0))
-    q = capi.get_params()
-    K, W = q.numEvalKey, lib.cuhe_hip_words_coeff(0)
-    ek = np.random.default_rng(7).integers(0, 1 << 32, (K, q.rawLen, W), dtype=np.uint32)
-    ek[:, :, W - 1] &= 0x7FFF
-    ck(lib.cuhe_hip_init_relin(ek.ctypes.data_as(C.c_void_p)))
-    hb = HipBackend()
-    sh = ShardedMulRelin(hb, 0, rank, world)
-    gen = torch.Generator(device=dev); gen.manual_seed(5)
-    a = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
-    b = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
-    na = hb.ntt_rows(sh.own(a).contiguous()); nb = hb.ntt_rows(sh.own(b).contiguous())
+    # local set-up first; the ranks then agree (one all-reduce) that everybody is ready before the first data-path
+    # collective, so that a local failure (e.g. out of memory) cannot leave the others hanging in the all-gather
+    ready, err = 1, None
+    try:
+        lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+        ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
+        ck(lib.cuhe_hip_init(None, 0))
+        q = capi.get_params()
+        K, W = q.numEvalKey, lib.cuhe_hip_words_coeff(0)
+        ek = np.random.default_rng(7).integers(0, 1 << 32, (K, q.rawLen, W), dtype=np.uint32)
+        ek[:, :, W - 1] &= 0x7FFF
+        ck(lib.cuhe_hip_init_relin(ek.ctypes.data_as(C.c_void_p)))
+        hb = HipBackend()
+        sh = ShardedMulRelin(hb, 0, rank, world)
+        gen = torch.Generator(device=dev); gen.manual_seed(5)
+        a = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+        b = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+        na = hb.ntt_rows(sh.own(a).contiguous()); nb = hb.ntt_rows(sh.own(b).contiguous())
+        torch.cuda.synchronize()
+    except Exception as ex:
+        ready, err = 0, repr(ex)[:200]
+    flag = torch.tensor([ready], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+        return {"error": "set-up failed on at least one rank" + (": " + err if err else "")}
     for _ in range(3):
         sh.mul_relin(na, nb)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
