@@ -33,7 +33,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="64K-point transforms per step per GPU")
+    # 8192 transforms (4 GiB of output) per step: a step lasts ~4 ms, so that even a 5-step timed region is long enough
+    # for the clocks to settle (the chip needs tens of ms of load; with 1024 per step a 10-step run reads 20 % low)
+    ap.add_argument("--batch", type=int, default=8192, help="64K-point transforms per step per GPU")
     ap.add_argument("--len", type=int, default=65536, dest="length")
     ap.add_argument("--chunk", type=int, default=0, help="transforms per launch pair (0 = library default)")
     ap.add_argument("--overlap", type=int, default=0, help="1: pass-1/pass-2 two-stream pipeline, 0: serial launches (default)")
@@ -142,7 +144,7 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_note": "HBM-side bytes per launch pair (256 transforms) from profiles/traffic_r*.json; algorithmic = 167772160",
-                    "kernel": "ntt_pass1<16,0> + ntt_pass2<16,false> (one transform = one launch pair)",
+                    "kernel": "ntt_pass1w<16,0> + ntt_pass2w<16,0> (wave-split forms; one transform = one launch pair)",
                     "algorithmic_bytes_per_transform": alg_bytes,
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),
                     "pass1_ms_per_batch": round(ms1.value / iters, 4), "pass2_ms_per_batch": round(ms2.value / iters, 4)}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # how the pass-1 -> pass-2 slab size (transforms per launch pair) changes each pass's time
-for c in 96 128 192 256 384 512; do for ov in 0; do
+for c in 128 256 512 1024; do for ov in 0; do
   python bench.py --steps 10 --warmup 3 --no-mulrelin --no-cpu --chunk $c --overlap $ov 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
