@@ -48,6 +48,9 @@ SIGNATURES = {
     "cuhe_hip_stop_allocator": (i32, []),
     "cuhe_hip_malloc": (vp, [i32, sz]),
     "cuhe_hip_free": (i32, [i32, vp]),
+    "cuhe_hip_set_alloc_cache": (i32, [sz]),
+    "cuhe_hip_host_alloc": (vp, [sz]),
+    "cuhe_hip_host_free": (i32, [vp]),
     "cuhe_hip_memset_async": (i32, [i32, vp, i32, sz, vp]),
     "cuhe_hip_memcpy_h2d": (i32, [i32, vp, vp, sz, vp]),
     "cuhe_hip_memcpy_d2h": (i32, [i32, vp, vp, sz, vp]),

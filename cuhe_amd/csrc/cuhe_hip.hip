@@ -74,6 +74,7 @@ struct DevCtx {
     hipEvent_t ev_start = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     std::multimap<size_t, void *> freeBlocks;
     std::map<void *, size_t> allocated;
+    size_t cachedBytes = 0;              // bytes parked in freeBlocks
 };
 
 struct Global {
@@ -86,6 +87,7 @@ struct Global {
     int reduce_kind = 0;                 // 0 generic, 1 x^n+1, 2 prime m
     bool force_generic = false;
     bool allocator_on = false;
+    size_t cache_cap = (size_t)4 << 30;  // with the pooled allocator off, freed blocks are still kept up to this many bytes
     int ntt_chunk = 0;
     bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
@@ -581,25 +583,40 @@ int cuhe_hip_force_generic_reduce(int on) { G_.force_generic = on != 0; return C
 
 // ---------------------------------------------------------------- allocator
 int cuhe_hip_start_allocator(void) { G_.allocator_on = true; return CUHE_OK; }   // no "grab all VRAM" 
+static void drop_cached(DevCtx &D) {
+    for (auto &kv : D.freeBlocks) hipFree(kv.second);
+    D.freeBlocks.clear();
+    D.cachedBytes = 0;
+}
 int cuhe_hip_stop_allocator(void) {
     G_.allocator_on = false;
     for (int d = 0; d < (int)G_.dev.size(); ++d) {
         hipSetDevice(G_.dev_base + d);
-        for (auto &kv : G_.dev[d].freeBlocks) hipFree(kv.second);
-        G_.dev[d].freeBlocks.clear();
+        drop_cached(G_.dev[d]);
     }
     return CUHE_OK;
 }
+int cuhe_hip_set_alloc_cache(size_t bytes) { G_.cache_cap = bytes; return CUHE_OK; }
+// Size-keyed block cache.  hipMalloc/hipFree cost tens to hundreds of microseconds and hipFree synchronises the
+// device, which is more than a whole CRT or NTT stage of a ciphertext takes, and the API allocates and frees a
+// representation on every domain change (cuhe/CuHE.cu:356-408).  Freed blocks are therefore parked and handed out
+// again for the same size: without limit while startAllocator() is in effect, up to cache_cap bytes otherwise.
 void *cuhe_hip_malloc(int dev, size_t bytes) {
     if (set_dev(dev) != CUHE_OK) return nullptr;
     DevCtx &D = G_.dev[dev];
     std::lock_guard<std::mutex> lk(G_.mu);
-    if (G_.allocator_on) {
-        auto it = D.freeBlocks.find(bytes);
-        if (it != D.freeBlocks.end()) { void *p = it->second; D.freeBlocks.erase(it); D.allocated[p] = bytes; return p; }
+    auto it = D.freeBlocks.find(bytes);
+    if (it != D.freeBlocks.end()) {
+        void *p = it->second;
+        D.freeBlocks.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+        return p;
     }
     void *p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(CUHE_EHIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        drop_cached(D);                                   // give the parked blocks back and try once more
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(CUHE_EHIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    }
     D.allocated[p] = bytes;
     return p;
 }
@@ -612,10 +629,17 @@ int cuhe_hip_free(int dev, void *ptr) {
     if (it == D.allocated.end()) return fail(CUHE_EINVAL, "free of unknown pointer");
     const size_t sz = it->second;
     D.allocated.erase(it);
-    if (G_.allocator_on) D.freeBlocks.insert({sz, ptr});
+    if (G_.allocator_on || D.cachedBytes + sz <= G_.cache_cap) { D.freeBlocks.insert({sz, ptr}); D.cachedBytes += sz; }
     else HIPCHK(hipFree(ptr));
     return CUHE_OK;
 }
+// pinned host staging memory for the ZZX <-> raw conversions of the C++ layer (cuhe/CuHE.cu:317-348 uses pageable)
+void *cuhe_hip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(CUHE_EHIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+int cuhe_hip_host_free(void *ptr) { if (ptr) HIPCHK(hipHostFree(ptr)); return CUHE_OK; }
 int cuhe_hip_memset_async(int dev, void *p, int v, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemsetAsync(p, v, n, S(st))); return CUHE_OK; }
 int cuhe_hip_memcpy_h2d(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, S(st))); return CUHE_OK; }
 int cuhe_hip_memcpy_d2h(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, S(st))); return CUHE_OK; }

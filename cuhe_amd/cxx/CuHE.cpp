@@ -10,6 +10,7 @@
 #include "Relinearization.h"
 
 #include <cstring>
+#include <utility>
 #include <exception>
 #include <vector>
 
@@ -175,7 +176,7 @@ void CuPolynomial::logq(int val) { logq_ = val; }
 void CuPolynomial::domain(int val) { domain_ = val; }
 void CuPolynomial::device(int val) { device_ = val; }
 void CuPolynomial::isProd(bool val) { isProd_ = val; }
-void CuPolynomial::zRep(ZZX val) { zRep_ = val; }
+void CuPolynomial::zRep(ZZX val) { zRep_ = std::move(val); }
 void CuPolynomial::rRep(uint32 *val) { rRep_ = val; }
 void CuPolynomial::cRep(uint32 *val) { cRep_ = val; }
 void CuPolynomial::nRep(uint64 *val) { nRep_ = val; }
@@ -184,6 +185,7 @@ int CuPolynomial::domain() { return domain_; }
 int CuPolynomial::device() { return device_; }
 bool CuPolynomial::isProd() { return isProd_; }
 ZZX CuPolynomial::zRep() { return zRep_; }
+void CuPolynomial::swapZRep(ZZX &other) { using std::swap; swap(zRep_, other); }
 uint32 *CuPolynomial::rRep() { return rRep_; }
 uint32 *CuPolynomial::cRep() { return cRep_; }
 uint64 *CuPolynomial::nRep() { return nRep_; }
@@ -208,15 +210,39 @@ void CuPolynomial::rRepFree() { CSC(cuhe_hip_free(device_, rRep_)); rRep_ = NULL
 void CuPolynomial::cRepFree() { CSC(cuhe_hip_free(device_, cRep_)); cRep_ = NULL; }
 void CuPolynomial::nRepFree() { CSC(cuhe_hip_free(device_, nRep_)); nRep_ = NULL; }
 
+// ---- host staging.  The reference packs coefficient by coefficient into a pageable vector and
+// copies that (cuhe/CuHE.cu:317-348).  Here each host thread owns one grow-only PINNED buffer (the examples drive
+// one OpenMP thread per device, Prince.cu:194-200), the copy is a single async DMA, the target is not memset first (the copy overwrites all of it) and only the
+// modLen coefficients that can be non-zero come back.  (Packing with an OpenMP team was measured and dropped: a
+// coefficient is a ~100-byte memcpy, and waking 128 host threads costs two orders of magnitude more than the loop.)
+struct PinnedStage {
+	void *buf = NULL; size_t cap = 0;
+	void *get(size_t bytes) {
+		if (bytes > cap) {
+			if (buf) cuhe_hip_host_free(buf);
+			buf = cuhe_hip_host_alloc(bytes);
+			if (!buf) CSC(CUHE_EHIP);
+			cap = bytes;
+		}
+		return buf;
+	}
+	~PinnedStage() { if (buf) cuhe_hip_host_free(buf); }
+};
+static thread_local PinnedStage tlsStage;
+
 void CuPolynomial::z2r(cudaStream_t st) {
 	if (domain_ != 0) { printf("Error: Not in domain ZZX!\n"); terminate(); }
-	rRepCreate(st);
+	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
 	const int W = coeffWords();
-	vector<uint32> host((size_t)param.rawLen * W, 0);
-	const long top = deg(zRep_);
-	for (long i = 0; i <= top && i < param.rawLen; i++)      // BytesFromZZ takes |coeff|: inputs are non-negative (CuHE.cu:325)
-		BytesFromZZ((uint8 *)&host[(size_t)i * W], coeff(zRep_, i), W * sizeof(uint32));
-	CSC(cuhe_hip_memcpy_h2d(device_, rRep_, host.data(), rRepSize(), st));
+	const long rows = param.rawLen, top = deg(zRep_);
+	const size_t rowBytes = (size_t)W * sizeof(uint32);
+	uint8 *host = (uint8 *)tlsStage.get(rRepSize());
+	// BytesFromZZ takes |coeff| and zero-pads: inputs are non-negative (cuhe/CuHE.cu:325)
+	for (long i = 0; i < rows; i++) {
+		if (i <= top) BytesFromZZ(host + (size_t)i * rowBytes, coeff(zRep_, i), (long)rowBytes);
+		else memset(host + (size_t)i * rowBytes, 0, rowBytes);
+	}
+	CSC(cuhe_hip_memcpy_h2d(device_, rRep_, host, rRepSize(), st));
 	CSC(cuhe_hip_stream_sync(device_, st));
 	clear(zRep_);
 	domain_ = 1;
@@ -224,12 +250,20 @@ void CuPolynomial::z2r(cudaStream_t st) {
 void CuPolynomial::r2z(cudaStream_t st) {
 	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }
 	const int W = coeffWords();
-	vector<uint32> host((size_t)param.rawLen * W);
-	CSC(cuhe_hip_memcpy_d2h(device_, host.data(), rRep_, rRepSize(), st));
+	const long n = param.modLen;
+	const size_t rowBytes = (size_t)W * sizeof(uint32);
+	uint8 *host = (uint8 *)tlsStage.get((size_t)n * rowBytes);
+	CSC(cuhe_hip_memcpy_d2h(device_, host, rRep_, (size_t)n * rowBytes, st));
 	CSC(cuhe_hip_stream_sync(device_, st));
 	clear(zRep_);
-	for (int i = param.modLen - 1; i >= 0; i--)               // high to low: one resize
-		SetCoeff(zRep_, i, ZZFromBytes((uint8 *)&host[(size_t)i * W], W * sizeof(uint32)));
+#ifdef CUHE_MINI_NTL
+	zRep_.rep.resize(n);
+#else
+	zRep_.rep.SetLength(n);
+#endif
+	for (long i = 0; i < n; i++)
+		ZZFromBytes(zRep_.rep[i], host + (size_t)i * rowBytes, (long)rowBytes);
+	zRep_.normalize();
 	rRepFree();
 	domain_ = 0;
 }
@@ -306,7 +340,7 @@ void CuCtxt::setLevel(int lvl, int domain, int device, cudaStream_t st) {
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
 void CuCtxt::setLevel(int lvl, int device, ZZX val) {
-	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = 0; device_ = device; zRep_ = val;
+	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = 0; device_ = device; zRep_ = std::move(val);
 }
 int CuCtxt::level() { return level_; }
 size_t CuCtxt::cRepSize() { return (size_t)param._numCrtPrime(level_) * param.crtLen * sizeof(uint32); }
@@ -338,7 +372,7 @@ void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
 	logq_ = logq; domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
-void CuPtxt::setLogq(int logq, int device, ZZX val) { logq_ = logq; domain_ = 0; device_ = device; zRep_ = val; }
+void CuPtxt::setLogq(int logq, int device, ZZX val) { logq_ = logq; domain_ = 0; device_ = device; zRep_ = std::move(val); }
 size_t CuPtxt::cRepSize() { return (size_t)param.crtLen * sizeof(uint32); }
 size_t CuPtxt::nRepSize() { return (size_t)param.nttLen * sizeof(uint64); }
 
@@ -437,15 +471,17 @@ void copyTo(CuCtxt &dst, CuCtxt &src, int dstDev, cudaStream_t st) {
 }
 
 // ------------------------------------------------------------------ NTL interface
+// The by-value parameters are the reference's signature (cuhe/CuHE.h:184); they are moved, not copied again, into
+// the operands, and the result is swapped out of the product instead of being copied.
 void mulZZX(ZZX &out, ZZX in0, ZZX in1, int lvl, int dev, cudaStream_t st) {
 	CuCtxt a, b;
-	a.setLevel(lvl, dev, in0);
-	b.setLevel(lvl, dev, in1);
+	a.setLevel(lvl, dev, std::move(in0));
+	b.setLevel(lvl, dev, std::move(in1));
 	a.x2n(st);
 	b.x2n(st);
 	cAnd(a, a, b, st);
 	a.x2z(st);
-	out = a.zRep();
+	a.swapZRep(out);
 }
 
 } // namespace cuHE

@@ -45,6 +45,7 @@ public:
 	int device();
 	bool isProd();
 	ZZX zRep();
+	void swapZRep(ZZX &other);       // (addition) exchange the host value without copying it
 	uint32 *rRep();
 	uint32 *cRep();
 	uint64 *nRep();

@@ -116,7 +116,8 @@ inline ZZ to_ZZ(unsigned long v) { ZZ r; while (v) { r.m.push_back((uint32_t)v);
 inline ZZ to_ZZ(const char *s) {
     ZZ r; bool neg = false; if (*s == '-') { neg = true; ++s; }
     for (; *s; ++s) r = r * ZZ(10) + ZZ(*s - '0');
-    if (neg) r = -r; return r;
+    if (neg) r = -r;
+    return r;
 }
 inline long to_long(const ZZ &a) { unsigned long v = 0; for (size_t i = a.m.size(); i-- > 0;) v = (v << 32) | a.m[i]; return a.neg ? -(long)v : (long)v; }
 inline void conv(unsigned &x, const ZZ &a) { x = a.m.empty() ? 0u : a.m[0]; }
@@ -127,15 +128,19 @@ inline long IsZero(const ZZ &a) { return a.zero(); }
 inline void clear(ZZ &a) { a = ZZ(); }
 inline ZZ power(const ZZ &a, long e) { ZZ r(1), b = a; while (e) { if (e & 1) r = r * b; b = b * b; e >>= 1; } return r; }
 inline ZZ power2_ZZ(long e) { ZZ r; r.m.assign(e / 32 + 1, 0); r.m[e / 32] = 1u << (e % 32); return r; }
-// BytesFromZZ: little-endian bytes of |a|, zero padded / truncated to n (NTL semantics)
+// BytesFromZZ: little-endian bytes of |a|, zero padded / truncated to n (NTL semantics).  The magnitude is an
+// array of little-endian 32-bit words, so on a little-endian host this is a memcpy.
 inline void BytesFromZZ(unsigned char *p, const ZZ &a, long n) {
-    for (long i = 0; i < n; ++i) { size_t w = (size_t)i / 4; p[i] = w < a.m.size() ? (unsigned char)(a.m[w] >> (8 * (i % 4))) : 0; }
+    const long have = std::min<long>(n, (long)a.m.size() * 4);
+    if (have) std::memcpy(p, a.m.data(), (size_t)have);
+    if (n > have) std::memset(p + have, 0, (size_t)(n - have));
 }
-inline ZZ ZZFromBytes(const unsigned char *p, long n) {
-    ZZ r; r.m.assign((n + 3) / 4, 0);
-    for (long i = 0; i < n; ++i) r.m[i / 4] |= (uint32_t)p[i] << (8 * (i % 4));
-    r.trim(); return r;
+inline void ZZFromBytes(ZZ &r, const unsigned char *p, long n) {
+    r.neg = false; r.m.assign((size_t)(n + 3) / 4, 0);
+    if (n) std::memcpy(r.m.data(), p, (size_t)n);
+    r.trim();
 }
+inline ZZ ZZFromBytes(const unsigned char *p, long n) { ZZ r; ZZFromBytes(r, p, n); return r; }
 inline std::ostream &operator<<(std::ostream &os, const ZZ &a) {
     if (a.zero()) return os << "0";
     std::string s; ZZ t = a; t.neg = false; ZZ ten(10);

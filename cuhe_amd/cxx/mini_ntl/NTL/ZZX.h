@@ -10,6 +10,8 @@ public:
     ZZX() {}
     ZZX(const ZZX &o) : rep(o.rep) {}
     ZZX &operator=(const ZZX &o) { rep = o.rep; return *this; }
+    ZZX(ZZX &&o) noexcept : rep(std::move(o.rep)) {}
+    ZZX &operator=(ZZX &&o) noexcept { rep = std::move(o.rep); return *this; }
     // releases the buffer and leaves a valid empty vector behind, so that the explicit-destructor-then-scope-exit
     // pattern of the reference's examples (Prince.cu:298-319) stays harmless with this fallback type too
     ~ZZX() { std::vector<ZZ>().swap(rep); }

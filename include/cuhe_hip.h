@@ -85,6 +85,12 @@ int cuhe_hip_start_allocator(void);
 int cuhe_hip_stop_allocator(void);
 void *cuhe_hip_malloc(int dev, size_t bytes);
 int cuhe_hip_free(int dev, void *ptr);
+/* freed blocks are parked for reuse (hipMalloc/hipFree cost more than a CRT or NTT stage): without limit between
+   start/stopAllocator, up to this many bytes per device otherwise (default 4 GiB; 0 = plain hipMalloc/hipFree) */
+int cuhe_hip_set_alloc_cache(size_t bytes);
+/* pinned host staging buffers for z2r / r2z (cuhe/CuHE.cu:317-348 stages through pageable memory) */
+void *cuhe_hip_host_alloc(size_t bytes);
+int cuhe_hip_host_free(void *ptr);
 int cuhe_hip_memset_async(int dev, void *ptr, int value, size_t bytes, void *stream);
 int cuhe_hip_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes, void *stream);
 int cuhe_hip_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes, void *stream);
