@@ -82,6 +82,9 @@ SIGNATURES = {
     "cuhe_hip_intt_one": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_init_relin": (i32, [vp]),
     "cuhe_hip_relinearization": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_relin_cache_size": (sz, []),
+    "cuhe_hip_relin_export": (i32, [vp, sz, i32]),
+    "cuhe_hip_relin_import": (i32, [vp, sz]),
     "cuhe_hip_ntt_rows": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_ntt_mul_rows": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_intt_mod_range": (i32, [vp, vp, i32, i32, i32, i32, vp]),

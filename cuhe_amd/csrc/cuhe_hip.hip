@@ -870,6 +870,79 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
     G_.relin_ready = true;
     return CUHE_OK;
 }
+// ---- binary evaluation-key cache.  initRelinearization costs numEvalKey * numCrtPrime forward
+// transforms plus the upload of the raw keys; the NTT-domain keys it produces depend only on the parameter set,
+// the CRT primes and the key polynomials, so a deployment computes them once and reloads this image.
+//   header (96 bytes, little endian): magic "CUHEEK\0\1", u32 version, i32 d,p,w,min,cut,m, i32 numCrtPrime,
+//   i32 numEvalKey, i32 nttLen, 2 x u32 0, u64 FNV-1a of the CRT primes, u64 payload bytes, u64 XOR of the payload words, 2 x u64 0;
+//   payload: u64[prime][key][nttLen], canonical residues mod P  (the HBM layout, cuhe/Relinearization.cu:45-55)
+struct EkHeader {
+    char magic[8]; uint32_t version; int32_t set[6]; int32_t np, k, L; uint32_t zero[2];
+    uint64_t primes_fnv, payload_bytes, payload_xor; uint64_t pad[2];
+};
+static_assert(sizeof(EkHeader) == 96, "cache header layout");
+static const char kEkMagic[8] = {'C', 'U', 'H', 'E', 'E', 'K', 0, 1};
+static uint64_t fnv1a(const void *p, size_t n) {
+    uint64_t h = 1469598103934665603ULL;
+    for (size_t i = 0; i < n; ++i) { h ^= ((const uint8_t *)p)[i]; h *= 1099511628211ULL; }
+    return h;
+}
+static uint64_t xor_words(const uint64_t *p, size_t n) {
+    uint64_t a = 0, b = 0, c = 0, d = 0; size_t i = 0;
+    for (; i + 4 <= n; i += 4) { a ^= p[i]; b ^= p[i + 1]; c ^= p[i + 2]; d ^= p[i + 3]; }
+    for (; i < n; ++i) a ^= p[i];
+    return a ^ b ^ c ^ d;
+}
+static EkHeader ek_header_now() {
+    const Params &q = G_.prm;
+    EkHeader h; memset(&h, 0, sizeof h);
+    memcpy(h.magic, kEkMagic, 8); h.version = 1;
+    const int set[6] = {q.depth, q.modMsg, q.logRelin, q.logCoeffMin, q.logCoeffCut, q.mSize};
+    memcpy(h.set, set, sizeof set);
+    h.np = q.numCrtPrime; h.k = q.numEvalKey; h.L = q.nttLen;
+    h.primes_fnv = fnv1a(G_.primes.data(), G_.primes.size() * sizeof(uint32_t));
+    h.payload_bytes = (uint64_t)q.numCrtPrime * q.numEvalKey * q.nttLen * sizeof(u64);
+    return h;
+}
+size_t cuhe_hip_relin_cache_size(void) {
+    if (!G_.inited || G_.prm.numEvalKey <= 0) return 0;
+    return sizeof(EkHeader) + (size_t)ek_header_now().payload_bytes;
+}
+int cuhe_hip_relin_export(void *dst, size_t cap, int dev) {
+    CHK(need_init(dev));
+    if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
+    EkHeader h = ek_header_now();
+    if (!dst || cap < sizeof h + h.payload_bytes) return fail(CUHE_EINVAL, "export buffer too small: %zu < %zu", cap, sizeof h + (size_t)h.payload_bytes);
+    uint8_t *out = (uint8_t *)dst;
+    HIPCHK(hipMemcpy(out + sizeof h, G_.dev[dev].ek, h.payload_bytes, hipMemcpyDeviceToHost));
+    h.payload_xor = xor_words((const uint64_t *)(out + sizeof h), h.payload_bytes / 8);
+    memcpy(out, &h, sizeof h);
+    return CUHE_OK;
+}
+int cuhe_hip_relin_import(const void *src, size_t bytes) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
+    if (!src || bytes < sizeof(EkHeader)) return fail(CUHE_EINVAL, "evaluation-key cache: truncated header");
+    EkHeader h; memcpy(&h, src, sizeof h);
+    const EkHeader want = ek_header_now();
+    if (memcmp(h.magic, kEkMagic, 8) != 0 || h.version != 1) return fail(CUHE_EINVAL, "evaluation-key cache: bad magic / version");
+    if (memcmp(h.set, want.set, sizeof h.set) != 0 || h.np != want.np || h.k != want.k || h.L != want.L)
+        return fail(CUHE_EINVAL, "evaluation-key cache was made for other parameters");
+    if (h.primes_fnv != want.primes_fnv) return fail(CUHE_EINVAL, "evaluation-key cache was made for other CRT primes");
+    if (h.payload_bytes != want.payload_bytes || bytes < sizeof h + h.payload_bytes) return fail(CUHE_EINVAL, "evaluation-key cache: truncated payload");
+    const uint8_t *payload = (const uint8_t *)src + sizeof h;
+    if (xor_words((const uint64_t *)payload, h.payload_bytes / 8) != h.payload_xor) return fail(CUHE_EINVAL, "evaluation-key cache: payload checksum mismatch");
+    const Params &q = G_.prm;
+    for (int dev = 0; dev < G_.ndev; ++dev) {
+        CHK(set_dev(dev));
+        DevCtx &D = G_.dev[dev];
+        if (!D.ek) HIPCHK(hipMalloc((void **)&D.ek, h.payload_bytes));
+        if (!D.relin) HIPCHK(hipMalloc((void **)&D.relin, (size_t)q.numEvalKey * q.nttLen * sizeof(u64)));
+        if (!D.win) HIPCHK(hipMalloc((void **)&D.win, (size_t)q.numEvalKey * q.crtLen * sizeof(u32)));
+        HIPCHK(hipMemcpy(D.ek, payload, h.payload_bytes, hipMemcpyHostToDevice));
+    }
+    G_.relin_ready = true;
+    return CUHE_OK;
+}
 static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, int count, int dev, void *st) {
     CHK(need_init(dev));
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");

@@ -9,6 +9,7 @@
 #include "Operations.h"
 #include "Relinearization.h"
 
+#include <cstdio>
 #include <cstring>
 #include <utility>
 #include <exception>
@@ -127,6 +128,27 @@ void initRelin(ZZX *evalkey) {
 		for (int i = 0; i < param.rawLen; i++)
 			BytesFromZZ((uint8 *)&host[((size_t)k * param.rawLen + i) * W0], coeff(evalkey[k], i), W0 * sizeof(uint32));
 	CSC(cuhe_hip_init_relin(host.data()));
+}
+void saveRelinearization(const char *path) {
+	const size_t bytes = cuhe_hip_relin_cache_size();
+	vector<uint8> img(bytes);
+	CSC(cuhe_hip_relin_export(img.data(), bytes, 0));
+	FILE *f = fopen(path, "wb");
+	if (!f || fwrite(img.data(), 1, bytes, f) != bytes) { fprintf(stderr, "saveRelinearization: cannot write %s\n", path); exit(-1); }
+	fclose(f);
+}
+bool loadRelinearization(const char *path) {
+	FILE *f = fopen(path, "rb");
+	if (!f) { fprintf(stderr, "loadRelinearization: cannot open %s\n", path); return false; }
+	fseek(f, 0, SEEK_END);
+	const long bytes = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	vector<uint8> img(bytes > 0 ? bytes : 0);
+	const bool readOk = bytes > 0 && fread(img.data(), 1, (size_t)bytes, f) == (size_t)bytes;
+	fclose(f);
+	if (!readOk) { fprintf(stderr, "loadRelinearization: cannot read %s\n", path); return false; }
+	if (cuhe_hip_relin_import(img.data(), img.size()) != CUHE_OK) { fprintf(stderr, "loadRelinearization: %s\n", cuhe_hip_last_error()); return false; }
+	return true;
 }
 void relinearization(uint64 *dst, uint32 *src, int lvl, int dev, cudaStream_t st) {
 	CSC(cuhe_hip_relinearization(U64P(dst), src, lvl, dev, st));

@@ -123,6 +123,9 @@ inline long to_long(const ZZ &a) { unsigned long v = 0; for (size_t i = a.m.size
 inline void conv(unsigned &x, const ZZ &a) { x = a.m.empty() ? 0u : a.m[0]; }
 inline void conv(long &x, const ZZ &a) { x = to_long(a); }
 inline void conv(ZZ &x, long a) { x = ZZ(a); }
+inline void conv(ZZ &x, int a) { x = ZZ((long)a); }
+inline void conv(ZZ &x, const char *s) { x = to_ZZ(s); }
+template <class T, class S> inline T conv(const S &a) { T x; conv(x, a); return x; }
 inline long NumBits(const ZZ &a) { return a.bits(); }
 inline long IsZero(const ZZ &a) { return a.zero(); }
 inline void clear(ZZ &a) { a = ZZ(); }

@@ -133,6 +133,12 @@ int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void 
 int cuhe_hip_init_relin(const uint32_t *evalkey_raw_host);
 /* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst ntt u64[np][nttLen] */
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
+/* binary evaluation-key cache: the NTT-domain keys initRelinearization computes (u64[prime][key][nttLen],
+   Relinearization.cu:45-55) behind a 96-byte header naming the parameter set and the CRT primes; import refuses
+   an image made for other parameters / primes or with a damaged payload.  cache_size = 0 before init. */
+size_t cuhe_hip_relin_cache_size(void);
+int cuhe_hip_relin_export(void *dst_host, size_t capacity, int dev);
+int cuhe_hip_relin_import(const void *src_host, size_t bytes);
 
 /* ---- CRT-prime-sharded variants (new): one rank owns primes [prime0, prime0+count) of level
  * `lvl`; row pointers address the shard's own rows (row 0 = prime0).  Per-prime stages need no communication;

@@ -3,6 +3,7 @@
 // host ZZX arithmetic: t = a*b; t %= Phi_m; coefficients % q  (examples/DHS/DHS.cu:219-221).
 // Runs on a GPU box; exit code 0 = all checks passed.
 #include "CuHE.h"
+#include "Relinearization.h"
 #include <cstdio>
 #include <vector>
 using namespace cuHE;
@@ -102,6 +103,21 @@ int main() {
 		CuCtxt keep; copy(keep, cz);
 		cz.x2z();
 		CHECK(cz.zRep() == want, "cAnd + relin equals the windowed key-switch sum");
+		// binary key cache: save, clobber the resident keys with other ones, load, relinearise again
+		{
+			const char *path = "/tmp/cuhe_evalkeys.bin";
+			saveRelinearization(path);
+			std::vector<ZZX> other(param.numEvalKey);
+			for (auto &e : other) e = randomPoly(n, q[0]);
+			initRelinearization(other.data());
+			CuCtxt c2; cAnd(c2, ca, cb); c2.relin(); c2.x2z();
+			const bool differs = !(c2.zRep() == want);
+			const bool loaded = loadRelinearization(path);
+			CuCtxt c3; cAnd(c3, ca, cb); c3.relin(); c3.x2z();
+			CHECK(differs && loaded && c3.zRep() == want, "saveRelinearization / loadRelinearization restore the NTT-domain keys");
+			remove(path);
+			CHECK(!loadRelinearization(path), "loading a missing key cache reports failure");
+		}
 		// modSwitch on the relinearised ciphertext
 		keep.modSwitch();
 		CHECK(keep.level() == 1 && keep.logq() == param._logCoeff(1), "modSwitch advances the level");

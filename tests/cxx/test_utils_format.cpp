@@ -1,0 +1,69 @@
+// test_utils_format.cpp -- the key-file text format of cuhe/Utils.h (Picklable / PicklableMap): known strings
+// written by hand from the format rules of cuhe/Utils.cu:76-121,141-146,203-213, parse/print round trips, and
+// the lookup behaviour examples/DHS/DHS.cu:62-124 depends on.  Host only.
+#include "Utils.h"
+#include <cstdio>
+using namespace cuHE_Utils;
+
+static int failures = 0;
+#define CHECK(cond, what) do { if (!(cond)) { printf("FAIL: %s (%s:%d)\n", what, __FILE__, __LINE__); ++failures; } else printf("ok: %s\n", what); } while (0)
+
+int main() {
+	ZZX p;
+	SetCoeff(p, 0, 3); SetCoeff(p, 2, 5); SetCoeff(p, 3, -7);
+	Picklable pk("pk0", p);
+	CHECK(pk.pickle() == "pk0,3,0,5,-7", "polynomial entry: key, then coefficients low degree first");
+	CHECK(pk.getValues() == "3,0,5,-7" && pk.getKey() == "pk0" && pk.getCoeffsLen() == 4, "accessors");
+
+	ZZ arr[3] = {to_ZZ(4), to_ZZ(0), to_ZZ(0)};
+	Picklable d("d", arr, 3);
+	CHECK(d.pickle() == "d,4", "an array goes through a polynomial: trailing zeros vanish");
+	arr[0] = to_ZZ(9);
+	CHECK(d.pickle() == "d,4" && d.getCoeffs()[0] == to_ZZ(4), "the entry keeps its own copy of the array");
+
+	ZZ big = power2_ZZ(100) + to_ZZ(1);
+	ZZ two[2] = {big, -big};
+	Picklable cm("coeffMod", two, 2);
+	CHECK(cm.pickle() == "coeffMod,1267650600228229401496703205377,-1267650600228229401496703205377", "multi-word integers in decimal");
+
+	Picklable parsed("ek3,10,0,0,1267650600228229401496703205377,0");
+	CHECK(parsed.getKey() == "ek3" && deg(parsed.getPoly()) == 3 && coeff(parsed.getPoly(), 3) == big && coeff(parsed.getPoly(), 0) == to_ZZ(10), "parse one entry");
+	CHECK(parsed.pickle() == "ek3,10,0,0,1267650600228229401496703205377", "re-printing drops the trailing zero");
+	Picklable gaps("k,,7,,8");
+	CHECK(gaps.pickle() == "k,7,8", "empty fields vanish (strtok semantics)");
+
+	Picklable semi("s;1;2;3", ";");
+	CHECK(semi.getKey() == "s" && semi.pickle() == "s;1;2;3", "custom field separator");
+	semi.setSeparator(" ");
+	CHECK(semi.pickle() == "s 1 2 3", "setSeparator re-renders the values");
+
+	Picklable copyOf(pk);
+	CHECK(copyOf.pickle() == pk.pickle() && copyOf.getCoeffs() != pk.getCoeffs(), "copy owns its own coefficient array");
+
+	vector<Picklable *> ps;
+	ps.push_back(new Picklable("d", arr, 1));
+	ps.push_back(new Picklable("polyMod", p));
+	ps.push_back(new Picklable("pk0", p));
+	PicklableMap m(ps);
+	const string text = m.toString();
+	CHECK(text == "d,9\npolyMod,3,0,5,-7\npk0,3,0,5,-7", "map: entries joined by newline, no trailing separator");
+	PicklableMap back(text);
+	CHECK(back.getPicklables().size() == 3 && back.toString() == text, "map text round trip");
+	CHECK(back.get("polyMod")->getPoly() == p && back.get("d")->getValues() == "9", "lookup by key");
+	bool threw = false;
+	try { back.get("sk0"); } catch (char const *s) { threw = string(s) == "not found"; }
+	CHECK(threw, "a missing key throws the C string \"not found\" (DHS.cu:85-90 catches char const*)");
+	PicklableMap custom("a:1:2|b:3", "|", ":");
+	CHECK(custom.get("b")->getValues() == "3" && custom.toString() == "a:1:2|b:3", "custom entry and field separators");
+
+	// random round trip with signed multi-word coefficients
+	SetSeed(to_ZZ(7));
+	ZZX r;
+	for (int i = 63; i >= 0; --i) SetCoeff(r, i, RandomBnd(power2_ZZ(200)) - power2_ZZ(199));
+	Picklable rp("r", r);
+	Picklable rq(rp.pickle());
+	CHECK(rq.getPoly() == r, "random signed 200-bit coefficients survive print + parse");
+
+	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+	return failures ? 1 : 0;
+}

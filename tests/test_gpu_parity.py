@@ -496,3 +496,49 @@ def test_alternative_kernel_forms(gu, p1, p2):
             g.close(); o.close()
     finally:
         ck(lib.cuhe_hip_set_pass1_form(1)); ck(lib.cuhe_hip_set_pass2_form(1))
+
+
+def test_evalkey_cache_roundtrip(gu):
+    """binary evaluation-key cache (include/cuhe_hip.h: cuhe_hip_relin_export / _import): an exported image, re-imported
+    into a FRESH context of the same parameters, relinearises exactly like the context that computed the keys and
+    like the oracle; images for other parameters, truncated images and damaged payloads are refused."""
+    import ctypes
+    import oracle_lib as O
+    args = (3, 2, 16, 25, 25, 21845)
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE000 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        assert gu.lib.cuhe_hip_relin_export(None, 0, 0) != 0          # nothing to export before initRelinearization
+        g.init_relin(ek_raw)
+        size = gu.lib.cuhe_hip_relin_cache_size()
+        assert size == 96 + q.numCrtPrime * K * q.nttLen * 8
+        img = np.zeros(size, dtype=np.uint8)
+        assert gu.lib.cuhe_hip_relin_export(img.ctypes.data_as(ctypes.c_void_p), size - 1, 0) != 0   # too small
+        gu.ck(gu.lib.cuhe_hip_relin_export(img.ctypes.data_as(ctypes.c_void_p), size, 0))
+        assert bytes(img[:8]) == b"CUHEEK\x00\x01"
+        keys = img[96:].view(np.uint64).reshape(q.numCrtPrime, K, q.nttLen)
+        assert np.array_equal(keys, np.asarray(ek).reshape(q.numCrtPrime, K, q.nttLen))    # payload = oracle's NTT-domain keys
+        ct, _ = O.random_raw(q.rawLen, q.modLen, o.words(1), o.coeff_modulus(1), 0xC1)
+        want = o.relin(ct, 1, ek)
+        assert np.array_equal(g.relin(ct, 1), want)
+    finally:
+        g.close()
+    g = gu.GpuCtx(*args)                                                # fresh context: no keys yet
+    try:
+        bad = img.copy(); bad[96 + 12345] ^= 1
+        assert gu.lib.cuhe_hip_relin_import(bad.ctypes.data_as(ctypes.c_void_p), size) != 0           # damaged payload
+        assert gu.lib.cuhe_hip_relin_import(img.ctypes.data_as(ctypes.c_void_p), size - 8) != 0       # truncated
+        bad = img.copy(); bad[0] = ord("X")
+        assert gu.lib.cuhe_hip_relin_import(bad.ctypes.data_as(ctypes.c_void_p), size) != 0           # bad magic
+        gu.ck(gu.lib.cuhe_hip_relin_import(img.ctypes.data_as(ctypes.c_void_p), size))
+        assert np.array_equal(g.relin(ct, 1), want)
+    finally:
+        g.close()
+    g = gu.GpuCtx(3, 2, 8, 25, 25, 21845)                              # other window size: the image must be refused
+    try:
+        assert gu.lib.cuhe_hip_relin_import(img.ctypes.data_as(ctypes.c_void_p), size) != 0
+    finally:
+        g.close(); o.close()
