@@ -70,14 +70,52 @@ public:
     bool bit(int i) const { size_t w = (size_t)i / 32; return w < m.size() && ((m[w] >> (i % 32)) & 1); }
     void shl1() { uint32_t c = 0; for (auto &x : m) { uint32_t n = x >> 31; x = (x << 1) | c; c = n; } if (c) m.push_back(c); }
     // floor division (NTL semantics: remainder has the sign of the divisor)
-    static void divrem(const ZZ &a, const ZZ &b, ZZ &q, ZZ &r) {
-        ZZ A = a, B = b; A.neg = B.neg = false;
-        q = ZZ(); r = ZZ();
-        q.m.assign(A.m.size(), 0);
-        for (int i = A.bits() - 1; i >= 0; --i) {
-            r.shl1(); if (A.bit(i)) { if (r.m.empty()) r.m.push_back(1); else r.m[0] |= 1; }
-            if (cmpmag(r, B) >= 0) { r = submag(r, B); q.m[i / 32] |= 1u << (i % 32); }
+    // |a| / |b| by schoolbook long division in base 2^32 (Knuth's algorithm D); b != 0
+    static void divmag(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, std::vector<uint32_t> &q, std::vector<uint32_t> &r) {
+        const size_t n = b.size();
+        if (a.size() < n) { q.clear(); r = a; return; }
+        if (n == 1) {
+            uint64_t rem = 0; q.assign(a.size(), 0);
+            for (size_t i = a.size(); i-- > 0;) { const uint64_t cur = (rem << 32) | a[i]; q[i] = (uint32_t)(cur / b[0]); rem = cur % b[0]; }
+            r.assign(1, (uint32_t)rem);
+            return;
         }
+        const size_t m = a.size() - n;
+        int s = 0; for (uint32_t t = b.back(); !(t & 0x80000000u); t <<= 1) ++s;
+        std::vector<uint32_t> v(n), u(a.size() + 1);
+        for (size_t i = n; i-- > 1;) v[i] = (b[i] << s) | (s ? b[i - 1] >> (32 - s) : 0);
+        v[0] = b[0] << s;
+        u[a.size()] = s ? a.back() >> (32 - s) : 0;
+        for (size_t i = a.size(); i-- > 1;) u[i] = (a[i] << s) | (s ? a[i - 1] >> (32 - s) : 0);
+        u[0] = a[0] << s;
+        q.assign(m + 1, 0);
+        for (size_t j = m + 1; j-- > 0;) {
+            const uint64_t num = ((uint64_t)u[j + n] << 32) | u[j + n - 1];
+            uint64_t qhat = num / v[n - 1], rhat = num % v[n - 1];
+            while (qhat >> 32 || qhat * v[n - 2] > ((rhat << 32) | u[j + n - 2])) { --qhat; rhat += v[n - 1]; if (rhat >> 32) break; }
+            int64_t borrow = 0; uint64_t carry = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const uint64_t pr = qhat * v[i] + carry; carry = pr >> 32;
+                const int64_t t = (int64_t)u[i + j] - borrow - (int64_t)(pr & 0xffffffffu);
+                u[i + j] = (uint32_t)t; borrow = t < 0;
+            }
+            const int64_t t = (int64_t)u[j + n] - borrow - (int64_t)carry;
+            u[j + n] = (uint32_t)t;
+            if (t < 0) {                       // qhat was one too large: add the divisor back
+                --qhat; uint64_t c = 0;
+                for (size_t i = 0; i < n; ++i) { c += (uint64_t)u[i + j] + v[i]; u[i + j] = (uint32_t)c; c >>= 32; }
+                u[j + n] += (uint32_t)c;
+            }
+            q[j] = (uint32_t)qhat;
+        }
+        r.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) r[i] = (u[i] >> s) | (s ? u[i + 1] << (32 - s) : 0);
+    }
+    // floor division (NTL semantics: remainder has the sign of the divisor)
+    static void divrem(const ZZ &a, const ZZ &b, ZZ &q, ZZ &r) {
+        ZZ B = b; B.neg = false;
+        q = ZZ(); r = ZZ();
+        divmag(a.m, B.m, q.m, r.m);
         q.trim(); r.trim();
         if (a.neg != b.neg) {         // truncated -> floor
             q.neg = !q.zero();
@@ -128,6 +166,8 @@ inline void conv(ZZ &x, const char *s) { x = to_ZZ(s); }
 template <class T, class S> inline T conv(const S &a) { T x; conv(x, a); return x; }
 inline long NumBits(const ZZ &a) { return a.bits(); }
 inline long IsZero(const ZZ &a) { return a.zero(); }
+inline long IsOdd(const ZZ &a) { return !a.m.empty() && (a.m[0] & 1); }
+inline long bit(const ZZ &a, long k) { return a.bit((int)k); }
 inline void clear(ZZ &a) { a = ZZ(); }
 inline ZZ power(const ZZ &a, long e) { ZZ r(1), b = a; while (e) { if (e & 1) r = r * b; b = b * b; e >>= 1; } return r; }
 inline ZZ power2_ZZ(long e) { ZZ r; r.m.assign(e / 32 + 1, 0); r.m[e / 32] = 1u << (e % 32); return r; }

@@ -6,154 +6,19 @@
 // image).  A wrong relinearisation, modulus switch, reduction mod Phi_m or CRT/ICRT makes decryption fail,
 // so "right" here is an end-to-end semantic check of the whole hot path, independent of the oracle.
 //
-// Scheme (examples/DHS/DHS.cu:212-372, restated):  f = 2f'+1 invertible in Z_q0[x]/Phi_m, pk = 2 g f^-1,
+// Scheme (examples/DHS/DHS.cu:212-372, restated in tests/cxx/dhs_client.hpp):  f = 2f'+1 invertible in Z_q0[x]/Phi_m, pk = 2 g f^-1,
 // Enc(m) = pk s + 2e + m, Dec(c) = centred(f c) mod 2, ek_j = pk s_j + 2 e_j + f 2^(w j),
 // AND = product, relin = sum_j window_j(c) ek_j, then modSwitch.  No batching: a message is a polynomial
 // with binary coefficients, XOR/AND act on it as addition/multiplication in Z_2[x]/Phi_m.
 //
 // usage: test_dhs_flow [d p w min cut m]   (default: the reference example's (5,2,1,61,20,8191))
-#include "CuHE.h"
-#include "cuhe_hip.h"
-#include <cstdio>
-#include <cstdlib>
-#include <vector>
+#include "dhs_client.hpp"
 using namespace cuHE;
+using dhs_client::Dhs;
 typedef long long i64;
-typedef unsigned long long u64x;
 
 static int failures = 0;
 static void report(const char *what, bool ok) { printf("%s\t%s\n", what, ok ? "right" : "wrong"); if (!ok) ++failures; }
-
-static std::vector<i64> cyclotomicInts(int m) {
-	auto mu = [](int n) { int r = 1; for (int p = 2; p * p <= n; ++p) if (n % p == 0) { n /= p; if (n % p == 0) return 0; r = -r; } if (n > 1) r = -r; return r; };
-	std::vector<i64> a(2 * m + 2, 0); int len = 1; a[0] = 1;
-	for (int d = 1; d <= m; ++d) if (m % d == 0 && mu(m / d) == 1) { for (int i = len - 1; i >= 0; --i) { a[i + d] += a[i]; a[i] = -a[i]; } len += d; }
-	for (int d = 1; d <= m; ++d) if (m % d == 0 && mu(m / d) == -1) { for (int i = 0; i < len - d; ++i) a[i] = (i >= d ? a[i - d] : 0) - a[i]; len -= d; }
-	a.resize(len); return a;
-}
-
-// ---------------------------------------------------------------- F_p[x] helpers for the key inverse
-static u64x powmod(u64x b, u64x e, u64x p) { u64x r = 1; b %= p; while (e) { if (e & 1) r = r * b % p; b = b * b % p; e >>= 1; } return r; }
-// inverse of f modulo (phi, p) by the extended Euclidean algorithm; false if gcd(f, phi) != 1 over F_p
-static bool invertModPrime(std::vector<unsigned> &inv, const std::vector<unsigned> &f, const std::vector<unsigned> &phi, unsigned p) {
-	typedef std::vector<u64x> Poly;
-	auto trim = [](Poly &a) { while (!a.empty() && a.back() == 0) a.pop_back(); };
-	Poly r0(phi.begin(), phi.end()), r1(f.begin(), f.end()), t0, t1(1, 1);
-	trim(r0); trim(r1);
-	while (!r1.empty()) {
-		// r0 = q r1 + r2, t2 = t0 - q t1, one quotient term at a time
-		const u64x lead = powmod(r1.back(), p - 2, p);
-		while (r0.size() >= r1.size()) {
-			const size_t sh = r0.size() - r1.size();
-			const u64x c = r0.back() * lead % p;
-			for (size_t i = 0; i < r1.size(); ++i) r0[i + sh] = (r0[i + sh] + (p - c) * r1[i]) % p;
-			if (t0.size() < t1.size() + sh) t0.resize(t1.size() + sh, 0);
-			for (size_t i = 0; i < t1.size(); ++i) t0[i + sh] = (t0[i + sh] + (p - c) * t1[i]) % p;
-			trim(r0);
-			if (r0.empty()) break;
-		}
-		std::swap(r0, r1); std::swap(t0, t1);
-	}
-	if (r0.size() != 1) return false;                       // gcd has positive degree
-	const u64x g = powmod(r0[0], p - 2, p);
-	// t0 may have degree >= deg(phi) only transiently; reduce modulo phi (monic)
-	Poly t = t0; const size_t n = phi.size() - 1;
-	for (size_t k = t.size(); k-- > n;) { const u64x c = t[k]; if (!c) continue; for (size_t i = 0; i <= n; ++i) t[k - n + i] = (t[k - n + i] + (p - c) * phi[i]) % p; }
-	inv.assign(n, 0);
-	for (size_t i = 0; i < n && i < t.size(); ++i) inv[i] = (unsigned)(t[i] * g % p);
-	return true;
-}
-
-// ---------------------------------------------------------------- the scheme
-struct Dhs {
-	int n, depth, np;
-	std::vector<ZZ> q;                 // coefficient modulus per level
-	std::vector<unsigned> primes;
-	std::vector<i64> phi;
-	ZZX phiZ;
-	std::vector<ZZX> pk, sk, ek;
-
-	ZZX sample() { ZZX r; for (int i = n - 1; i >= 0; --i) SetCoeff(r, i, RandomBnd(to_ZZ(3)) - to_ZZ(1)); return r; }
-	ZZX reduce(const ZZX &a, const ZZ &m) { ZZX r; for (long i = deg(a); i >= 0; --i) SetCoeff(r, i, coeff(a, i) % m); return r; }
-	ZZX scaleAdd(const ZZX &a, long s, const ZZX &b) { ZZX r; long d = std::max(deg(a), deg(b)); for (long i = d; i >= 0; --i) SetCoeff(r, i, coeff(a, i) * to_ZZ(s) + coeff(b, i)); return r; }
-
-	bool invert(ZZX &finv, const ZZX &f) {
-		// per CRT prime (Z_q0[x]/Phi is the product of the F_p[x]/Phi), then lift the coefficients
-		std::vector<std::vector<unsigned>> rows(np);
-		for (int i = 0; i < np; ++i) {
-			const unsigned p = primes[i];
-			std::vector<unsigned> fp(n), php(n + 1);
-			for (int k = 0; k < n; ++k) fp[k] = (unsigned)to_long(coeff(f, k) % to_ZZ((long)p));
-			for (int k = 0; k <= n; ++k) php[k] = (unsigned)(((phi[k] % (i64)p) + p) % p);
-			if (!invertModPrime(rows[i], fp, php, p)) return false;
-		}
-		std::vector<ZZ> lift(np);
-		for (int i = 0; i < np; ++i) {
-			const ZZ mi = q[0] / to_ZZ((long)primes[i]);
-			const u64x bi = powmod((u64x)to_long(mi % to_ZZ((long)primes[i])), primes[i] - 2, primes[i]);
-			lift[i] = mi * to_ZZ((long)bi);
-		}
-		clear(finv);
-		for (int k = n - 1; k >= 0; --k) {
-			ZZ v;
-			for (int i = 0; i < np; ++i) v += lift[i] * to_ZZ((long)rows[i][k]);
-			SetCoeff(finv, k, v % q[0]);
-		}
-		return true;
-	}
-
-	void setup(int d, int p, int w, int mn, int cut, int m) {
-		setParameters(d, p, w, mn, cut, m);
-		n = param.modLen; depth = param.depth; np = param.numCrtPrime;
-		phi = cyclotomicInts(m);
-		for (size_t i = 0; i < phi.size(); ++i) if (phi[i]) SetCoeff(phiZ, (long)i, to_ZZ((long)phi[i]));
-		q.resize(depth);
-		initCuHE(q.data(), phiZ);
-		primes.resize(np);
-		if (cuhe_hip_get_crt_primes(primes.data(), np) != 0) { printf("cannot read the CRT primes\n"); exit(2); }
-		// keys (DHS.cu:286-322)
-		ZZX f, finv, g;
-		for (;;) {
-			f = scaleAdd(sample(), param.modMsg, ZZX());
-			SetCoeff(f, 0, coeff(f, 0) + to_ZZ(1));
-			f = reduce(f, q[0]);
-			if (invert(finv, f)) break;
-		}
-		g = reduce(sample(), q[0]);
-		pk.resize(depth); sk.resize(depth);
-		sk[0] = f;
-		mulZZX(pk[0], g, finv, 0, 0, 0);
-		pk[0] = reduce(scaleAdd(pk[0], param.modMsg, ZZX()), q[0]);
-		for (int i = 1; i < depth; ++i) { sk[i] = reduce(sk[i - 1], q[i]); pk[i] = reduce(pk[i - 1], q[i]); }
-		// evaluation keys (DHS.cu:323-345)
-		ek.resize(param.numEvalKey);
-		ZZ tw = to_ZZ(1); const ZZ wbase = power2_ZZ(param.logRelin);
-		for (int j = 0; j < param.numEvalKey; ++j) {
-			ZZX tp; for (int k = n - 1; k >= 0; --k) SetCoeff(tp, k, (coeff(sk[0], k) * tw) % q[0]);
-			ZZX s = reduce(sample(), q[0]), e = sample(), t;
-			mulZZX(t, pk[0], s, 0, 0, 0);
-			ek[j] = reduce(scaleAdd(e, param.modMsg, t) + tp, q[0]);
-			tw *= wbase;
-		}
-		initRelinearization(ek.data());
-	}
-	ZZX encrypt(const ZZX &msg, int lvl) {
-		ZZX s = reduce(sample(), q[lvl]), e = sample(), t;
-		mulZZX(t, pk[lvl], s, lvl, 0, 0);
-		return reduce(scaleAdd(e, param.modMsg, t) + msg, q[lvl]);
-	}
-	ZZX decrypt(const ZZX &c, int lvl) {
-		ZZX t, out;
-		mulZZX(t, reduce(c, q[lvl]), sk[lvl], lvl, 0, 0);
-		const ZZ half = (q[lvl] - to_ZZ(1)) / to_ZZ(2);
-		for (long i = deg(t); i >= 0; --i) {
-			ZZ x = coeff(t, i);
-			if (x > half) x -= q[lvl];
-			SetCoeff(out, i, x % to_ZZ(param.modMsg));
-		}
-		return out;
-	}
-};
 
 static ZZX randomBits(int n) { ZZX r; for (int i = n - 1; i >= 0; --i) SetCoeff(r, i, RandomBnd(to_ZZ(2))); return r; }
 // (a * b mod Phi) mod 2 with machine integers

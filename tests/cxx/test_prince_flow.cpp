@@ -1,0 +1,267 @@
+// test_prince_flow.cpp -- homomorphic evaluation of the PRINCE block cipher through the C++ drop-in API
+// (cuhe_amd/cxx/CuHE.h), BASELINE config 5 on one GPU: the application the reference ships as
+// examples/Prince (Prince.cu).  Written from scratch: the cipher comes from its published specification
+// (Borghoff et al., ASIACRYPT 2012) and is first checked against the five test vectors of that paper; the
+// S-box circuits are DERIVED here from the S-box table (algebraic normal form by the Moebius transform), and
+// evaluated with the multiplication schedule the reference's S-box uses (Prince.cu:204-322: six pairwise
+// products, ab and cd relinearised, four cubic products, one relinearisation per output bit -- 10 cAnd and
+// 6 relin per S-box, 1920 cAnd and 1152 relin per encryption, depth 24 over 25 levels).
+//
+// Known answers: PRINCE(pt = 0, k0 = ff..ff, k1 = 0) = 0x9fb51935fc3df524 (Prince.cu:96) and the
+// 12 intermediate states after each S-box layer (Prince.cu:108-145), which the plain implementation below
+// reproduces and the homomorphic evaluation must decrypt to, bit for bit, at every layer.
+//
+// Unlike the reference, the 64 state ciphertexts stay resident on the GPU between layers (the linear layers are
+// cXor / cNot on CRT-domain ciphertexts instead of host ZZX additions).
+//
+// usage: test_prince_flow [--no-round-checks]
+#include "dhs_client.hpp"
+#include <chrono>
+#include <memory>
+#include <string>
+using namespace cuHE;
+using dhs_client::Dhs;
+typedef unsigned long long u64x;
+typedef std::chrono::steady_clock clk;
+
+// ------------------------------------------------------------------ plain PRINCE on bit vectors (bit 0 = MSB)
+static const int SBOX[16] = {0xB, 0xF, 0x3, 0x2, 0xA, 0xC, 0x9, 0x1, 0x6, 0x7, 0x8, 0x0, 0xE, 0x5, 0xD, 0x4};
+static const u64x RC[12] = {0x0000000000000000ULL, 0x13198a2e03707344ULL, 0xa4093822299f31d0ULL, 0x082efa98ec4e6c89ULL,
+                            0x452821e638d01377ULL, 0xbe5466cf34e90c6cULL, 0x7ef84f78fd955cb1ULL, 0x85840851f1ac43aaULL,
+                            0xc882d32f25323c54ULL, 0x64a51195e0e3610dULL, 0xd3b5a399ca0c2399ULL, 0xc0ac29b7c97c50ddULL};
+static const int SR[16] = {0, 5, 10, 15, 4, 9, 14, 3, 8, 13, 2, 7, 12, 1, 6, 11};
+typedef std::vector<int> Bits;
+static Bits toBits(u64x x) { Bits b(64); for (int i = 0; i < 64; ++i) b[i] = (int)((x >> (63 - i)) & 1); return b; }
+static u64x toVal(const Bits &b) { u64x v = 0; for (int i = 0; i < 64; ++i) v = (v << 1) | (u64x)b[i]; return v; }
+// M' as a list of three source bits per output bit: block-diagonal (M^0, M^1, M^1, M^0), each 16x16 built from the
+// 4x4 identity matrices with one diagonal entry cleared
+static std::vector<std::vector<int>> mPrimeSources() {
+	std::vector<std::vector<int>> src(64);
+	const int first[4] = {0, 1, 1, 0};
+	for (int chunk = 0; chunk < 4; ++chunk)
+		for (int br = 0; br < 4; ++br) for (int r = 0; r < 4; ++r)
+			for (int bc = 0; bc < 4; ++bc) {
+				const int cleared = (first[chunk] + br + bc) % 4;
+				if (r != cleared) src[16 * chunk + 4 * br + r].push_back(16 * chunk + 4 * bc + r);
+			}
+	return src;
+}
+static Bits plainSub(const Bits &b, const int *box) {
+	Bits o(64);
+	for (int i = 0; i < 16; ++i) {
+		const int v = box[(b[4 * i] << 3) | (b[4 * i + 1] << 2) | (b[4 * i + 2] << 1) | b[4 * i + 3]];
+		for (int k = 0; k < 4; ++k) o[4 * i + k] = (v >> (3 - k)) & 1;
+	}
+	return o;
+}
+static Bits plainMPrime(const Bits &b) { static const auto src = mPrimeSources(); Bits o(64); for (int i = 0; i < 64; ++i) { int v = 0; for (int s : src[i]) v ^= b[s]; o[i] = v; } return o; }
+static Bits plainSR(const Bits &b) { Bits o(64); for (int i = 0; i < 16; ++i) for (int k = 0; k < 4; ++k) o[4 * i + k] = b[4 * SR[i] + k]; return o; }
+static Bits plainSRinv(const Bits &b) { Bits o(64); for (int i = 0; i < 16; ++i) for (int k = 0; k < 4; ++k) o[4 * SR[i] + k] = b[4 * i + k]; return o; }
+static Bits plainXor(Bits a, const Bits &b) { for (int i = 0; i < 64; ++i) a[i] ^= b[i]; return a; }
+static u64x plainPrince(u64x pt, u64x k0, u64x k1, std::vector<u64x> *states) {
+	int inv[16]; for (int i = 0; i < 16; ++i) inv[SBOX[i]] = i;
+	const u64x k0p = ((k0 >> 1) | ((k0 & 1) << 63)) ^ (k0 >> 63);
+	Bits s = plainXor(plainXor(plainXor(toBits(pt), toBits(k0)), toBits(k1)), toBits(RC[0]));
+	for (int i = 1; i <= 5; ++i) {
+		s = plainSub(s, SBOX); if (states) states->push_back(toVal(s));
+		s = plainXor(plainXor(plainSR(plainMPrime(s)), toBits(RC[i])), toBits(k1));
+	}
+	s = plainSub(s, SBOX); if (states) states->push_back(toVal(s));
+	s = plainSub(plainMPrime(s), inv); if (states) states->push_back(toVal(s));
+	for (int i = 6; i <= 10; ++i) {
+		s = plainXor(plainXor(s, toBits(k1)), toBits(RC[i]));
+		s = plainSub(plainMPrime(plainSRinv(s)), inv); if (states) states->push_back(toVal(s));
+	}
+	return toVal(plainXor(plainXor(plainXor(s, toBits(RC[11])), toBits(k1)), toBits(k0p)));
+}
+
+// algebraic normal form of a 4-bit S-box: anf[o][mask] = coefficient of the monomial `mask` (8 = a, 4 = b, 2 = c, 1 = d;
+// a is the most significant input bit) in output bit o (0 = most significant)
+struct Anf { int c[4][16]; };
+static Anf anfOf(const int *box) {
+	Anf f;
+	for (int o = 0; o < 4; ++o) {
+		int t[16]; for (int x = 0; x < 16; ++x) t[x] = (box[x] >> (3 - o)) & 1;
+		for (int bit = 1; bit < 16; bit <<= 1) for (int x = 0; x < 16; ++x) if (x & bit) t[x] ^= t[x ^ bit];
+		for (int x = 0; x < 16; ++x) f.c[o][x] = t[x];
+	}
+	return f;
+}
+
+// ------------------------------------------------------------------ homomorphic evaluation
+typedef std::unique_ptr<CuCtxt> Ct;
+static int failures = 0;
+static long numAnd = 0, numRelin = 0, numModSwitch = 0;
+
+static void accumulate(CuCtxt &out, bool &has, CuCtxt &term) {
+	if (!has) { copy(out, term); has = true; } else cXor(out, out, term);
+}
+static void relinCt(CuCtxt &x) { x.relin(); ++numRelin; }
+static void modSwitchCt(CuCtxt &x) { x.modSwitch(); ++numModSwitch; }
+
+// one S-box on the nibble (s[0..3] = a..d, CRT domain, level L) -> four outputs at level L + 2
+static void sboxNibble(Ct s[4], const Anf &f) {
+	CuCtxt &a = *s[0], &b = *s[1], &c = *s[2], &d = *s[3];
+	a.x2n(); b.x2n(); c.x2n(); d.x2n();
+	CuCtxt ab, ac, ad, bc, bd, cd;
+	cAnd(ab, a, b); cAnd(ac, a, c); cAnd(ad, a, d); cAnd(bc, b, c); cAnd(bd, b, d); cAnd(cd, c, d);
+	numAnd += 6;
+	relinCt(ab); relinCt(cd);
+	CuCtxt *lvl1[10] = {&ab, &ac, &ad, &bc, &bd, &cd, &a, &b, &c, &d};
+	for (CuCtxt *x : lvl1) modSwitchCt(*x);
+	// linear and quadratic monomials (all in the CRT domain at level L + 1)
+	struct Term { int mask; CuCtxt *ct; };
+	const Term low[10] = {{8, &a}, {4, &b}, {2, &c}, {1, &d}, {12, &ab}, {10, &ac}, {9, &ad}, {6, &bc}, {5, &bd}, {3, &cd}};
+	Ct out[4]; bool has[4] = {false, false, false, false};
+	for (int o = 0; o < 4; ++o) {
+		out[o].reset(new CuCtxt);
+		for (const Term &t : low) if (f.c[o][t.mask]) accumulate(*out[o], has[o], *t.ct);
+	}
+	// cubic monomials from the two relinearised pairs
+	a.x2n(); b.x2n(); c.x2n(); d.x2n(); ab.x2n(); cd.x2n();
+	CuCtxt abd, acd, bcd, abc;
+	cAnd(abd, ab, d); cAnd(acd, cd, a); cAnd(bcd, cd, b); cAnd(abc, ab, c);
+	numAnd += 4;
+	abd.x2c(); acd.x2c(); bcd.x2c(); abc.x2c();
+	const Term high[4] = {{13, &abd}, {11, &acd}, {7, &bcd}, {14, &abc}};
+	for (int o = 0; o < 4; ++o) {
+		for (const Term &t : high) if (f.c[o][t.mask]) accumulate(*out[o], has[o], *t.ct);
+		if (f.c[o][15] || !has[o]) { printf("unexpected S-box structure\n"); exit(2); }
+		if (f.c[o][0]) cNot(*out[o], *out[o]);
+		relinCt(*out[o]);
+		modSwitchCt(*out[o]);
+	}
+	for (int o = 0; o < 4; ++o) s[o] = std::move(out[o]);
+}
+
+struct Evaluator {
+	Dhs &dhs;
+	std::vector<Ct> state, k1;
+	int level = 0;
+	bool checkRounds;
+	double paused = 0;                              // seconds spent in round checks (excluded from the timing)
+	std::vector<u64x> expect;
+	int layer = 0;
+	Evaluator(Dhs &d, bool chk) : dhs(d), checkRounds(chk) {}
+
+	static Ct upload(const ZZX &c, int lvl) { Ct x(new CuCtxt); x->setLevel(lvl, 0, c); x->x2c(); return x; }
+	int decryptBit(CuCtxt &x, int lvl, bool &constant) {
+		CuCtxt t; copy(t, x); t.x2z();
+		const ZZX m = dhs.decrypt(t.zRep(), lvl);
+		constant = deg(m) <= 0;
+		return IsZero(coeff(m, 0)) ? 0 : 1;
+	}
+	u64x decryptState(bool &constant) {
+		u64x v = 0; constant = true;
+		for (int i = 0; i < 64; ++i) { bool c; v = (v << 1) | (u64x)decryptBit(*state[i], level, c); constant = constant && c; }
+		return v;
+	}
+	void check() {
+		if (checkRounds) {
+			const auto t0 = clk::now();
+			bool constant; const u64x got = decryptState(constant);
+			const bool ok = constant && got == expect[layer];
+			printf("S-box layer %2d  level %2d  %016llx  %s\n", layer, level, got, ok ? "right" : "wrong");
+			if (!ok) ++failures;
+			paused += std::chrono::duration<double>(clk::now() - t0).count();
+		}
+		++layer;
+	}
+	void addConstant(u64x rc) { for (int i = 0; i < 64; ++i) if ((rc >> (63 - i)) & 1) cNot(*state[i], *state[i]); }
+	void addKey(std::vector<Ct> &k) { for (int i = 0; i < 64; ++i) cXor(*state[i], *state[i], *k[i]); }
+	void mPrime() {
+		static const auto src = mPrimeSources();
+		std::vector<Ct> next(64);
+		for (int i = 0; i < 64; ++i) {
+			next[i].reset(new CuCtxt);
+			copy(*next[i], *state[src[i][0]]);
+			for (size_t k = 1; k < src[i].size(); ++k) cXor(*next[i], *next[i], *state[src[i][k]]);
+		}
+		state.swap(next);
+	}
+	void shiftRows(bool inverse) {
+		std::vector<Ct> next(64);
+		for (int i = 0; i < 16; ++i) for (int k = 0; k < 4; ++k) {
+			if (!inverse) next[4 * i + k] = std::move(state[4 * SR[i] + k]);
+			else next[4 * SR[i] + k] = std::move(state[4 * i + k]);
+		}
+		state.swap(next);
+	}
+	void sboxLayer(const Anf &f) {
+		for (int i = 0; i < 16; ++i) sboxNibble(&state[4 * i], f);
+		level += 2;
+		for (auto &k : k1) { modSwitchCt(*k); modSwitchCt(*k); }
+	}
+	void encrypt(std::vector<Ct> &k0) {
+		int inv[16]; for (int i = 0; i < 16; ++i) inv[SBOX[i]] = i;
+		const Anf fwd = anfOf(SBOX), bwd = anfOf(inv);
+		addKey(k0); addKey(k1); addConstant(RC[0]);
+		for (int i = 1; i <= 5; ++i) {
+			sboxLayer(fwd); check();
+			mPrime(); shiftRows(false);
+			addConstant(RC[i]); addKey(k1);
+		}
+		sboxLayer(fwd); check();
+		mPrime();
+		sboxLayer(bwd); check();
+		for (int i = 6; i <= 10; ++i) {
+			addKey(k1); addConstant(RC[i]);
+			shiftRows(true); mPrime();
+			sboxLayer(bwd); check();
+		}
+		addConstant(RC[11]); addKey(k1);
+		// k0' = (k0 >>> 1) ^ (k0 >> 63), brought down to the final level
+		for (auto &k : k0) for (int l = 0; l < level; ++l) modSwitchCt(*k);
+		std::vector<Ct> k0p(64);
+		for (int i = 0; i < 64; ++i) { k0p[i].reset(new CuCtxt); copy(*k0p[i], *k0[(i + 63) % 64]); }
+		cXor(*k0p[63], *k0p[63], *k0[0]);
+		addKey(k0p);
+	}
+};
+
+int main(int argc, char **argv) {
+	const bool checkRounds = !(argc > 1 && std::string(argv[1]) == "--no-round-checks");
+	// the cipher itself, against the test vectors of the PRINCE paper (plaintext, k0, k1, ciphertext)
+	const u64x F = ~0ULL;
+	const u64x tv[5][4] = {{0, 0, 0, 0x818665aa0d02dfdaULL}, {F, 0, 0, 0x604ae6ca03c20adaULL}, {0, F, 0, 0x9fb51935fc3df524ULL},
+	                       {0, 0, F, 0x78a54cbe737bb7efULL}, {0x0123456789abcdefULL, 0, 0xfedcba9876543210ULL, 0xae25ad3ca8fa9ccfULL}};
+	for (auto &v : tv) if (plainPrince(v[0], v[1], v[2], NULL) != v[3]) { printf("plain PRINCE disagrees with a published test vector\n"); return 2; }
+	printf("plain PRINCE reproduces the 5 published test vectors\n");
+
+	const u64x pt = 0, key0 = F, key1 = 0;                  // the reference's run (Prince.cu:69-74)
+	const auto t0 = clk::now();
+	multiGPUs(1);
+	Dhs dhs;
+	dhs.setup(25, 2, 16, 25, 25, 21845);                    // Prince.cu:49
+	startAllocator();
+	const auto t1 = clk::now();
+	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d   key generation %.2f s\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey,
+	       std::chrono::duration<double>(t1 - t0).count());
+
+	Evaluator ev(dhs, checkRounds);
+	plainPrince(pt, key0, key1, &ev.expect);
+	std::vector<Ct> k0(64);
+	ev.state.resize(64); ev.k1.resize(64);
+	for (int i = 0; i < 64; ++i) {
+		ev.state[i] = Evaluator::upload(dhs.encryptBit((int)((pt >> (63 - i)) & 1), 0), 0);
+		k0[i] = Evaluator::upload(dhs.encryptBit((int)((key0 >> (63 - i)) & 1), 0), 0);
+		ev.k1[i] = Evaluator::upload(dhs.encryptBit((int)((key1 >> (63 - i)) & 1), 0), 0);
+	}
+	const auto t2 = clk::now();
+	printf("encrypted 192 bits in %.2f s\n", std::chrono::duration<double>(t2 - t1).count());
+
+	ev.encrypt(k0);
+	const auto t3 = clk::now();
+	const double encSeconds = std::chrono::duration<double>(t3 - t2).count() - ev.paused;
+
+	bool constant; const u64x got = ev.decryptState(constant);
+	const u64x want = plainPrince(pt, key0, key1, NULL);
+	printf("homomorphic PRINCE: %016llx   expected %016llx   %s\n", got, want, (constant && got == want && want == 0x9fb51935fc3df524ULL) ? "right" : "wrong");
+	if (!(constant && got == want && want == 0x9fb51935fc3df524ULL)) ++failures;
+	printf("circuit: %ld cAnd, %ld relin, %ld modSwitch, final level %d\n", numAnd, numRelin, numModSwitch, ev.level);
+	if (numAnd != 1920 || numRelin != 1152 || ev.level != 24) { printf("unexpected operation counts\n"); ++failures; }
+	printf("Prince Encryption: %.3f s on 1 GPU (round checks excluded)\n", encSeconds);
+	stopAllocator();
+	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
+	return failures ? 1 : 0;
+}

@@ -40,3 +40,23 @@ def test_dhs_scheme_flow(params):
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
+
+
+def test_prince_known_answer():
+    """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
+    reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
+    (Prince.cu:108-145) must decrypt bit for bit; 1920 cAnd / 1152 relin / depth 24 as in the reference's circuit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    import __graft_entry__ as ge
+    ge.build()
+    cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
+    subprocess.check_call(["make", "-C", cxx, "-s", "test"])
+    exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_flow")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
+    assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
+    assert r.stdout.count("right") == 13
