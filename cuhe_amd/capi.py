@@ -56,6 +56,8 @@ SIGNATURES = {
     "cuhe_hip_memcpy_d2h": (i32, [i32, vp, vp, sz, vp]),
     "cuhe_hip_memcpy_d2d": (i32, [i32, vp, vp, sz, vp]),
     "cuhe_hip_memcpy_peer": (i32, [vp, i32, vp, i32, sz, vp]),
+    "cuhe_hip_stream_create": (i32, [i32, vp]),
+    "cuhe_hip_stream_destroy": (i32, [i32, vp]),
     "cuhe_hip_stream_sync": (i32, [i32, vp]),
     "cuhe_hip_crt": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_icrt": (i32, [vp, vp, i32, i32, vp]),

@@ -48,8 +48,22 @@ int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------ state
 struct NttTab {
     u64 *T1 = nullptr, *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of the wave-split pass 1
-    u64 *scratch[2] = {nullptr, nullptr};      // two slabs: pass 2 of chunk c overlaps pass 1 of chunk c+1
-    int scratch_batch = 0;
+    int chunk = 0;                             // transforms per launch pair (slab size / transform size)
+};
+// Mutable scratch of ONE host thread on one device.  The reference keeps a single set per device and is therefore
+// not re-entrant per device (cuhe/Operations.cu:171-209, Relinearization.cu:37-38); here every host thread that
+// calls into the library gets its own set, so several threads can drive the same GPU on their own streams and the
+// small kernels of independent ciphertext operations overlap on the device.
+struct Workspace {
+    u64 *slab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // pass-1 -> pass-2 slabs per length
+    size_t slab_bytes[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    u64 *b_ntt = nullptr;                // Barrett scratch (cuhe/Operations.cu:196-209)
+    u32 *b_src = nullptr, *b_crt = nullptr;
+    u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
+    u64 *relin = nullptr;                // NTT-domain windows of the ciphertext being relinearised
+    u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows
+    hipStream_t last = nullptr; bool used = false;
+    hipEvent_t ev = nullptr;             // orders this thread's work when it moves to another stream
 };
 struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0; };
 
@@ -62,12 +76,11 @@ struct DevCtx {
     int maxW = 0;
     std::vector<IcrtLevel> icrt;
     // Barrett tables / scratch (cuhe/Operations.cu:193-209, Base.cu:181-223)
-    u64 *u_ntt = nullptr, *m_ntt = nullptr, *b_ntt = nullptr;
-    u32 *m_crt = nullptr, *b_src = nullptr, *b_crt = nullptr;
-    u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
+    u64 *u_ntt = nullptr, *m_ntt = nullptr;
+    u32 *m_crt = nullptr;
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
-    u64 *relin = nullptr, *ek = nullptr;
-    u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows of the ciphertext being relinearised
+    u64 *ek = nullptr;
+    std::vector<Workspace *> spaces;     // one per host thread that has used this device
     // allocator (cuhe/DeviceManager.cu:98-138)
     // helper streams/events for the pass-1 / pass-2 software pipeline
     hipStream_t s1 = nullptr, s2 = nullptr;
@@ -92,6 +105,7 @@ struct Global {
     bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
     std::mutex mu;
+    uint64_t generation = 1;      // bumped by shutdown: thread-local workspace pointers of older generations are stale
 } G_;
 
 inline int lg_index(int len) { return len == 16384 ? 0 : len == 32768 ? 1 : len == 65536 ? 2 : -1; }
@@ -102,6 +116,69 @@ int set_dev(int dev) {
     HIPCHK(hipSetDevice(G_.dev_base + dev));
     if ((int)G_.dev.size() < G_.ndev) G_.dev.resize(G_.ndev);
     return CUHE_OK;
+}
+
+// the calling thread's workspace on `dev`, ordered after whatever this thread last enqueued with it
+struct TlsSpaces { uint64_t gen = 0; std::vector<Workspace *> per_dev; };
+thread_local TlsSpaces tls_spaces;
+int workspace_of_thread(int dev, Workspace **out) {
+    TlsSpaces &T = tls_spaces;
+    if (T.gen != G_.generation) { T.per_dev.clear(); T.gen = G_.generation; }
+    if ((int)T.per_dev.size() <= dev) T.per_dev.resize(dev + 1, nullptr);
+    Workspace *w = T.per_dev[dev];
+    if (!w) {
+        w = new Workspace();
+        HIPCHK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
+        std::lock_guard<std::mutex> lk(G_.mu);
+        G_.dev[dev].spaces.push_back(w);
+        T.per_dev[dev] = w;
+    }
+    *out = w;
+    return CUHE_OK;
+}
+int workspace(int dev, hipStream_t st, Workspace **out) {
+    Workspace *w = nullptr;
+    CHK(workspace_of_thread(dev, &w));
+    if (w->used && w->last != st) {               // same thread, other stream: keep the scratch hazards ordered
+        HIPCHK(hipEventRecord(w->ev, w->last));
+        HIPCHK(hipStreamWaitEvent(st, w->ev, 0));
+    }
+    w->last = st; w->used = true;
+    *out = w;
+    return CUHE_OK;
+}
+template <typename T>
+int ws_buffer(T **ptr, size_t count) {           // lazily allocated, fixed-size workspace member
+    if (!*ptr) HIPCHK(hipMalloc((void **)ptr, std::max<size_t>(count, 1) * sizeof(T)));
+    return CUHE_OK;
+}
+int ws_barrett(Workspace &w) {
+    const Params &q = G_.prm;
+    const size_t rows = (size_t)q.numCrtPrime * q.nttLen;
+    CHK(ws_buffer(&w.b_src, rows)); CHK(ws_buffer(&w.b_crt, rows)); CHK(ws_buffer(&w.b_ntt, rows)); CHK(ws_buffer(&w.hold, rows));
+    return CUHE_OK;
+}
+int ws_relin(Workspace &w) {
+    const Params &q = G_.prm;
+    CHK(ws_buffer(&w.relin, (size_t)q.numEvalKey * q.nttLen)); CHK(ws_buffer(&w.win, (size_t)q.numEvalKey * q.crtLen));
+    return CUHE_OK;
+}
+int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        // grow-only
+    if (w.slab_bytes[li][which] < bytes) {
+        if (w.slab[li][which]) HIPCHK(hipFree(w.slab[li][which]));            // (synchronises: rare, sizes settle at once)
+        w.slab[li][which] = nullptr; w.slab_bytes[li][which] = 0;
+        HIPCHK(hipMalloc((void **)&w.slab[li][which], bytes));
+        w.slab_bytes[li][which] = bytes;
+    }
+    *out = w.slab[li][which];
+    return CUHE_OK;
+}
+void free_workspace(Workspace *w) {
+    for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
+    void *ptrs[] = {w->b_ntt, w->b_src, w->b_crt, w->hold, w->relin, w->win};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (w->ev) hipEventDestroy(w->ev);
+    delete w;
 }
 
 template <typename T>
@@ -143,8 +220,10 @@ int make_ntt_tables(NttTab &tab) {
 }
 
 int ensure_ntt(int dev, int len, int batch_hint) {
+    (void)batch_hint;
     const int li = lg_index(len);
     if (li < 0) return fail(CUHE_EINVAL, "unsupported transform length %d (16384/32768/65536 only)", len);
+    std::lock_guard<std::mutex> lk(G_.mu);
     NttTab &tab = G_.dev[dev].ntt[li];
     if (!tab.T1) {
         if (li == 0) CHK(make_ntt_tables<14>(tab));
@@ -154,15 +233,7 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     // transforms per launch pair: 128 MiB slabs by default (profiles/r01_chunk_sweep.txt)
     int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (128 << 20) / (len * 8);
     if (chunk < 8) chunk = 8;
-    chunk = (chunk + 7) & ~7;
-    int want = std::min(chunk, (std::max(batch_hint, 1) + 7) & ~7);
-    if (tab.scratch_batch < want) {
-        for (auto &sl : tab.scratch) {
-            if (sl) HIPCHK(hipFree(sl));
-            HIPCHK(hipMalloc((void **)&sl, (size_t)want * len * sizeof(u64)));
-        }
-        tab.scratch_batch = want;
-    }
+    tab.chunk = (chunk + 7) & ~7;
     DevCtx &D = G_.dev[dev];
     if (!D.s1) {
         HIPCHK(hipStreamCreateWithFlags(&D.s1, hipStreamNonBlocking));
@@ -238,14 +309,18 @@ struct EvTimer {                 // optional per-pass hipEvent timing (bench)
 // one batched transform, chunked so that the pass-1 -> pass-2 slab stays cache resident
 template <int LG>
 int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-               int prime0, WindowArgs wa, DevCtx &D, hipStream_t st, EvTimer *tm) {
+               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm) {
     constexpr int L = 1 << LG;
     NttTab &tab = D.ntt[LG - 14];
-    const int chunk = tab.scratch_batch;
+    const int chunk = tab.chunk;
     // Two-stage software pipeline over chunks: pass 1 (VALU/LDS bound) of chunk c+1 runs on stream s1 while
     // pass 2 (load/store heavy, 1 wave/SIMD fits beside pass 1's 2) of chunk c runs on s2.
     const bool pipe = G_.ntt_overlap && !(tm && tm->on) && batch > chunk;
     hipStream_t q1 = pipe ? D.s1 : st, q2 = pipe ? D.s2 : st;
+    const size_t slab_bytes = (size_t)((std::min(chunk, batch) + 7) & ~7) * L * sizeof(u64);
+    u64 *slabs[2] = {nullptr, nullptr};
+    CHK(ws_slab(W, LG - 14, 0, slab_bytes, &slabs[0]));
+    if (pipe) CHK(ws_slab(W, LG - 14, 1, slab_bytes, &slabs[1]));
     if (pipe) {
         HIPCHK(hipEventRecord(D.ev_start, st));
         HIPCHK(hipStreamWaitEvent(D.s1, D.ev_start, 0));
@@ -255,7 +330,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
     for (int b0 = 0; b0 < batch; b0 += chunk, ++c) {
         const int nb = std::min(chunk, batch - b0);
         const int sl = pipe ? (c & 1) : 0;
-        u64 *slab = tab.scratch[sl];
+        u64 *slab = slabs[sl];
         if (pipe && c >= 2) HIPCHK(hipStreamWaitEvent(q1, D.ev_p2[sl], 0));       // slab free again
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU32Ext) {
@@ -290,10 +365,12 @@ int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_s
     if (batch <= 0) return CUHE_OK;
     CHK(ensure_ntt(dev, len, batch));
     DevCtx &D = G_.dev[dev];
+    Workspace *W = nullptr;
+    CHK(workspace(dev, st, &W));
     switch (len) {
-        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, st, tm);
-        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, st, tm);
-        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, st, tm);
+        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm);
+        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm);
+        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm);
     }
 }
 
@@ -344,18 +421,22 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
     const u64 *u_ntt = D.u_ntt + (size_t)prime0 * L, *m_ntt = D.m_ntt + (size_t)prime0 * L;
     const u32 *m_crt = D.m_crt + (size_t)prime0 * cl;
     WindowArgs wa{0, 0, 0};
-    if (src != D.b_src) HIPCHK(hipMemcpyAsync(D.b_src, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
-    CHK(run_ntt(L, kSrcU32Ext, D.b_ntt, D.b_src + (n - 1), np, L, L, L, 0, wa, dev, st));            // f >> (n-1)
-    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, u_ntt, pairs);
-    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // u * (f>>(n-1))
-    hipLaunchKernelGGL(k_zero_rows, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_crt, n, L);
-    CHK(run_ntt(L, kSrcU32Ext, D.b_ntt, D.b_crt + n, np, L, L, L, 0, wa, dev, st));                  // q = (..)>>n
-    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, D.b_ntt, D.b_ntt, m_ntt, pairs);
-    hipLaunchKernelGGL(k_barrett_sub, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, D.b_crt, pt, n, n, L);
-    CHK(run_ntt(L, kSrcU64Neg, D.b_crt, D.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // (m - x^n) * q
-    hipLaunchKernelGGL(k_barrett_sub, dim3((L + 255) / 256, np), dim3(256), 0, st, D.b_src, D.b_crt, pt, 0, L, L);
-    hipLaunchKernelGGL(k_barrett_sub_mc, dim3((n + 255) / 256, np), dim3(256), 0, st, D.b_src, m_crt, pt, n, cl, L);
-    hipLaunchKernelGGL(k_gather_rows, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, D.b_src, cl, L);
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, st, &Wp));
+    CHK(ws_barrett(*Wp));
+    Workspace &Ws = *Wp;
+    if (src != Ws.b_src) HIPCHK(hipMemcpyAsync(Ws.b_src, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_src + (n - 1), np, L, L, L, 0, wa, dev, st));            // f >> (n-1)
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, u_ntt, pairs);
+    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // u * (f>>(n-1))
+    hipLaunchKernelGGL(k_zero_rows, dim3((n + 255) / 256, np), dim3(256), 0, st, Ws.b_crt, n, L);
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st));                  // q = (..)>>n
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, m_ntt, pairs);
+    hipLaunchKernelGGL(k_barrett_sub, dim3((n + 255) / 256, np), dim3(256), 0, st, Ws.b_src, Ws.b_crt, pt, n, n, L);
+    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // (m - x^n) * q
+    hipLaunchKernelGGL(k_barrett_sub, dim3((L + 255) / 256, np), dim3(256), 0, st, Ws.b_src, Ws.b_crt, pt, 0, L, L);
+    hipLaunchKernelGGL(k_barrett_sub_mc, dim3((n + 255) / 256, np), dim3(256), 0, st, Ws.b_src, m_crt, pt, n, cl, L);
+    hipLaunchKernelGGL(k_gather_rows, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, Ws.b_src, cl, L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -399,11 +480,7 @@ int init_device(int dev) {
     }
     // ---- transforms + scratch (initNtt: cuhe/Operations.cu:173-184)
     CHK(ensure_ntt(dev, L, pnum));
-    HIPCHK(hipMalloc((void **)&D.hold, (size_t)pnum * L * sizeof(u32)));
     // ---- Barrett (initBarrett: cuhe/Operations.cu:196-238)
-    HIPCHK(hipMalloc((void **)&D.b_src, (size_t)pnum * L * sizeof(u32)));
-    HIPCHK(hipMalloc((void **)&D.b_crt, (size_t)pnum * L * sizeof(u32)));
-    HIPCHK(hipMalloc((void **)&D.b_ntt, (size_t)pnum * L * sizeof(u64)));
     HIPCHK(hipMalloc((void **)&D.u_ntt, (size_t)pnum * L * sizeof(u64)));
     HIPCHK(hipMalloc((void **)&D.m_ntt, (size_t)pnum * L * sizeof(u64)));
     std::vector<long long> u;
@@ -548,10 +625,10 @@ int cuhe_hip_shutdown(void) {
     for (int d = 0; d < (int)G_.dev.size(); ++d) {
         hipSetDevice(G_.dev_base + d);
         DevCtx &D = G_.dev[d];
-        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.scratch[0]); hipFree(t.scratch[1]); t = NttTab(); }
+        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
-        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.b_ntt, D.m_crt, D.b_src, D.b_crt,
-                        D.hold, D.relin, D.ek, D.win};
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.m_crt, D.ek};
+        for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);
         for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
         for (auto &kv : D.freeBlocks) hipFree(kv.second);
@@ -559,6 +636,7 @@ int cuhe_hip_shutdown(void) {
         D = DevCtx();
     }
     G_.inited = false; G_.relin_ready = false; G_.allocator_on = false;
+    ++G_.generation;
     return CUHE_OK;
 }
 
@@ -649,6 +727,14 @@ int cuhe_hip_memcpy_peer(void *d, int dd, const void *s, int sd, size_t n, void 
     HIPCHK(hipMemcpyPeerAsync(d, G_.dev_base + dd, s, G_.dev_base + sd, n, S(st)));
     return CUHE_OK;
 }
+int cuhe_hip_stream_create(int dev, void **out) {
+    CHK(set_dev(dev));
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void *)s;
+    return CUHE_OK;
+}
+int cuhe_hip_stream_destroy(int dev, void *st) { CHK(set_dev(dev)); if (st) HIPCHK(hipStreamDestroy(S(st))); return CUHE_OK; }
 int cuhe_hip_stream_sync(int dev, void *st) { CHK(set_dev(dev)); HIPCHK(hipStreamSynchronize(S(st))); return CUHE_OK; }
 
 // ---------------------------------------------------------------- drivers
@@ -756,7 +842,10 @@ int cuhe_hip_intt_hold(const uint64_t *X, int logq, int dev, void *st) {
     CHK(need_init(dev));
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
-    return run_ntt(q.nttLen, kSrcU64Neg, G_.dev[dev].hold, X, np, q.nttLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0},
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, S(st), &Wp));
+    CHK(ws_barrett(*Wp));
+    return run_ntt(q.nttLen, kSrcU64Neg, Wp->hold, X, np, q.nttLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0},
                    dev, S(st));
 }
 int cuhe_hip_intt_double_deg(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
@@ -772,7 +861,10 @@ int cuhe_hip_barrett(uint32_t *dst, const uint32_t *src, int lvl, int dev, void 
 }
 int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *st) {
     CHK(need_init(dev));
-    return cuhe_hip_barrett(dst, G_.dev[dev].hold, lvl, dev, st);
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, S(st), &Wp));
+    CHK(ws_barrett(*Wp));
+    return cuhe_hip_barrett(dst, Wp->hold, lvl, dev, st);
 }
 static bool fused_xn1() {
     return !G_.force_generic && G_.reduce_kind == 1 && G_.prm.modLen * 2 == G_.prm.nttLen && G_.prm.crtLen == G_.prm.modLen;
@@ -788,11 +880,15 @@ int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *s
     CHK(cuhe_hip_intt_hold(X, logq, dev, st));
     int lvl = G_.prm.getLevel(logq);
     if (lvl < 0) return fail(CUHE_EINVAL, "inttMod below level 0");
-    return barrett_impl(x, G_.dev[dev].hold, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st));
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, S(st), &Wp));
+    return barrett_impl(x, Wp->hold, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st));
 }
 uint32_t *cuhe_hip_intt_result(int dev) {
-    if (!G_.inited || dev < 0 || dev >= (int)G_.dev.size()) return nullptr;
-    return G_.dev[dev].hold;
+    if (!G_.inited || dev < 0 || dev >= (int)G_.dev.size() || set_dev(dev) != CUHE_OK) return nullptr;
+    Workspace *Wp = nullptr;                      // the CALLING thread's buffer (every host thread has its own)
+    if (workspace_of_thread(dev, &Wp) != CUHE_OK || ws_barrett(*Wp) != CUHE_OK) return nullptr;
+    return Wp->hold;
 }
 
 static int binop(bool mul, bool nx1, uint64_t *z, const uint64_t *x, const uint64_t *y, int logq, int dev, void *st) {
@@ -846,11 +942,7 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
         CHK(set_dev(dev));
         DevCtx &D = G_.dev[dev];
         if (D.ek) { hipFree(D.ek); D.ek = nullptr; }
-        if (D.relin) { hipFree(D.relin); D.relin = nullptr; }
         HIPCHK(hipMalloc((void **)&D.ek, (size_t)np * K * L * sizeof(u64)));
-        HIPCHK(hipMalloc((void **)&D.relin, (size_t)K * L * sizeof(u64)));
-        if (D.win) { hipFree(D.win); D.win = nullptr; }
-        HIPCHK(hipMalloc((void **)&D.win, (size_t)K * q.crtLen * sizeof(u32)));
         u32 *raw = nullptr, *crt = nullptr; u64 *ntt = nullptr;
         HIPCHK(hipMalloc((void **)&raw, rawBytes));
         HIPCHK(hipMalloc((void **)&crt, (size_t)np * q.crtLen * 4));
@@ -936,8 +1028,6 @@ int cuhe_hip_relin_import(const void *src, size_t bytes) {
         CHK(set_dev(dev));
         DevCtx &D = G_.dev[dev];
         if (!D.ek) HIPCHK(hipMalloc((void **)&D.ek, h.payload_bytes));
-        if (!D.relin) HIPCHK(hipMalloc((void **)&D.relin, (size_t)q.numEvalKey * q.nttLen * sizeof(u64)));
-        if (!D.win) HIPCHK(hipMalloc((void **)&D.win, (size_t)q.numEvalKey * q.crtLen * sizeof(u32)));
         HIPCHK(hipMemcpy(D.ek, payload, h.payload_bytes, hipMemcpyHostToDevice));
     }
     G_.relin_ready = true;
@@ -951,14 +1041,17 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = q.nttLen;
     if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d) at level %d", prime0, prime0 + count, lvl);
     DevCtx &D = G_.dev[dev];
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, S(st), &Wp));
+    CHK(ws_relin(*Wp));
     // window rows once (coalesced), then k plain zero-padded transforms (replaces k strided window loads)
     const int W = q.wordsCoeff(lvl);
     hipLaunchKernelGGL(k_extract_windows, dim3((q.crtLen + kWinCoef - 1) / kWinCoef), dim3(kWinCoef * kWinGroups),
-                       (size_t)W * kWinCoef * 4, S(st), D.win, src, W, q.logRelin, k, q.crtLen, q.crtLen);
+                       (size_t)W * kWinCoef * 4, S(st), Wp->win, src, W, q.logRelin, k, q.crtLen, q.crtLen);
     HIPCHK(hipGetLastError());
-    CHK(run_ntt(L, kSrcU32Ext, D.relin, D.win, k, q.crtLen, L, L, 0, WindowArgs{0, 0, 0}, dev, S(st)));
+    CHK(run_ntt(L, kSrcU32Ext, Wp->relin, Wp->win, k, q.crtLen, L, L, 0, WindowArgs{0, 0, 0}, dev, S(st)));
     constexpr int PB = 4;
-    hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (count + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, D.relin,
+    hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (count + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
                        D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
@@ -992,8 +1085,11 @@ int cuhe_hip_intt_mod_range(uint32_t *x, const uint64_t *X, int lvl, int prime0,
     DevCtx &D = G_.dev[dev];
     if (fused_xn1())
         return run_ntt(q.nttLen, kSrcU64Neg, x, X, count, q.nttLen, q.crtLen, kFoldXn1, prime0, WindowArgs{0, 0, 0}, dev, S(st));
-    CHK(run_ntt(q.nttLen, kSrcU64Neg, D.hold, X, count, q.nttLen, q.nttLen, q.nttLen, prime0, WindowArgs{0, 0, 0}, dev, S(st)));
-    return barrett_impl(x, D.hold, prime0, count, dev, S(st));
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, S(st), &Wp));
+    CHK(ws_barrett(*Wp));
+    CHK(run_ntt(q.nttLen, kSrcU64Neg, Wp->hold, X, count, q.nttLen, q.nttLen, q.nttLen, prime0, WindowArgs{0, 0, 0}, dev, S(st)));
+    return barrett_impl(x, Wp->hold, prime0, count, dev, S(st));
 }
 int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0, int count, int dev, void *st) {
     CHK(need_init(dev));
@@ -1014,7 +1110,6 @@ int cuhe_hip_ntt_prepare(int len, int dev) {
 }
 int cuhe_hip_set_ntt_chunk(int chunk) {
     G_.ntt_chunk = chunk;
-    for (auto &D : G_.dev) for (auto &t : D.ntt) for (auto &sl : t.scratch) if (sl) { hipFree(sl); sl = nullptr; t.scratch_batch = 0; }
     return CUHE_OK;
 }
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }

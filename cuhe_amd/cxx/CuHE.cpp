@@ -369,7 +369,7 @@ size_t CuCtxt::cRepSize() { return (size_t)param._numCrtPrime(level_) * param.cr
 size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * param.nttLen * sizeof(uint64); }
 void CuCtxt::modSwitch(cudaStream_t st) {
 	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
-	x2c();
+	x2c(st);
 	crtModSwitch(cRep_, cRep_, logq_, device_, st);
 	CSC(cuhe_hip_stream_sync(device_, st));
 	logq_ -= param.logCoeffCut;
@@ -380,14 +380,14 @@ void CuCtxt::modSwitch(int lvl, cudaStream_t st) {
 	while (level_ < lvl) modSwitch(st);       // (the reference's loop never advances level_: SURVEY A.7)
 }
 void CuCtxt::relin(cudaStream_t st) {
-	x2r();
+	x2r(st);
 	nRepCreate(st);
 	relinearization(nRep_, rRep_, level_, device_, st);
 	CSC(cuhe_hip_stream_sync(device_, st));
 	rRepFree();
 	isProd_ = true;
 	domain_ = 3;
-	n2c();
+	n2c(st);
 	CSC(cuhe_hip_stream_sync(device_, st));
 }
 void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {

@@ -97,6 +97,11 @@ int cuhe_hip_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes, void 
 int cuhe_hip_memcpy_d2d(int dev, void *dst, const void *src, size_t bytes, void *stream);
 /* moveTo / copyTo transport (cuhe/CuHE.cu:217-256: cudaMemcpyPeerAsync) */
 int cuhe_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, void *stream);
+/* Streams for callers without HIP headers (the C++ layer's cudaStream_t is this void*).  The library is re-entrant
+   per host thread: each thread owns its scratch on every device, so T threads with T streams keep T independent
+   ciphertext operations in flight on one GPU (the reference has one scratch set per device, Operations.cu:171-209). */
+int cuhe_hip_stream_create(int dev, void **stream_out);
+int cuhe_hip_stream_destroy(int dev, void *stream);
 int cuhe_hip_stream_sync(int dev, void *stream);
 
 /* ---- operation drivers (cuhe/Operations.h:60-108), same argument order */

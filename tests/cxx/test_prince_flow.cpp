@@ -14,10 +14,19 @@
 // Unlike the reference, the 64 state ciphertexts stay resident on the GPU between layers (the linear layers are
 // cXor / cNot on CRT-domain ciphertexts instead of host ZZX additions).
 //
-// usage: test_prince_flow [--no-round-checks]
+// The 16 S-boxes of a layer (and the 64 bits of a linear layer) are independent; the reference spreads them over
+// GPUs with one OpenMP thread per device (Prince.cu:194-200).  Here T host threads, each with its own stream, share
+// ONE GPU: the library keeps its scratch per host thread, so the small kernels of independent ciphertext operations
+// overlap on the device.  T = 1 is the reference's single-device behaviour (default stream, no threads).
+//
+// usage: test_prince_flow [--no-round-checks] [--threads T]
 #include "dhs_client.hpp"
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 using namespace cuHE;
 using dhs_client::Dhs;
@@ -88,48 +97,89 @@ static Anf anfOf(const int *box) {
 	return f;
 }
 
+// ------------------------------------------------------------------ T persistent host threads, one stream each
+struct Pool {
+	typedef std::function<void(int, cudaStream_t)> Job;
+	int T;
+	std::vector<std::thread> threads;
+	std::vector<void *> streams;
+	std::mutex m;
+	std::condition_variable cvStart, cvDone;
+	Job job; int count = 0, gen = 0, running = 0; bool stop = false;
+	std::atomic<int> next{0};
+	explicit Pool(int t) : T(t) {
+		if (T <= 1) return;
+		streams.resize(T, NULL);
+		for (int i = 0; i < T; ++i) if (cuhe_hip_stream_create(0, &streams[i]) != 0) { printf("cannot create a stream\n"); exit(2); }
+		for (int i = 0; i < T; ++i) threads.emplace_back([this, i] { worker(i); });
+	}
+	~Pool() {
+		if (T <= 1) return;
+		{ std::lock_guard<std::mutex> lk(m); stop = true; }
+		cvStart.notify_all();
+		for (auto &t : threads) t.join();
+		for (void *s : streams) cuhe_hip_stream_destroy(0, s);
+	}
+	void worker(int t) {
+		int seen = 0;
+		for (;;) {
+			{ std::unique_lock<std::mutex> lk(m); cvStart.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+			for (int i; (i = next.fetch_add(1)) < count;) job(i, (cudaStream_t)streams[t]);
+			{ std::lock_guard<std::mutex> lk(m); if (--running == 0) cvDone.notify_one(); }
+		}
+	}
+	// job(i, stream) for i in [0, n), on the pool's threads (inline on the default stream when T = 1)
+	void run(int n, Job f) {
+		if (T <= 1) { for (int i = 0; i < n; ++i) f(i, (cudaStream_t)0); return; }
+		{ std::lock_guard<std::mutex> lk(m); job = f; count = n; next = 0; running = T; ++gen; }
+		cvStart.notify_all();
+		std::unique_lock<std::mutex> lk(m);
+		cvDone.wait(lk, [&] { return running == 0; });
+	}
+};
+
 // ------------------------------------------------------------------ homomorphic evaluation
 typedef std::unique_ptr<CuCtxt> Ct;
 static int failures = 0;
-static long numAnd = 0, numRelin = 0, numModSwitch = 0;
+static std::atomic<long> numAnd{0}, numRelin{0}, numModSwitch{0};
 
-static void accumulate(CuCtxt &out, bool &has, CuCtxt &term) {
-	if (!has) { copy(out, term); has = true; } else cXor(out, out, term);
+static void accumulate(CuCtxt &out, bool &has, CuCtxt &term, cudaStream_t st) {
+	if (!has) { copy(out, term, st); has = true; } else cXor(out, out, term, st);
 }
-static void relinCt(CuCtxt &x) { x.relin(); ++numRelin; }
-static void modSwitchCt(CuCtxt &x) { x.modSwitch(); ++numModSwitch; }
+static void relinCt(CuCtxt &x, cudaStream_t st) { x.relin(st); ++numRelin; }
+static void modSwitchCt(CuCtxt &x, cudaStream_t st) { x.modSwitch(st); ++numModSwitch; }
 
 // one S-box on the nibble (s[0..3] = a..d, CRT domain, level L) -> four outputs at level L + 2
-static void sboxNibble(Ct s[4], const Anf &f) {
+static void sboxNibble(Ct s[4], const Anf &f, cudaStream_t st) {
 	CuCtxt &a = *s[0], &b = *s[1], &c = *s[2], &d = *s[3];
-	a.x2n(); b.x2n(); c.x2n(); d.x2n();
+	a.x2n(st); b.x2n(st); c.x2n(st); d.x2n(st);
 	CuCtxt ab, ac, ad, bc, bd, cd;
-	cAnd(ab, a, b); cAnd(ac, a, c); cAnd(ad, a, d); cAnd(bc, b, c); cAnd(bd, b, d); cAnd(cd, c, d);
+	cAnd(ab, a, b, st); cAnd(ac, a, c, st); cAnd(ad, a, d, st); cAnd(bc, b, c, st); cAnd(bd, b, d, st); cAnd(cd, c, d, st);
 	numAnd += 6;
-	relinCt(ab); relinCt(cd);
+	relinCt(ab, st); relinCt(cd, st);
 	CuCtxt *lvl1[10] = {&ab, &ac, &ad, &bc, &bd, &cd, &a, &b, &c, &d};
-	for (CuCtxt *x : lvl1) modSwitchCt(*x);
+	for (CuCtxt *x : lvl1) modSwitchCt(*x, st);
 	// linear and quadratic monomials (all in the CRT domain at level L + 1)
 	struct Term { int mask; CuCtxt *ct; };
 	const Term low[10] = {{8, &a}, {4, &b}, {2, &c}, {1, &d}, {12, &ab}, {10, &ac}, {9, &ad}, {6, &bc}, {5, &bd}, {3, &cd}};
 	Ct out[4]; bool has[4] = {false, false, false, false};
 	for (int o = 0; o < 4; ++o) {
 		out[o].reset(new CuCtxt);
-		for (const Term &t : low) if (f.c[o][t.mask]) accumulate(*out[o], has[o], *t.ct);
+		for (const Term &t : low) if (f.c[o][t.mask]) accumulate(*out[o], has[o], *t.ct, st);
 	}
 	// cubic monomials from the two relinearised pairs
-	a.x2n(); b.x2n(); c.x2n(); d.x2n(); ab.x2n(); cd.x2n();
+	a.x2n(st); b.x2n(st); c.x2n(st); d.x2n(st); ab.x2n(st); cd.x2n(st);
 	CuCtxt abd, acd, bcd, abc;
-	cAnd(abd, ab, d); cAnd(acd, cd, a); cAnd(bcd, cd, b); cAnd(abc, ab, c);
+	cAnd(abd, ab, d, st); cAnd(acd, cd, a, st); cAnd(bcd, cd, b, st); cAnd(abc, ab, c, st);
 	numAnd += 4;
-	abd.x2c(); acd.x2c(); bcd.x2c(); abc.x2c();
+	abd.x2c(st); acd.x2c(st); bcd.x2c(st); abc.x2c(st);
 	const Term high[4] = {{13, &abd}, {11, &acd}, {7, &bcd}, {14, &abc}};
 	for (int o = 0; o < 4; ++o) {
-		for (const Term &t : high) if (f.c[o][t.mask]) accumulate(*out[o], has[o], *t.ct);
+		for (const Term &t : high) if (f.c[o][t.mask]) accumulate(*out[o], has[o], *t.ct, st);
 		if (f.c[o][15] || !has[o]) { printf("unexpected S-box structure\n"); exit(2); }
-		if (f.c[o][0]) cNot(*out[o], *out[o]);
-		relinCt(*out[o]);
-		modSwitchCt(*out[o]);
+		if (f.c[o][0]) cNot(*out[o], *out[o], st);
+		relinCt(*out[o], st);
+		modSwitchCt(*out[o], st);
 	}
 	for (int o = 0; o < 4; ++o) s[o] = std::move(out[o]);
 }
@@ -142,7 +192,8 @@ struct Evaluator {
 	double paused = 0;                              // seconds spent in round checks (excluded from the timing)
 	std::vector<u64x> expect;
 	int layer = 0;
-	Evaluator(Dhs &d, bool chk) : dhs(d), checkRounds(chk) {}
+	Pool &pool;
+	Evaluator(Dhs &d, bool chk, Pool &p) : dhs(d), checkRounds(chk), pool(p) {}
 
 	static Ct upload(const ZZX &c, int lvl) { Ct x(new CuCtxt); x->setLevel(lvl, 0, c); x->x2c(); return x; }
 	int decryptBit(CuCtxt &x, int lvl, bool &constant) {
@@ -167,16 +218,16 @@ struct Evaluator {
 		}
 		++layer;
 	}
-	void addConstant(u64x rc) { for (int i = 0; i < 64; ++i) if ((rc >> (63 - i)) & 1) cNot(*state[i], *state[i]); }
-	void addKey(std::vector<Ct> &k) { for (int i = 0; i < 64; ++i) cXor(*state[i], *state[i], *k[i]); }
+	void addConstant(u64x rc) { pool.run(64, [&](int i, cudaStream_t st) { if ((rc >> (63 - i)) & 1) cNot(*state[i], *state[i], st); }); }
+	void addKey(std::vector<Ct> &k) { pool.run(64, [&](int i, cudaStream_t st) { cXor(*state[i], *state[i], *k[i], st); }); }
 	void mPrime() {
 		static const auto src = mPrimeSources();
 		std::vector<Ct> next(64);
-		for (int i = 0; i < 64; ++i) {
+		pool.run(64, [&](int i, cudaStream_t st) {
 			next[i].reset(new CuCtxt);
-			copy(*next[i], *state[src[i][0]]);
-			for (size_t k = 1; k < src[i].size(); ++k) cXor(*next[i], *next[i], *state[src[i][k]]);
-		}
+			copy(*next[i], *state[src[i][0]], st);
+			for (size_t k = 1; k < src[i].size(); ++k) cXor(*next[i], *next[i], *state[src[i][k]], st);
+		});
 		state.swap(next);
 	}
 	void shiftRows(bool inverse) {
@@ -188,9 +239,9 @@ struct Evaluator {
 		state.swap(next);
 	}
 	void sboxLayer(const Anf &f) {
-		for (int i = 0; i < 16; ++i) sboxNibble(&state[4 * i], f);
+		pool.run(16, [&](int i, cudaStream_t st) { sboxNibble(&state[4 * i], f, st); });
 		level += 2;
-		for (auto &k : k1) { modSwitchCt(*k); modSwitchCt(*k); }
+		pool.run(64, [&](int i, cudaStream_t st) { modSwitchCt(*k1[i], st); modSwitchCt(*k1[i], st); });
 	}
 	void encrypt(std::vector<Ct> &k0) {
 		int inv[16]; for (int i = 0; i < 16; ++i) inv[SBOX[i]] = i;
@@ -211,16 +262,20 @@ struct Evaluator {
 		}
 		addConstant(RC[11]); addKey(k1);
 		// k0' = (k0 >>> 1) ^ (k0 >> 63), brought down to the final level
-		for (auto &k : k0) for (int l = 0; l < level; ++l) modSwitchCt(*k);
+		pool.run(64, [&](int i, cudaStream_t st) { for (int l = 0; l < level; ++l) modSwitchCt(*k0[i], st); });
 		std::vector<Ct> k0p(64);
-		for (int i = 0; i < 64; ++i) { k0p[i].reset(new CuCtxt); copy(*k0p[i], *k0[(i + 63) % 64]); }
+		pool.run(64, [&](int i, cudaStream_t st) { k0p[i].reset(new CuCtxt); copy(*k0p[i], *k0[(i + 63) % 64], st); });
 		cXor(*k0p[63], *k0p[63], *k0[0]);
 		addKey(k0p);
 	}
 };
 
 int main(int argc, char **argv) {
-	const bool checkRounds = !(argc > 1 && std::string(argv[1]) == "--no-round-checks");
+	bool checkRounds = true; int threads = 8;
+	for (int i = 1; i < argc; ++i) {
+		if (std::string(argv[i]) == "--no-round-checks") checkRounds = false;
+		else if (std::string(argv[i]) == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
+	}
 	// the cipher itself, against the test vectors of the PRINCE paper (plaintext, k0, k1, ciphertext)
 	const u64x F = ~0ULL;
 	const u64x tv[5][4] = {{0, 0, 0, 0x818665aa0d02dfdaULL}, {F, 0, 0, 0x604ae6ca03c20adaULL}, {0, F, 0, 0x9fb51935fc3df524ULL},
@@ -238,7 +293,8 @@ int main(int argc, char **argv) {
 	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d   key generation %.2f s\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey,
 	       std::chrono::duration<double>(t1 - t0).count());
 
-	Evaluator ev(dhs, checkRounds);
+	Pool pool(threads);
+	Evaluator ev(dhs, checkRounds, pool);
 	plainPrince(pt, key0, key1, &ev.expect);
 	std::vector<Ct> k0(64);
 	ev.state.resize(64); ev.k1.resize(64);
@@ -258,9 +314,9 @@ int main(int argc, char **argv) {
 	const u64x want = plainPrince(pt, key0, key1, NULL);
 	printf("homomorphic PRINCE: %016llx   expected %016llx   %s\n", got, want, (constant && got == want && want == 0x9fb51935fc3df524ULL) ? "right" : "wrong");
 	if (!(constant && got == want && want == 0x9fb51935fc3df524ULL)) ++failures;
-	printf("circuit: %ld cAnd, %ld relin, %ld modSwitch, final level %d\n", numAnd, numRelin, numModSwitch, ev.level);
+	printf("circuit: %ld cAnd, %ld relin, %ld modSwitch, final level %d\n", numAnd.load(), numRelin.load(), numModSwitch.load(), ev.level);
 	if (numAnd != 1920 || numRelin != 1152 || ev.level != 24) { printf("unexpected operation counts\n"); ++failures; }
-	printf("Prince Encryption: %.3f s on 1 GPU (round checks excluded)\n", encSeconds);
+	printf("Prince Encryption: %.3f s on 1 GPU with %d host thread(s) (round checks excluded)\n", encSeconds, threads);
 	stopAllocator();
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;
