@@ -542,3 +542,66 @@ def test_evalkey_cache_roundtrip(gu):
         assert gu.lib.cuhe_hip_relin_import(img.ctypes.data_as(ctypes.c_void_p), size) != 0
     finally:
         g.close(); o.close()
+
+
+def test_reentrant_host_threads(gu):
+    """Several host threads drive ONE GPU through the C ABI at the same time, each on its own stream
+    (cuhe_hip_stream_create): the library keeps its scratch per host thread (the reference has one set per device and is
+    not re-entrant, cuhe/Operations.cu:171-209).  Every thread runs the mul + relin chain (generic Barrett reduction,
+    window transforms, key-switch inner product) on its own operands; all results must equal the oracle's."""
+    import ctypes
+    import threading
+    import torch
+    import oracle_lib as O
+    args = (3, 2, 8, 40, 20, 1155)                # toy ring: generic NTT-Barrett path, 16K-point transforms
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE100 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        g.init_relin(ek_raw)
+        T, REPS, lvl = 6, 4, 0
+        logq, npr = o.logq(lvl), o.np_(lvl)
+        ins = [[(_rand_crt(o, npr, 1000 + 10 * t + r), _rand_crt(o, npr, 2000 + 10 * t + r)) for r in range(REPS)] for t in range(T)]
+        want = [[o.mul_relin_crt(a, b, lvl, ek) for a, b in ins[t]] for t in range(T)]
+        # device buffers are prepared up front on torch's stream; the threads only call the C ABI
+        bufs = []
+        for t in range(T):
+            per = []
+            for a, b in ins[t]:
+                per.append(dict(ca=gu.to_dev(a), cb=gu.to_dev(b), na=gu.empty_u64(npr, q.nttLen), nb=gu.empty_u64(npr, q.nttLen),
+                                cr=gu.empty_u32(npr, q.crtLen), raw=gu.empty_u32(q.rawLen, o.words(lvl))))
+            bufs.append(per)
+        torch.cuda.synchronize()
+        errors = []
+        barrier = threading.Barrier(T)
+
+        def work(t):
+            try:
+                st = ctypes.c_void_p()
+                gu.ck(gu.lib.cuhe_hip_stream_create(0, ctypes.byref(st)))
+                barrier.wait()
+                for d in bufs[t]:
+                    L = gu.lib
+                    gu.ck(L.cuhe_hip_ntt(d["na"].data_ptr(), d["ca"].data_ptr(), logq, 0, st))
+                    gu.ck(L.cuhe_hip_ntt(d["nb"].data_ptr(), d["cb"].data_ptr(), logq, 0, st))
+                    gu.ck(L.cuhe_hip_ntt_mul(d["na"].data_ptr(), d["na"].data_ptr(), d["nb"].data_ptr(), logq, 0, st))
+                    gu.ck(L.cuhe_hip_intt_mod(d["cr"].data_ptr(), d["na"].data_ptr(), logq, 0, st))
+                    gu.ck(L.cuhe_hip_icrt(d["raw"].data_ptr(), d["cr"].data_ptr(), logq, 0, st))
+                    gu.ck(L.cuhe_hip_relinearization(d["na"].data_ptr(), d["raw"].data_ptr(), lvl, 0, st))
+                    gu.ck(L.cuhe_hip_intt_mod(d["cr"].data_ptr(), d["na"].data_ptr(), logq, 0, st))
+                gu.ck(gu.lib.cuhe_hip_stream_sync(0, st))
+                gu.ck(gu.lib.cuhe_hip_stream_destroy(0, st))
+            except Exception as e:                      # surfaced in the main thread
+                errors.append((t, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        for th in threads: th.start()
+        for th in threads: th.join()
+        assert not errors, errors
+        for t in range(T):
+            for r in range(REPS):
+                assert np.array_equal(gu.host_u32(bufs[t][r]["cr"]), want[t][r]), (t, r)
+    finally:
+        g.close(); o.close()
