@@ -80,7 +80,8 @@ struct DevCtx {
     u32 *m_crt = nullptr;
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *ek = nullptr;
-    std::vector<Workspace *> spaces;     // one per host thread that has used this device
+    std::vector<Workspace *> spaces;     // every workspace of this device (owned here)
+    std::vector<Workspace *> idle;       // workspaces of finished threads, adopted by later ones
     // allocator (cuhe/DeviceManager.cu:98-138)
     // helper streams/events for the pass-1 / pass-2 software pipeline
     hipStream_t s1 = nullptr, s2 = nullptr;
@@ -119,7 +120,17 @@ int set_dev(int dev) {
 }
 
 // the calling thread's workspace on `dev`, ordered after whatever this thread last enqueued with it
-struct TlsSpaces { uint64_t gen = 0; std::vector<Workspace *> per_dev; };
+struct TlsSpaces {
+    uint64_t gen = 0;
+    std::vector<Workspace *> per_dev;
+    ~TlsSpaces();                                 // a finished thread hands its workspaces to later threads
+};
+TlsSpaces::~TlsSpaces() {
+    std::lock_guard<std::mutex> lk(G_.mu);
+    if (gen != G_.generation) return;             // the library was shut down since: already freed
+    for (size_t d = 0; d < per_dev.size() && d < G_.dev.size(); ++d)
+        if (per_dev[d]) G_.dev[d].idle.push_back(per_dev[d]);
+}
 thread_local TlsSpaces tls_spaces;
 int workspace_of_thread(int dev, Workspace **out) {
     TlsSpaces &T = tls_spaces;
@@ -127,10 +138,20 @@ int workspace_of_thread(int dev, Workspace **out) {
     if ((int)T.per_dev.size() <= dev) T.per_dev.resize(dev + 1, nullptr);
     Workspace *w = T.per_dev[dev];
     if (!w) {
-        w = new Workspace();
-        HIPCHK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
-        std::lock_guard<std::mutex> lk(G_.mu);
-        G_.dev[dev].spaces.push_back(w);
+        {
+            std::lock_guard<std::mutex> lk(G_.mu);
+            auto &idle = G_.dev[dev].idle;
+            if (!idle.empty()) { w = idle.back(); idle.pop_back(); }
+        }
+        if (w) {                                  // adopted from a finished thread: its last work may still be in flight
+            HIPCHK(hipDeviceSynchronize());
+            w->used = false; w->last = nullptr;
+        } else {
+            w = new Workspace();
+            HIPCHK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
+            std::lock_guard<std::mutex> lk(G_.mu);
+            G_.dev[dev].spaces.push_back(w);
+        }
         T.per_dev[dev] = w;
     }
     *out = w;
@@ -140,8 +161,8 @@ int workspace(int dev, hipStream_t st, Workspace **out) {
     Workspace *w = nullptr;
     CHK(workspace_of_thread(dev, &w));
     if (w->used && w->last != st) {               // same thread, other stream: keep the scratch hazards ordered
-        HIPCHK(hipEventRecord(w->ev, w->last));
-        HIPCHK(hipStreamWaitEvent(st, w->ev, 0));
+        if (hipEventRecord(w->ev, w->last) == hipSuccess) HIPCHK(hipStreamWaitEvent(st, w->ev, 0));
+        else { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }     // the previous stream no longer exists
     }
     w->last = st; w->used = true;
     *out = w;
