@@ -170,6 +170,38 @@ inline long IsOdd(const ZZ &a) { return !a.m.empty() && (a.m[0] & 1); }
 inline long bit(const ZZ &a, long k) { return a.bit((int)k); }
 inline void clear(ZZ &a) { a = ZZ(); }
 inline ZZ power(const ZZ &a, long e) { ZZ r(1), b = a; while (e) { if (e & 1) r = r * b; b = b * b; e >>= 1; } return r; }
+inline ZZ operator<<(const ZZ &a, long k) {
+    if (a.zero() || k == 0) return a;
+    ZZ r; r.neg = a.neg; r.m.assign(a.m.size() + (size_t)k / 32 + 1, 0);
+    const int s = (int)(k % 32); const size_t w = (size_t)k / 32;
+    for (size_t i = 0; i < a.m.size(); ++i) { const uint64_t v = (uint64_t)a.m[i] << s; r.m[i + w] |= (uint32_t)v; r.m[i + w + 1] |= (uint32_t)(v >> 32); }
+    r.trim(); return r;
+}
+inline ZZ operator>>(const ZZ &a, long k) {          // magnitude shift, sign kept (NTL semantics)
+    ZZ r; const size_t w = (size_t)k / 32; const int s = (int)(k % 32);
+    if (w >= a.m.size()) return r;
+    r.neg = a.neg; r.m.assign(a.m.size() - w, 0);
+    for (size_t i = w; i < a.m.size(); ++i) { uint64_t v = a.m[i]; if (i + 1 < a.m.size()) v |= (uint64_t)a.m[i + 1] << 32; r.m[i - w] = (uint32_t)(v >> s); }
+    r.trim(); return r;
+}
+inline long GCD(long a, long b) { if (a < 0) a = -a; if (b < 0) b = -b; while (b) { const long t = a % b; a = b; b = t; } return a; }
+inline ZZ GCD(const ZZ &a, const ZZ &b) { ZZ x = a, y = b; x.neg = y.neg = false; while (!y.zero()) { ZZ t = x % y; x = y; y = t; } return x; }
+// deterministic Miller-Rabin for 64-bit values (the bases 2..37 decide every n < 2^64)
+inline long ProbPrime(long n, long = 10) {
+    if (n < 2) return 0;
+    for (long p : {2L, 3L, 5L, 7L, 11L, 13L, 17L, 19L, 23L, 29L, 31L, 37L}) { if (n == p) return 1; if (n % p == 0) return 0; }
+    typedef unsigned __int128 u128; const uint64_t N = (uint64_t)n; uint64_t d = N - 1; int r = 0;
+    while (!(d & 1)) { d >>= 1; ++r; }
+    for (uint64_t a : {2ULL, 3ULL, 5ULL, 7ULL, 11ULL, 13ULL, 17ULL, 19ULL, 23ULL, 29ULL, 31ULL, 37ULL}) {
+        uint64_t x = 1, b = a % N, e = d;
+        while (e) { if (e & 1) x = (uint64_t)((u128)x * b % N); b = (uint64_t)((u128)b * b % N); e >>= 1; }
+        if (x == 1 || x == N - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < r && comp; ++i) { x = (uint64_t)((u128)x * x % N); if (x == N - 1) comp = false; }
+        if (comp) return 0;
+    }
+    return 1;
+}
 inline ZZ power2_ZZ(long e) { ZZ r; r.m.assign(e / 32 + 1, 0); r.m[e / 32] = 1u << (e % 32); return r; }
 // BytesFromZZ: little-endian bytes of |a|, zero padded / truncated to n (NTL semantics).  The magnitude is an
 // array of little-endian 32-bit words, so on a little-endian host this is a memcpy.

@@ -12,6 +12,7 @@ public:
     ZZX &operator=(const ZZX &o) { rep = o.rep; return *this; }
     ZZX(ZZX &&o) noexcept : rep(std::move(o.rep)) {}
     ZZX &operator=(ZZX &&o) noexcept { rep = std::move(o.rep); return *this; }
+    ZZX &operator=(long c) { rep.clear(); if (c) rep.push_back(ZZ(c)); return *this; }      // constant polynomial
     // releases the buffer and leaves a valid empty vector behind, so that the explicit-destructor-then-scope-exit
     // pattern of the reference's examples (Prince.cu:298-319) stays harmless with this fallback type too
     ~ZZX() { std::vector<ZZ>().swap(rep); }
@@ -57,6 +58,30 @@ inline ZZX operator%(const ZZX &a, const ZZX &m) {
     r.normalize(); return r;
 }
 inline ZZX &operator%=(ZZX &a, const ZZX &m) { a = a % m; return a; }
+inline ZZX operator*(const ZZX &a, const ZZ &c) { ZZX r; r.rep.resize(a.rep.size()); for (size_t i = 0; i < a.rep.size(); ++i) r.rep[i] = a.rep[i] * c; r.normalize(); return r; }
+inline ZZX operator*(const ZZ &c, const ZZX &a) { return a * c; }
+inline ZZX operator*(const ZZX &a, long c) { return a * ZZ(c); }
+inline ZZX operator*(long c, const ZZX &a) { return a * ZZ(c); }
+inline ZZX &operator*=(ZZX &a, const ZZ &c) { a = a * c; return a; }
+inline ZZX &operator*=(ZZX &a, long c) { a = a * ZZ(c); return a; }
+inline ZZX operator+(const ZZX &a, long c) { ZZX r = a; if (r.rep.empty()) r.rep.resize(1); r.rep[0] += ZZ(c); r.normalize(); return r; }
+inline ZZX operator-(const ZZX &a) { ZZX r = a; for (auto &c : r.rep) c = -c; return r; }
+inline ZZX &operator-=(ZZX &a, const ZZX &b) { a = a - b; return a; }
+// quotient by a polynomial whose leading coefficient is +-1 (what the cyclotomic construction of the examples needs)
+inline ZZX operator/(const ZZX &a, const ZZX &b) {
+    ZZX q, r = a; const long n = deg(b);
+    if (n < 0 || deg(a) < n) return q;
+    const bool negLead = b.rep[n] == ZZ(-1);
+    q.rep.assign((size_t)(deg(a) - n) + 1, ZZ());
+    for (long k = deg(r); k >= n; --k) {
+        ZZ c = coeff(r, k); if (c.zero()) continue;
+        if (negLead) c = -c;
+        q.rep[k - n] = c;
+        for (long i = 0; i <= n; ++i) if (!b.rep[i].zero()) r.rep[k - n + i] -= c * b.rep[i];
+    }
+    q.normalize(); return q;
+}
+inline ZZX &operator/=(ZZX &a, const ZZX &b) { a = a / b; return a; }
 inline ZZX &operator+=(ZZX &a, const ZZX &b) { a = a + b; return a; }
 inline ZZX &operator*=(ZZX &a, const ZZX &b) { a = a * b; return a; }
 inline std::ostream &operator<<(std::ostream &os, const ZZX &a) {

@@ -64,6 +64,33 @@ int main() {
 	Picklable rq(rp.pickle());
 	CHECK(rq.getPoly() == r, "random signed 200-bit coefficients survive print + parse");
 
+#ifdef CUHE_MINI_NTL
+	// the fallback big integer itself (cuhe_amd/cxx/mini_ntl): division identity on random and adversarial operands,
+	// shifts, gcd, primality, polynomial helpers the DHS construction uses
+	{
+		int bad = 0;
+		for (int it = 0; it < 5000; ++it) {
+			const int ba = 1 + (int)(mini_next() % 700), bb = 1 + (int)(mini_next() % 700);
+			ZZ a = RandomBits_ZZ(ba), b = RandomBits_ZZ(bb) + to_ZZ(1);
+			if (it % 7 == 0) b = power2_ZZ(bb) - to_ZZ(1);
+			if (it % 11 == 0) a = power2_ZZ(ba + 64) - to_ZZ(1);
+			if (it % 3 == 0) a = -a;
+			if (it % 5 == 0) b = -b;
+			const ZZ q = a / b, rem = a % b;
+			const bool ok = (q * b + rem == a) && ((b > to_ZZ(0)) ? (rem >= to_ZZ(0) && rem < b) : (rem <= to_ZZ(0) && rem > b));
+			if (!ok) ++bad;
+			if (!(((a << 37) >> 37) == a) || !((a << 5) == a * to_ZZ(32))) ++bad;
+		}
+		CHECK(bad == 0, "fallback ZZ: floor division identity, remainder sign, shifts");
+		CHECK(GCD(84L, -36L) == 12 && GCD(to_ZZ(1) << 90, to_ZZ(3) << 70) == (to_ZZ(1) << 70), "fallback ZZ: GCD");
+		CHECK(ProbPrime(2097143L) && ProbPrime(33554393L) && !ProbPrime(33554391L) && ProbPrime(18446744069414584321UL >> 1 ? 2147483647L : 2L) && !ProbPrime(1L), "fallback ZZ: ProbPrime");
+		ZZX a, b; SetCoeff(a, 0, -1); SetCoeff(a, 15, 1);            // x^15 - 1
+		SetCoeff(b, 0, -1); SetCoeff(b, 5, 1);                        // x^5 - 1
+		ZZX qd = a / b, want; SetCoeff(want, 0, 1); SetCoeff(want, 5, 1); SetCoeff(want, 10, 1);
+		CHECK(qd == want && (qd * b) == a && (a % b) == ZZX(), "fallback ZZX: exact division by a monic polynomial");
+		CHECK((b * 3L) == (b * to_ZZ(3)) && coeff(b * 3L, 5) == to_ZZ(3) && coeff(b + 4L, 0) == to_ZZ(3), "fallback ZZX: scalar operations");
+	}
+#endif
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;
 }

@@ -1,0 +1,32 @@
+"""CPU, only where /root/reference is mounted (this container; skipped on the GPU box): the reference's example
+sources -- examples/DHS/{DHS,simple_DHS}.cu and examples/Prince/{DHS,Prince,Timer,test_Prince}.cu -- are run through
+`g++ -fsyntax-only` UNCHANGED, from where they lie, against this repository's headers (cuhe_amd/cxx/CuHE.h, Utils.h).
+They include "../../cuhe/CuHE.h" relative to their own directory, so a scratch tree of symlinks puts cuhe_amd/cxx in
+that place.  NTL is not installed: ZZ/ZZX come from the fallback in cuhe_amd/cxx/mini_ntl and the modular-polynomial
+types the DHS scheme uses are DECLARED (not implemented) in tests/cxx/ntl_decls.  Nothing is built or run -- this is a
+check that every cuHE symbol the examples use exists here with a compatible signature."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/examples"
+SOURCES = ["DHS/DHS.cu", "DHS/simple_DHS.cu", "Prince/DHS.cu", "Prince/Prince.cu", "Prince/Timer.cu", "Prince/test_Prince.cu"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not mounted here")
+def test_reference_examples_pass_syntax_check_against_our_headers(tmp_path):
+    (tmp_path / "examples").mkdir()
+    os.symlink(os.path.join(ROOT, "cuhe_amd", "cxx"), tmp_path / "cuhe")
+    for d in ("DHS", "Prince"):
+        (tmp_path / "examples" / d).mkdir()
+        for f in os.listdir(os.path.join(REF, d)):
+            if f.endswith((".cu", ".h")):
+                os.symlink(os.path.join(REF, d, f), tmp_path / "examples" / d / f)
+    inc = ["-I" + os.path.join(ROOT, "cuhe_amd", "cxx", "mini_ntl"), "-I" + os.path.join(ROOT, "tests", "cxx", "ntl_decls")]
+    for src in SOURCES:
+        r = subprocess.run(["g++", "-std=c++17", "-x", "c++", "-fsyntax-only", "-fopenmp"] + inc + [os.path.join("examples", src)],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        errors = [l for l in r.stderr.splitlines() if "error" in l]
+        assert r.returncode == 0 and not errors, src + "\n" + "\n".join(errors[:20])
