@@ -2,6 +2,9 @@
 // written by hand from the format rules of cuhe/Utils.cu:76-121,141-146,203-213, parse/print round trips, and
 // the lookup behaviour examples/DHS/DHS.cu:62-124 depends on.  Host only.
 #include "Utils.h"
+#ifdef CUHE_MINI_NTL
+#include <NTL/ZZ_pE.h>
+#endif
 #include <cstdio>
 using namespace cuHE_Utils;
 
@@ -89,6 +92,47 @@ int main() {
 		ZZX qd = a / b, want; SetCoeff(want, 0, 1); SetCoeff(want, 5, 1); SetCoeff(want, 10, 1);
 		CHECK(qd == want && (qd * b) == a && (a % b) == ZZX(), "fallback ZZX: exact division by a monic polynomial");
 		CHECK((b * 3L) == (b * to_ZZ(3)) && coeff(b * 3L, 5) == to_ZZ(3) && coeff(b + 4L, 0) == to_ZZ(3), "fallback ZZX: scalar operations");
+	}
+	// modular polynomials of the fallback (what a DHS client needs: GF(2) batching arithmetic, the key inverse)
+	{
+		int bad = 0;
+		ZZ_p::init(to_ZZ(2));
+		for (int it = 0; it < 200; ++it) {
+			ZZX az, bz; const int da = 1 + (int)(mini_next() % 300), db = 1 + (int)(mini_next() % 40);
+			for (int i = 0; i <= da; ++i) SetCoeff(az, i, (long)(mini_next() & 1));
+			for (int i = 0; i <= db; ++i) SetCoeff(bz, i, (long)(mini_next() & 1));
+			SetCoeff(az, da, 1); SetCoeff(bz, db, 1);
+			ZZ_pX a = to_ZZ_pX(az), b = to_ZZ_pX(bz), q, r;
+			DivRem(q, r, a, b);
+			if (!(q * b + r == a) || deg(r) >= deg(b) || !(to_ZZ_pX(to_ZZX(a)) == a)) ++bad;
+		}
+		ZZX pz; SetCoeff(pz, 0, 1); SetCoeff(pz, 1, 1); SetCoeff(pz, 4, 1);              // x^4 + x + 1, irreducible over GF(2)
+		ZZ_pE::init(to_ZZ_pX(pz));
+		ZZ_pX one; SetCoeff(one, 0, 1);
+		for (int v = 1; v < 16; ++v) {
+			ZZX fz; for (int i = 0; i < 4; ++i) SetCoeff(fz, i, (long)((v >> i) & 1));
+			const ZZ_pE f = to_ZZ_pE(to_ZZ_pX(fz));
+			if (!(rep(f * inv(f)) == one)) ++bad;
+		}
+		CHECK(bad == 0, "fallback ZZ_pX over GF(2): division identity, inverses in GF(16)");
+		bad = 0;
+		const ZZ q3 = to_ZZ(2097143L) * to_ZZ(2097133L) * to_ZZ(524287L);              // CRT primes of the (5,2,1,61,20,8191) set
+		ZZ_p::init(q3);
+		ZZX cz; SetCoeff(cz, 0, 1); SetCoeff(cz, 16, 1);
+		ZZ_pE::init(to_ZZ_pX(cz));
+		ZZ_pX one3; SetCoeff(one3, 0, 1);
+		int inverted = 0;
+		for (int it = 0; it < 10; ++it) {
+			ZZX fz; for (int i = 0; i < 16; ++i) SetCoeff(fz, i, RandomBnd(q3));
+			const ZZ_pE f = to_ZZ_pE(to_ZZ_pX(fz));
+			try { if (!(rep(f * inv(f)) == one3)) ++bad; ++inverted; } catch (std::runtime_error &) {}
+		}
+		SetCoeff(cz, 0, 0);                                                             // x^16: x itself is not a unit
+		ZZ_pE::init(to_ZZ_pX(cz));
+		ZZX xz; SetCoeff(xz, 1, 1);
+		bool threw = false;
+		try { inv(to_ZZ_pE(to_ZZ_pX(xz))); } catch (std::runtime_error &) { threw = true; }
+		CHECK(bad == 0 && inverted >= 8 && threw, "fallback ZZ_pE over a composite modulus: per-prime inverse + CRT lift; runtime_error when there is none");
 	}
 #endif
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
