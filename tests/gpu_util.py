@@ -71,6 +71,11 @@ class GpuCtx:
         ck(lib.cuhe_hip_get_coeff_modulus(lvl, buf, 4096, C.byref(n)))
         return int.from_bytes(bytes(buf[:n.value]), "little")
 
+    def crt_primes(self):
+        out = (C.c_uint32 * self.prm.numCrtPrime)()
+        ck(lib.cuhe_hip_get_crt_primes(out, self.prm.numCrtPrime))
+        return [int(x) for x in out]
+
     # --- stages: numpy in, numpy out, compute on the GPU through the C ABI
     def crt(self, raw, lvl):
         d_in = to_dev(raw)

@@ -605,3 +605,47 @@ def test_reentrant_host_threads(gu):
                 assert np.array_equal(gu.host_u32(bufs[t][r]["cr"]), want[t][r]), (t, r)
     finally:
         g.close(); o.close()
+
+
+def test_config4_relin_structured_keys_vs_python(gu):
+    """BASELINE config 4 at full size (64K-point transforms, 48 CRT primes, 72 evaluation keys of 16-bit windows):
+    relinearisation pinned by exact Python integers, independent of the oracle.  With the keys ek_j = s * 2^(w j) mod q0
+    the key-switch sum  sum_j window_j(c) * ek_j  equals  c * s  modulo Phi and q (the windows recompose c), and for a
+    sparse s the product c * s mod (x^n + 1) is a few negacyclic shifts of c -- cheap to compute exactly in Python.
+    Covers the window extraction, the 72 window transforms, the 3456 key transforms of initRelinearization, the
+    inner-product kernel and the fused INTT + reduction, at levels 0 and 5."""
+    import oracle_lib as O
+    g = gu.GpuCtx(25, 2, 16, 576, 24, 65536)
+    try:
+        q = g.prm
+        assert (q.nttLen, q.numCrtPrime, q.numEvalKey, q.modLen) == (65536, 48, 72, 32768)
+        n, w, K = q.modLen, q.logRelin, q.numEvalKey
+        q0 = g.coeff_modulus(0)
+        primes = g.crt_primes()
+        rng = np.random.default_rng(4)
+        terms = [(int(e), int.from_bytes(rng.bytes(150), "little") % q0) for e in (0, 1, 777, 20011, n - 1)]   # s = sum v x^e
+        W0 = g.words(0)
+        ek_raw = np.zeros((K, q.rawLen, W0), dtype=np.uint32)
+        for j in range(K):
+            for e, v in terms:
+                ek_raw[j, e] = np.frombuffer(((v << (w * j)) % q0).to_bytes(4 * W0, "little"), dtype=np.uint32)
+        g.init_relin(ek_raw)
+        for lvl in (0, 5):
+            ql, npr = g.coeff_modulus(lvl), g.np_(lvl)
+            ct, cv = O.random_raw(q.rawLen, n, g.words(lvl), ql, 0xC400 + lvl)
+            got = g.intt_mod(g.relin(ct, lvl), lvl)                  # u32[npr][crtLen]
+            # exact: (c * s mod x^n + 1) mod q_lvl, then its residues
+            acc = [0] * n
+            for e, v in terms:
+                for i in range(n):
+                    k = i + e
+                    if k < n: acc[k] += cv[i] * v
+                    else: acc[k - n] -= cv[i] * v
+            want = np.zeros((npr, q.crtLen), dtype=np.uint32)
+            for i in range(n):
+                r = acc[i] % ql
+                for t in range(npr):
+                    want[t, i] = r % primes[t]
+            assert np.array_equal(got, want), lvl
+    finally:
+        g.close()
