@@ -58,8 +58,9 @@ struct Workspace {
     u64 *slab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // pass-1 -> pass-2 slabs per length
     size_t slab_bytes[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     u64 *b_ntt = nullptr;                // Barrett scratch (cuhe/Operations.cu:196-209)
-    u32 *b_src = nullptr, *b_crt = nullptr;
+    u32 *b_mq = nullptr, *b_crt = nullptr;  // q (at offset n) and (m - x^n) q
     u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
+    u32 *b_alias = nullptr;              // copy of the input when barrett() is asked to work in place
     u64 *relin = nullptr;                // NTT-domain windows of the ciphertext being relinearised
     u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows
     hipStream_t last = nullptr; bool used = false;
@@ -176,7 +177,7 @@ int ws_buffer(T **ptr, size_t count) {           // lazily allocated, fixed-size
 int ws_barrett(Workspace &w) {
     const Params &q = G_.prm;
     const size_t rows = (size_t)q.numCrtPrime * q.nttLen;
-    CHK(ws_buffer(&w.b_src, rows)); CHK(ws_buffer(&w.b_crt, rows)); CHK(ws_buffer(&w.b_ntt, rows)); CHK(ws_buffer(&w.hold, rows));
+    CHK(ws_buffer(&w.b_mq, rows)); CHK(ws_buffer(&w.b_crt, rows)); CHK(ws_buffer(&w.b_ntt, rows)); CHK(ws_buffer(&w.hold, rows));
     return CUHE_OK;
 }
 int ws_relin(Workspace &w) {
@@ -196,7 +197,7 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 }
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
-    void *ptrs[] = {w->b_ntt, w->b_src, w->b_crt, w->hold, w->relin, w->win};
+    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     delete w;
@@ -309,7 +310,9 @@ int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stri
     if (g_pass2_form == 1) {
         const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
         hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
-                           OUT != kOutU64 ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0);
+                           (OUT == kOutModP || OUT == kOutModPFoldXn1) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0);
+    } else if constexpr (OUT == kOutU64Mul) {
+        return fail(CUHE_EINVAL, "the fused table multiply exists in the wave-split pass 2 only");
     } else {
         const int tiles = N1 / p2_threads<LG>();
         const int grid = ((nb + 7) / 8) * 8 * tiles;
@@ -330,7 +333,7 @@ struct EvTimer {                 // optional per-pass hipEvent timing (bench)
 // one batched transform, chunked so that the pass-1 -> pass-2 slab stays cache resident
 template <int LG>
 int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm) {
+               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab) {
     constexpr int L = 1 << LG;
     NttTab &tab = D.ntt[LG - 14];
     const int chunk = tab.chunk;
@@ -372,7 +375,8 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, mul_tab, prime0 + b0, q2)));
+            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
@@ -382,16 +386,16 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
 }
 
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr) {
+            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr) {
     if (batch <= 0) return CUHE_OK;
     CHK(ensure_ntt(dev, len, batch));
     DevCtx &D = G_.dev[dev];
     Workspace *W = nullptr;
     CHK(workspace(dev, st, &W));
     switch (len) {
-        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm);
-        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm);
-        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm);
+        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab);
+        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab);
+        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab);
     }
 }
 
@@ -435,10 +439,15 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
         HIPCHK(hipGetLastError());
         return CUHE_OK;
     }
-    // generic: the sequence of cuhe/Operations.cu:460-501 with every per-prime loop batched
-    const size_t rows = (size_t)np * L;
-    const long pairs = (long)rows / 2;
-    const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
+    // generic: the algorithm of cuhe/Operations.cu:460-501 (q = ((f >> (n-1)) * u) >> n, r = f - q x^n - (m - x^n) q)
+    // with every per-prime loop batched and its elementwise steps fused into their neighbours:
+    //   * the two pointwise products by the precomputed NTT-domain constants (u, m - x^n) ride on the forward
+    //     transforms' output (kOutU64Mul), instead of two more passes over u64[np][L];
+    //   * f is only read (no working copy), q stays in b_crt while the last inverse transform writes to b_mq;
+    //   * one kernel forms r[0..n) = f - (m - x^n) q, applies the reference's "coefficient n is non-zero -> subtract m
+    //     once more" correction (barrett_sub_mc, Base.cu:978-1001) from r[n] = f[n] - q[0] - ((m - x^n) q)[n], and
+    //     writes the crtLen-strided result.  The q x^n term only touches coefficients >= n, which are not output.
+    // 11 launches per call (5 transform pairs + 1) instead of 18.
     const u64 *u_ntt = D.u_ntt + (size_t)prime0 * L, *m_ntt = D.m_ntt + (size_t)prime0 * L;
     const u32 *m_crt = D.m_crt + (size_t)prime0 * cl;
     WindowArgs wa{0, 0, 0};
@@ -446,18 +455,22 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
     CHK(workspace(dev, st, &Wp));
     CHK(ws_barrett(*Wp));
     Workspace &Ws = *Wp;
-    if (src != Ws.b_src) HIPCHK(hipMemcpyAsync(Ws.b_src, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
-    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_src + (n - 1), np, L, L, L, 0, wa, dev, st));            // f >> (n-1)
-    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, u_ntt, pairs);
-    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // u * (f>>(n-1))
-    hipLaunchKernelGGL(k_zero_rows, dim3((n + 255) / 256, np), dim3(256), 0, st, Ws.b_crt, n, L);
-    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st));                  // q = (..)>>n
-    hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, m_ntt, pairs);
-    hipLaunchKernelGGL(k_barrett_sub, dim3((n + 255) / 256, np), dim3(256), 0, st, Ws.b_src, Ws.b_crt, pt, n, n, L);
-    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));                 // (m - x^n) * q
-    hipLaunchKernelGGL(k_barrett_sub, dim3((L + 255) / 256, np), dim3(256), 0, st, Ws.b_src, Ws.b_crt, pt, 0, L, L);
-    hipLaunchKernelGGL(k_barrett_sub_mc, dim3((n + 255) / 256, np), dim3(256), 0, st, Ws.b_src, m_crt, pt, n, cl, L);
-    hipLaunchKernelGGL(k_gather_rows, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, Ws.b_src, cl, L);
+    const bool fuse_mul = g_pass2_form == 1;
+    const size_t rows = (size_t)np * L;
+    if (dst < src + rows && src < dst + (size_t)np * cl) {      // result rows would overwrite input rows still to be read
+        CHK(ws_buffer(&Ws.b_alias, (size_t)G_.prm.numCrtPrime * L));
+        HIPCHK(hipMemcpyAsync(Ws.b_alias, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
+        src = Ws.b_alias;
+    }
+    const long pairs = (long)rows / 2;
+    const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, src + (n - 1), np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? u_ntt : nullptr));   // (f >> (n-1)) * u
+    if (!fuse_mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, u_ntt, pairs);
+    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));                  // q at [n, 2n-1)
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? m_ntt : nullptr));     // q * (m - x^n)
+    if (!fuse_mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, m_ntt, pairs);
+    CHK(run_ntt(L, kSrcU64Neg, Ws.b_mq, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));
+    hipLaunchKernelGGL(k_barrett_final, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, Ws.b_crt, Ws.b_mq, m_crt, pt, n, cl, L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }

@@ -160,7 +160,9 @@ void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
     }
 }
 
-enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2 };
+// kOutU64Mul (wave-split pass 2 only): forward transform whose outputs are multiplied by a table row on the way out
+// (the pointwise product with a precomputed NTT-domain constant, fused: `pinv` carries the table, u64[prime][L])
+enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2, kOutU64Mul = 3 };
 
 template <int LG, int OUT>
 __global__ __launch_bounds__(p2_threads<LG>(), 2)
@@ -250,7 +252,7 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
                 long dst_stride, int nbatch, int nstore,
                 const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
     constexpr int L = 1 << LG, N1 = L / 64;
-    constexpr bool INV = OUT != kOutU64;
+    constexpr bool INV = (OUT == kOutModP || OUT == kOutModPFoldXn1);
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     int batch, tile;
     xcd_map(N1 / kP2wCols, batch, tile);
@@ -291,6 +293,14 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
             u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(y[bitrev<4>(c)], &dst[(long)(b + 16 * c) * N1]);
+        } else if constexpr (OUT == kOutU64Mul) {
+            u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
+            const u64 *tab = pinv + (long)(prime0 + batch) * L + k1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long o = (long)(b + 16 * c) * N1;
+                __builtin_nontemporal_store(mulp(y[bitrev<4>(c)], tab[o]), &dst[o]);
+            }
         } else if constexpr (OUT == kOutModP) {
             u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
 #pragma unroll

@@ -149,6 +149,33 @@ void k_gather_rows(u32 *__restrict__ dst, const u32 *__restrict__ src, int clen,
     if (idx < clen) dst[(long)crt * clen + idx] = src[(long)crt * nlen + idx];
 }
 
+// Last step of the NTT-based Barrett reduction, fused (replaces barrett_sub x2, barrett_sub_mc and the strided gather
+// of Base.cu:951-1001):  f = polynomial to reduce (row stride nlen, residues < p), qrow = quotient q stored at offset
+// mlen of its row, mq = ((m - x^n) q) mod p.  r = f - q x^n - (m - x^n) q has degree <= n; for idx < n the q x^n term
+// does not contribute, and the reference's correction subtracts m once more when the coefficient of x^n is non-zero.
+__global__ __launch_bounds__(256)
+void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32 *__restrict__ qrow, const u32 *__restrict__ mq,
+                     const u32 *__restrict__ m_crt, PrimeTab pt, int mlen, int clen, int nlen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= clen) return;
+    const long base = (long)crt * nlen;
+    const u32 p = pt.p[crt];
+    u32 r = 0;
+    if (idx < mlen) {
+        u32 a = f[base + idx], b = mq[base + idx];
+        r = a >= b ? a - b : a + p - b;
+        // coefficient mlen of r (wave-uniform per row): f[n] - q[0] - mq[n]
+        u32 t = f[base + mlen], q0 = qrow[base + mlen], b2 = mq[base + mlen];
+        t = t >= q0 ? t - q0 : t + p - q0;
+        t = t >= b2 ? t - b2 : t + p - b2;
+        if (t != 0 && idx < mlen - 1) {
+            const u32 s = m_crt[(long)crt * clen + idx];
+            r = r >= s ? r - s : r + p - s;
+        }
+    }
+    dst[(long)crt * clen + idx] = r;
+}
+
 // fast exact reduction when the modulus is x^n + 1 (m = 2n a power of two):
 //   r[i] = f[i] - f[i+n]           (f has degree <= 2n-2)
 // and when m is prime (Phi_m = 1 + x + ... + x^(m-1), n = m-1):

@@ -228,6 +228,20 @@ void CuPolynomial::nRepCreate(cudaStream_t st) {
 	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize());
 	CSC(cuhe_hip_memset_async(device_, nRep_, 0, nRepSize(), st));
 }
+// kernels that produce RAW / CRT rows write the modLen coefficients of the ring; the rest of a row has to read as
+// zero, which only needs a fill when the ring is shorter than the row.  NTT-domain rows are always written in full.
+static bool shortRing() { return param.modLen < param.crtLen; }
+void CuPolynomial::rRepAlloc(cudaStream_t st) {
+	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
+	if (shortRing()) CSC(cuhe_hip_memset_async(device_, rRep_, 0, rRepSize(), st));
+}
+void CuPolynomial::cRepAlloc(cudaStream_t st) {
+	cRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : cRepSize());
+	if (shortRing()) CSC(cuhe_hip_memset_async(device_, cRep_, 0, cRepSize(), st));
+}
+void CuPolynomial::nRepAlloc(cudaStream_t) {
+	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize());
+}
 void CuPolynomial::rRepFree() { CSC(cuhe_hip_free(device_, rRep_)); rRep_ = NULL; }
 void CuPolynomial::cRepFree() { CSC(cuhe_hip_free(device_, cRep_)); cRep_ = NULL; }
 void CuPolynomial::nRepFree() { CSC(cuhe_hip_free(device_, nRep_)); nRep_ = NULL; }
@@ -292,7 +306,7 @@ void CuPolynomial::r2z(cudaStream_t st) {
 void CuPolynomial::r2c(cudaStream_t st) {
 	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }
 	if (logq_ > param.logCrtPrime) {
-		cRepCreate(st);
+		cRepAlloc(st);
 		crt(cRep_, rRep_, logq_, device_, st);
 		CSC(cuhe_hip_stream_sync(device_, st));
 		rRepFree();
@@ -304,7 +318,7 @@ void CuPolynomial::r2c(cudaStream_t st) {
 void CuPolynomial::c2r(cudaStream_t st) {
 	if (domain_ != 2) { printf("Error: Not in domain CRT!\n"); terminate(); }
 	if (logq_ > param.logCrtPrime) {
-		rRepCreate(st);
+		rRepAlloc(st);
 		icrt(rRep_, cRep_, logq_, device_, st);
 		CSC(cuhe_hip_stream_sync(device_, st));
 		cRepFree();
@@ -315,7 +329,7 @@ void CuPolynomial::c2r(cudaStream_t st) {
 }
 void CuPolynomial::c2n(cudaStream_t st) {
 	if (domain_ != 2) { printf("Error: Not in domain CRT!\n"); terminate(); }
-	nRepCreate(st);
+	nRepAlloc(st);
 	ntt(nRep_, cRep_, logq_, device_, st);
 	CSC(cuhe_hip_stream_sync(device_, st));
 	cRepFree();
@@ -323,7 +337,7 @@ void CuPolynomial::c2n(cudaStream_t st) {
 }
 void CuPolynomial::n2c(cudaStream_t st) {
 	if (domain_ != 3) { printf("Error: Not in domain NTT!\n"); terminate(); }
-	cRepCreate(st);
+	cRepAlloc(st);
 	if (isProd_) inttMod(cRep_, nRep_, logq_, device_, st);
 	else intt(cRep_, nRep_, logq_, device_, st);
 	CSC(cuhe_hip_stream_sync(device_, st));
@@ -361,6 +375,13 @@ void CuCtxt::setLevel(int lvl, int domain, int device, cudaStream_t st) {
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
+void CuCtxt::setLevelForOutput(int lvl, int domain, int device, cudaStream_t st) {
+	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
+	if (domain_ == 0) clear(zRep_);
+	else if (domain_ == 1) rRepAlloc(st);
+	else if (domain_ == 2) cRepAlloc(st);
+	else if (domain_ == 3) nRepAlloc(st);
+}
 void CuCtxt::setLevel(int lvl, int device, ZZX val) {
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = 0; device_ = device; zRep_ = std::move(val);
 }
@@ -381,7 +402,7 @@ void CuCtxt::modSwitch(int lvl, cudaStream_t st) {
 }
 void CuCtxt::relin(cudaStream_t st) {
 	x2r(st);
-	nRepCreate(st);
+	nRepAlloc(st);
 	relinearization(nRep_, rRep_, level_, device_, st);
 	CSC(cuhe_hip_stream_sync(device_, st));
 	rRepFree();
@@ -402,7 +423,7 @@ size_t CuPtxt::nRepSize() { return (size_t)param.nttLen * sizeof(uint64); }
 void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	if (&dst == &src) return;
 	dst.reset();
-	dst.setLevel(src.level(), src.domain(), src.device(), st);
+	dst.setLevelForOutput(src.level(), src.domain(), src.device(), st);
 	dst.isProd(src.isProd());
 	const int dev = dst.device();
 	if (dst.domain() == 0) dst.zRep(src.zRep());
@@ -412,7 +433,7 @@ void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	if (dev >= 0) CSC(cuhe_hip_stream_sync(dev, st));
 }
 static void prepareOut(CuCtxt &out, CuCtxt &like, int domain, cudaStream_t st) {
-	if (&out != &like) { out.reset(); out.setLevel(like.level(), domain, like.device(), st); }
+	if (&out != &like) { out.reset(); out.setLevelForOutput(like.level(), domain, like.device(), st); }
 }
 void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.device() != in1.device()) misuse("Error: Multiplication of different devices!");

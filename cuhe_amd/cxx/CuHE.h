@@ -65,6 +65,11 @@ public:
 	size_t rRepSize();
 	virtual size_t cRepSize() = 0;
 	virtual size_t nRepSize() = 0;
+	// (additions) storage for a representation every element of which is about to be written: no memset, except
+	// for the tail beyond modLen of RAW/CRT rows when the ring is shorter than the row (kernels write modLen entries)
+	void rRepAlloc(cudaStream_t st = 0);
+	void cRepAlloc(cudaStream_t st = 0);
+	void nRepAlloc(cudaStream_t st = 0);
 protected:
 	void z2r(cudaStream_t st = 0);   // ZZX -> RAW
 	void r2z(cudaStream_t st = 0);   // RAW -> ZZX
@@ -88,6 +93,7 @@ public:
 	CuCtxt() : CuPolynomial() { level_ = -1; }
 	void setLevel(int lvl, int dom, int dev, cudaStream_t st = 0);   // allocate, no value
 	void setLevel(int lvl, int dev, ZZX val);                        // host value
+	void setLevelForOutput(int lvl, int dom, int dev, cudaStream_t st = 0);   // (addition) like setLevel(lvl, dom, dev) without zero fill
 	int level();
 	void modSwitch(cudaStream_t st = 0);           // one level down
 	void modSwitch(int lvl, cudaStream_t st = 0);  // down to level lvl
