@@ -49,6 +49,8 @@ SIGNATURES = {
     "cuhe_hip_malloc": (vp, [i32, sz]),
     "cuhe_hip_free": (i32, [i32, vp]),
     "cuhe_hip_set_alloc_cache": (i32, [sz]),
+    "cuhe_hip_malloc_stream": (vp, [i32, sz, vp]),
+    "cuhe_hip_free_stream": (i32, [i32, vp, vp]),
     "cuhe_hip_host_alloc": (vp, [sz]),
     "cuhe_hip_host_free": (i32, [vp]),
     "cuhe_hip_memset_async": (i32, [i32, vp, i32, sz, vp]),

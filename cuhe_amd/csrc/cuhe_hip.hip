@@ -89,7 +89,8 @@ struct DevCtx {
     hipEvent_t ev_start = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     std::multimap<size_t, void *> freeBlocks;
     std::map<void *, size_t> allocated;
-    size_t cachedBytes = 0;              // bytes parked in freeBlocks
+    size_t cachedBytes = 0;              // bytes parked in freeBlocks and streamBlocks
+    std::map<hipStream_t, std::multimap<size_t, void *>> streamBlocks;   // freed in stream order, not yet synchronised
 };
 
 struct Global {
@@ -696,9 +697,19 @@ int cuhe_hip_force_generic_reduce(int on) { G_.force_generic = on != 0; return C
 // ---------------------------------------------------------------- allocator
 int cuhe_hip_start_allocator(void) { G_.allocator_on = true; return CUHE_OK; }   // no "grab all VRAM" 
 static void drop_cached(DevCtx &D) {
-    for (auto &kv : D.freeBlocks) hipFree(kv.second);
+    for (auto &kv : D.freeBlocks) hipFree(kv.second);            // (hipFree waits for the device: in-flight users are safe)
     D.freeBlocks.clear();
+    for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) hipFree(kv.second);
+    D.streamBlocks.clear();
     D.cachedBytes = 0;
+}
+// blocks freed in stream order become ordinary free blocks once that stream has been synchronised
+static void settle_stream_blocks(DevCtx &D, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.streamBlocks.find(st);
+    if (it == D.streamBlocks.end()) return;
+    for (auto &kv : it->second) D.freeBlocks.insert(kv);
+    D.streamBlocks.erase(it);
 }
 int cuhe_hip_stop_allocator(void) {
     G_.allocator_on = false;
@@ -745,6 +756,40 @@ int cuhe_hip_free(int dev, void *ptr) {
     else HIPCHK(hipFree(ptr));
     return CUHE_OK;
 }
+// Stream-ordered variants: a block freed with free_stream may still be in use by work already enqueued on `st`, so it
+// is handed out again only to allocations made for the SAME stream (which run after that work) until the stream has
+// been synchronised through cuhe_hip_stream_sync.  This is what lets a caller enqueue a whole chain of ciphertext
+// operations without a host synchronisation after each (the C++ layer's setAsynchronous(true)).
+void *cuhe_hip_malloc_stream(int dev, size_t bytes, void *st) {
+    if (set_dev(dev) != CUHE_OK) return nullptr;
+    DevCtx &D = G_.dev[dev];
+    {
+        std::lock_guard<std::mutex> lk(G_.mu);
+        auto sb = D.streamBlocks.find(S(st));
+        if (sb != D.streamBlocks.end()) {
+            auto it = sb->second.find(bytes);
+            if (it != sb->second.end()) {
+                void *p = it->second;
+                sb->second.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+                return p;
+            }
+        }
+    }
+    return cuhe_hip_malloc(dev, bytes);
+}
+int cuhe_hip_free_stream(int dev, void *ptr, void *st) {
+    if (!ptr) return CUHE_OK;
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.allocated.find(ptr);
+    if (it == D.allocated.end()) return fail(CUHE_EINVAL, "free of unknown pointer");
+    const size_t sz = it->second;
+    D.allocated.erase(it);
+    if (G_.allocator_on || D.cachedBytes + sz <= G_.cache_cap) { D.streamBlocks[S(st)].insert({sz, ptr}); D.cachedBytes += sz; }
+    else HIPCHK(hipFree(ptr));
+    return CUHE_OK;
+}
 // pinned host staging memory for the ZZX <-> raw conversions of the C++ layer (cuhe/CuHE.cu:317-348 uses pageable)
 void *cuhe_hip_host_alloc(size_t bytes) {
     void *p = nullptr;
@@ -768,8 +813,17 @@ int cuhe_hip_stream_create(int dev, void **out) {
     *out = (void *)s;
     return CUHE_OK;
 }
-int cuhe_hip_stream_destroy(int dev, void *st) { CHK(set_dev(dev)); if (st) HIPCHK(hipStreamDestroy(S(st))); return CUHE_OK; }
-int cuhe_hip_stream_sync(int dev, void *st) { CHK(set_dev(dev)); HIPCHK(hipStreamSynchronize(S(st))); return CUHE_OK; }
+int cuhe_hip_stream_destroy(int dev, void *st) {
+    CHK(set_dev(dev));
+    if (st) { HIPCHK(hipStreamSynchronize(S(st))); settle_stream_blocks(G_.dev[dev], S(st)); HIPCHK(hipStreamDestroy(S(st))); }
+    return CUHE_OK;
+}
+int cuhe_hip_stream_sync(int dev, void *st) {
+    CHK(set_dev(dev));
+    HIPCHK(hipStreamSynchronize(S(st)));
+    if (!G_.dev[dev].streamBlocks.empty()) settle_stream_blocks(G_.dev[dev], S(st));
+    return CUHE_OK;
+}
 
 // ---------------------------------------------------------------- drivers
 int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st) {

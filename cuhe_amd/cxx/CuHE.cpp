@@ -73,8 +73,17 @@ void *deviceMalloc(size_t size) {
 }
 void deviceFree(void *ptr) { CSC(cuhe_hip_free(tlsDevice, ptr)); }
 
-static void *devAlloc(int dev, size_t bytes) {
-	void *p = cuhe_hip_malloc(dev, bytes);
+// ---- asynchronous gates (addition).  The reference ends every public operation with a stream synchronise
+// (cuhe/CuHE.cu:98,121,...).  With setAsynchronous(true) the operations only ENQUEUE work on their stream: device
+// buffers are allocated and released in stream order (cuhe_hip_malloc_stream / free_stream), and the caller
+// synchronises when it needs a result on the host (x2z does it itself) or hands a ciphertext to another stream.
+static bool asyncGates = false;
+void setAsynchronous(bool on) { asyncGates = on; }
+bool isAsynchronous() { return asyncGates; }
+#define GATE_SYNC(dev, st) do { if (!asyncGates) CSC(cuhe_hip_stream_sync(dev, st)); } while (0)
+
+static void *devAlloc(int dev, size_t bytes, cudaStream_t st = 0) {
+	void *p = asyncGates ? cuhe_hip_malloc_stream(dev, bytes, st) : cuhe_hip_malloc(dev, bytes);
 	if (!p) CSC(CUHE_EHIP);
 	return p;
 }
@@ -185,7 +194,7 @@ void initCuHE(ZZ *coeffMod_, ZZX modulus) {
 // ------------------------------------------------------------------ CuPolynomial
 static void misuse(const char *msg) { cout << msg << endl; terminate(); }
 
-CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), rRep_(NULL), cRep_(NULL), nRep_(NULL) { clear(zRep_); }
+CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), rRep_(NULL), cRep_(NULL), nRep_(NULL), stream_(0) { clear(zRep_); }
 CuPolynomial::~CuPolynomial() { reset(); }
 void CuPolynomial::reset() {
 	clear(zRep_);
@@ -211,40 +220,43 @@ void CuPolynomial::swapZRep(ZZX &other) { using std::swap; swap(zRep_, other); }
 uint32 *CuPolynomial::rRep() { return rRep_; }
 uint32 *CuPolynomial::cRep() { return cRep_; }
 uint64 *CuPolynomial::nRep() { return nRep_; }
+void CuPolynomial::stream(cudaStream_t st) { stream_ = st; }
+cudaStream_t CuPolynomial::stream() { return stream_; }
 int CuPolynomial::coeffWords() { return (logq_ + 31) / 32; }
 size_t CuPolynomial::rRepSize() { return (size_t)param.rawLen * coeffWords() * sizeof(uint32); }
 
 // with the pooled allocator every representation is one fixed-size block (cuhe/CuHE.cu:469,477,485)
 static size_t poolBlock() { return (size_t)param.numCrtPrime * param.nttLen * sizeof(uint64); }
 void CuPolynomial::rRepCreate(cudaStream_t st) {
-	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
+	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize(), stream_ = st);
 	CSC(cuhe_hip_memset_async(device_, rRep_, 0, rRepSize(), st));
 }
 void CuPolynomial::cRepCreate(cudaStream_t st) {
-	cRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : cRepSize());
+	cRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : cRepSize(), stream_ = st);
 	CSC(cuhe_hip_memset_async(device_, cRep_, 0, cRepSize(), st));
 }
 void CuPolynomial::nRepCreate(cudaStream_t st) {
-	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize());
+	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize(), stream_ = st);
 	CSC(cuhe_hip_memset_async(device_, nRep_, 0, nRepSize(), st));
 }
 // kernels that produce RAW / CRT rows write the modLen coefficients of the ring; the rest of a row has to read as
 // zero, which only needs a fill when the ring is shorter than the row.  NTT-domain rows are always written in full.
 static bool shortRing() { return param.modLen < param.crtLen; }
 void CuPolynomial::rRepAlloc(cudaStream_t st) {
-	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
+	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize(), stream_ = st);
 	if (shortRing()) CSC(cuhe_hip_memset_async(device_, rRep_, 0, rRepSize(), st));
 }
 void CuPolynomial::cRepAlloc(cudaStream_t st) {
-	cRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : cRepSize());
+	cRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : cRepSize(), stream_ = st);
 	if (shortRing()) CSC(cuhe_hip_memset_async(device_, cRep_, 0, cRepSize(), st));
 }
-void CuPolynomial::nRepAlloc(cudaStream_t) {
-	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize());
+void CuPolynomial::nRepAlloc(cudaStream_t st) {
+	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize(), stream_ = st);
 }
-void CuPolynomial::rRepFree() { CSC(cuhe_hip_free(device_, rRep_)); rRep_ = NULL; }
-void CuPolynomial::cRepFree() { CSC(cuhe_hip_free(device_, cRep_)); cRep_ = NULL; }
-void CuPolynomial::nRepFree() { CSC(cuhe_hip_free(device_, nRep_)); nRep_ = NULL; }
+static void devFree(int dev, void *p, cudaStream_t st) { CSC(asyncGates ? cuhe_hip_free_stream(dev, p, st) : cuhe_hip_free(dev, p)); }
+void CuPolynomial::rRepFree() { devFree(device_, rRep_, stream_); rRep_ = NULL; }
+void CuPolynomial::cRepFree() { devFree(device_, cRep_, stream_); cRep_ = NULL; }
+void CuPolynomial::nRepFree() { devFree(device_, nRep_, stream_); nRep_ = NULL; }
 
 // ---- host staging.  The reference packs coefficient by coefficient into a pageable vector and
 // copies that (cuhe/CuHE.cu:317-348).  Here each host thread owns one grow-only PINNED buffer (the examples drive
@@ -268,7 +280,7 @@ static thread_local PinnedStage tlsStage;
 
 void CuPolynomial::z2r(cudaStream_t st) {
 	if (domain_ != 0) { printf("Error: Not in domain ZZX!\n"); terminate(); }
-	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
+	rRep_ = (uint32 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : rRepSize(), stream_ = st);
 	const int W = coeffWords();
 	const long rows = param.rawLen, top = deg(zRep_);
 	const size_t rowBytes = (size_t)W * sizeof(uint32);
@@ -308,7 +320,7 @@ void CuPolynomial::r2c(cudaStream_t st) {
 	if (logq_ > param.logCrtPrime) {
 		cRepAlloc(st);
 		crt(cRep_, rRep_, logq_, device_, st);
-		CSC(cuhe_hip_stream_sync(device_, st));
+		GATE_SYNC(device_, st);
 		rRepFree();
 	} else {                                                   // one word per coefficient: RAW and CRT coincide
 		cRep_ = rRep_; rRep_ = NULL;
@@ -320,7 +332,7 @@ void CuPolynomial::c2r(cudaStream_t st) {
 	if (logq_ > param.logCrtPrime) {
 		rRepAlloc(st);
 		icrt(rRep_, cRep_, logq_, device_, st);
-		CSC(cuhe_hip_stream_sync(device_, st));
+		GATE_SYNC(device_, st);
 		cRepFree();
 	} else {
 		rRep_ = cRep_; cRep_ = NULL;
@@ -331,7 +343,7 @@ void CuPolynomial::c2n(cudaStream_t st) {
 	if (domain_ != 2) { printf("Error: Not in domain CRT!\n"); terminate(); }
 	nRepAlloc(st);
 	ntt(nRep_, cRep_, logq_, device_, st);
-	CSC(cuhe_hip_stream_sync(device_, st));
+	GATE_SYNC(device_, st);
 	cRepFree();
 	domain_ = 3;
 }
@@ -340,7 +352,7 @@ void CuPolynomial::n2c(cudaStream_t st) {
 	cRepAlloc(st);
 	if (isProd_) inttMod(cRep_, nRep_, logq_, device_, st);
 	else intt(cRep_, nRep_, logq_, device_, st);
-	CSC(cuhe_hip_stream_sync(device_, st));
+	GATE_SYNC(device_, st);
 	isProd_ = false;
 	nRepFree();
 	domain_ = 2;
@@ -391,8 +403,9 @@ size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * param.nt
 void CuCtxt::modSwitch(cudaStream_t st) {
 	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
 	x2c(st);
+	stream_ = st;
 	crtModSwitch(cRep_, cRep_, logq_, device_, st);
-	CSC(cuhe_hip_stream_sync(device_, st));
+	GATE_SYNC(device_, st);
 	logq_ -= param.logCoeffCut;
 	level_++;
 }
@@ -404,12 +417,12 @@ void CuCtxt::relin(cudaStream_t st) {
 	x2r(st);
 	nRepAlloc(st);
 	relinearization(nRep_, rRep_, level_, device_, st);
-	CSC(cuhe_hip_stream_sync(device_, st));
+	GATE_SYNC(device_, st);
 	rRepFree();
 	isProd_ = true;
 	domain_ = 3;
 	n2c(st);
-	CSC(cuhe_hip_stream_sync(device_, st));
+	GATE_SYNC(device_, st);
 }
 void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
 	logq_ = logq; domain_ = domain; device_ = device;
@@ -422,6 +435,7 @@ size_t CuPtxt::nRepSize() { return (size_t)param.nttLen * sizeof(uint64); }
 // ------------------------------------------------------------------ gates
 void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	if (&dst == &src) return;
+	src.stream(st);
 	dst.reset();
 	dst.setLevelForOutput(src.level(), src.domain(), src.device(), st);
 	dst.isProd(src.isProd());
@@ -430,7 +444,7 @@ void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	else if (dst.domain() == 1) CSC(cuhe_hip_memcpy_d2d(dev, dst.rRep(), src.rRep(), dst.rRepSize(), st));
 	else if (dst.domain() == 2) CSC(cuhe_hip_memcpy_d2d(dev, dst.cRep(), src.cRep(), dst.cRepSize(), st));
 	else if (dst.domain() == 3) CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(), src.nRep(), dst.nRepSize(), st));
-	if (dev >= 0) CSC(cuhe_hip_stream_sync(dev, st));
+	if (dev >= 0) GATE_SYNC(dev, st);
 }
 static void prepareOut(CuCtxt &out, CuCtxt &like, int domain, cudaStream_t st) {
 	if (&out != &like) { out.reset(); out.setLevelForOutput(like.level(), domain, like.device(), st); }
@@ -440,20 +454,23 @@ void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.domain() != 3 || in1.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
 	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
 	prepareOut(out, in0, 3, st);
+	in0.stream(st); in1.stream(st); out.stream(st);
 	nttMul(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
 	out.isProd(true);
-	CSC(cuhe_hip_stream_sync(out.device(), st));
+	GATE_SYNC(out.device(), st);
 }
 void cAnd(CuCtxt &out, CuCtxt &inc, CuPtxt &inp, cudaStream_t st) {
 	if (inc.device() != inp.device()) misuse("Error: Multiplication of different devices!");
 	if (inc.domain() != 3 || inp.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
 	prepareOut(out, inc, 3, st);
+	inc.stream(st); inp.stream(st); out.stream(st);
 	nttMulNX1(out.nRep(), inc.nRep(), inp.nRep(), out.logq(), out.device(), st);
 	out.isProd(true);
-	CSC(cuhe_hip_stream_sync(out.device(), st));
+	GATE_SYNC(out.device(), st);
 }
 void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
+	in0.stream(st); in1.stream(st);
 	if (in0.logq() != in1.logq()) misuse("Error: Addition of different levels!");
 	if (in0.domain() == 2 && in1.domain() == 2) {
 		prepareOut(out, in0, 2, st);
@@ -463,10 +480,11 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
 		nttAdd(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
-	CSC(cuhe_hip_stream_sync(out.device(), st));
+	GATE_SYNC(out.device(), st);
 }
 void cXor(CuCtxt &out, CuCtxt &in0, CuPtxt &in1, cudaStream_t st) {
 	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
+	in0.stream(st); in1.stream(st);
 	if (in0.domain() == 2 && in1.domain() == 2) {
 		prepareOut(out, in0, 2, st);
 		crtAddNX1(out.cRep(), in0.cRep(), in1.cRep(), out.logq(), out.device(), st);
@@ -475,17 +493,18 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuPtxt &in1, cudaStream_t st) {
 		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
 		nttAddNX1(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
-	CSC(cuhe_hip_stream_sync(out.device(), st));
+	GATE_SYNC(out.device(), st);
 }
 void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
 	if (in.domain() != 2) misuse("Error: cNot of non-CRT domain!");
+	in.stream(st);
 	if (&out != &in) {
 		// the reference allocates a zeroed result and only writes the constant term (crt_add_int,
 		// cuhe/Base.cu:1096): a value-preserving NOT needs the other coefficients too
 		copy(out, in, st);
 	}
 	crtAddInt(out.cRep(), in.cRep(), (unsigned)param.modMsg - 1, out.logq(), out.device(), st);
-	CSC(cuhe_hip_stream_sync(out.device(), st));
+	GATE_SYNC(out.device(), st);
 }
 void moveTo(CuCtxt &tar, int dstDev, cudaStream_t st) {
 	if (dstDev == tar.device()) return;

@@ -49,6 +49,8 @@ public:
 	uint32 *rRep();
 	uint32 *cRep();
 	uint64 *nRep();
+	void stream(cudaStream_t st);    // (addition) the stream whose work last touched the device representation;
+	cudaStream_t stream();           //            buffers are released in that stream's order in asynchronous mode
 	// any domain -> the named domain
 	void x2z(cudaStream_t st = 0);
 	void x2r(cudaStream_t st = 0);
@@ -85,6 +87,7 @@ protected:
 	uint32 *rRep_;
 	uint32 *cRep_;
 	uint64 *nRep_;
+	cudaStream_t stream_;
 };
 
 // ciphertext: a polynomial per CRT prime of its level
@@ -121,6 +124,11 @@ void stopAllocator();
 void multiGPUs(int num);
 int numGPUs();
 void setParameters(int d, int p, int w, int min, int cut, int m);
+// (addition) asynchronous gates: with setAsynchronous(true) conversions and gates only enqueue work on their stream
+// (the reference synchronises after each one, cuhe/CuHE.cu:98,121,...); the caller synchronises -- cuhe_hip_stream_sync
+// or any x2z() -- before it reads a result on the host or hands a ciphertext to work on another stream.  Default: off.
+void setAsynchronous(bool on);
+bool isAsynchronous();
 void resetParameters();
 void initRelinearization(ZZX *evalkey);
 

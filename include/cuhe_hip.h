@@ -88,6 +88,11 @@ int cuhe_hip_free(int dev, void *ptr);
 /* freed blocks are parked for reuse (hipMalloc/hipFree cost more than a CRT or NTT stage): without limit between
    start/stopAllocator, up to this many bytes per device otherwise (default 4 GiB; 0 = plain hipMalloc/hipFree) */
 int cuhe_hip_set_alloc_cache(size_t bytes);
+/* stream-ordered variants: a block freed with free_stream is reused only by malloc_stream calls for the same stream
+   until cuhe_hip_stream_sync(stream) has returned; callers can then enqueue chains of operations without a host
+   synchronisation between them */
+void *cuhe_hip_malloc_stream(int dev, size_t bytes, void *stream);
+int cuhe_hip_free_stream(int dev, void *ptr, void *stream);
 /* pinned host staging buffers for z2r / r2z (cuhe/CuHE.cu:317-348 stages through pageable memory) */
 void *cuhe_hip_host_alloc(size_t bytes);
 int cuhe_hip_host_free(void *ptr);

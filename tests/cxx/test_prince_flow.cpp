@@ -19,7 +19,10 @@
 // ONE GPU: the library keeps its scratch per host thread, so the small kernels of independent ciphertext operations
 // overlap on the device.  T = 1 is the reference's single-device behaviour (default stream, no threads).
 //
-// usage: test_prince_flow [--no-round-checks] [--threads T]
+// --async switches the library to asynchronous gates (setAsynchronous, an addition to the reference API): the ~100
+// gates and conversions of an S-box are enqueued back to back and synchronised once.
+//
+// usage: test_prince_flow [--no-round-checks] [--threads T] [--async]
 #include "dhs_client.hpp"
 #include <atomic>
 #include <chrono>
@@ -124,13 +127,16 @@ struct Pool {
 		int seen = 0;
 		for (;;) {
 			{ std::unique_lock<std::mutex> lk(m); cvStart.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
-			for (int i; (i = next.fetch_add(1)) < count;) job(i, (cudaStream_t)streams[t]);
+			for (int i; (i = next.fetch_add(1)) < count;) { job(i, (cudaStream_t)streams[t]); finish((cudaStream_t)streams[t]); }
 			{ std::lock_guard<std::mutex> lk(m); if (--running == 0) cvDone.notify_one(); }
 		}
 	}
+	// with asynchronous gates an item's work is only enqueued when job() returns: wait for it before the item's results
+	// can be used from another stream (one synchronisation per S-box instead of one per gate)
+	static void finish(cudaStream_t st) { if (isAsynchronous() && cuhe_hip_stream_sync(0, st) != 0) { printf("stream sync failed\n"); exit(2); } }
 	// job(i, stream) for i in [0, n), on the pool's threads (inline on the default stream when T = 1)
 	void run(int n, Job f) {
-		if (T <= 1) { for (int i = 0; i < n; ++i) f(i, (cudaStream_t)0); return; }
+		if (T <= 1) { for (int i = 0; i < n; ++i) f(i, (cudaStream_t)0); finish((cudaStream_t)0); return; }
 		{ std::lock_guard<std::mutex> lk(m); job = f; count = n; next = 0; running = T; ++gen; }
 		cvStart.notify_all();
 		std::unique_lock<std::mutex> lk(m);
@@ -266,15 +272,17 @@ struct Evaluator {
 		std::vector<Ct> k0p(64);
 		pool.run(64, [&](int i, cudaStream_t st) { k0p[i].reset(new CuCtxt); copy(*k0p[i], *k0[(i + 63) % 64], st); });
 		cXor(*k0p[63], *k0p[63], *k0[0]);
+		Pool::finish((cudaStream_t)0);
 		addKey(k0p);
 	}
 };
 
 int main(int argc, char **argv) {
-	bool checkRounds = true; int threads = 8;
+	bool checkRounds = true, async = false; int threads = 8;
 	for (int i = 1; i < argc; ++i) {
 		if (std::string(argv[i]) == "--no-round-checks") checkRounds = false;
 		else if (std::string(argv[i]) == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
+		else if (std::string(argv[i]) == "--async") async = true;
 	}
 	// the cipher itself, against the test vectors of the PRINCE paper (plaintext, k0, k1, ciphertext)
 	const u64x F = ~0ULL;
@@ -303,6 +311,7 @@ int main(int argc, char **argv) {
 		k0[i] = Evaluator::upload(dhs.encryptBit((int)((key0 >> (63 - i)) & 1), 0), 0);
 		ev.k1[i] = Evaluator::upload(dhs.encryptBit((int)((key1 >> (63 - i)) & 1), 0), 0);
 	}
+	setAsynchronous(async);
 	const auto t2 = clk::now();
 	printf("encrypted 192 bits in %.2f s\n", std::chrono::duration<double>(t2 - t1).count());
 
@@ -316,7 +325,7 @@ int main(int argc, char **argv) {
 	if (!(constant && got == want && want == 0x9fb51935fc3df524ULL)) ++failures;
 	printf("circuit: %ld cAnd, %ld relin, %ld modSwitch, final level %d\n", numAnd.load(), numRelin.load(), numModSwitch.load(), ev.level);
 	if (numAnd != 1920 || numRelin != 1152 || ev.level != 24) { printf("unexpected operation counts\n"); ++failures; }
-	printf("Prince Encryption: %.3f s on 1 GPU with %d host thread(s) (round checks excluded)\n", encSeconds, threads);
+	printf("Prince Encryption: %.3f s on 1 GPU with %d host thread(s), %s gates (round checks excluded)\n", encSeconds, threads, async ? "asynchronous" : "synchronous");
 	stopAllocator();
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;

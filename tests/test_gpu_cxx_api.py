@@ -42,10 +42,14 @@ def test_dhs_scheme_flow(params):
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
 
 
-def test_prince_known_answer():
+@pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"]],
+                         ids=["sync-8-threads", "async-4-threads", "async-1-thread"])
+def test_prince_known_answer(flags):
     """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
     reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
-    (Prince.cu:108-145) must decrypt bit for bit; 1920 cAnd / 1152 relin / depth 24 as in the reference's circuit."""
+    (Prince.cu:108-145) must decrypt bit for bit; 1920 cAnd / 1152 relin / depth 24 as in the reference's circuit.
+    Run with the reference's synchronous gate semantics on 8 host threads / streams, and with asynchronous gates
+    (setAsynchronous: stream-ordered buffers, one synchronisation per S-box) on 4 threads and on the default stream."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
@@ -54,7 +58,7 @@ def test_prince_known_answer():
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_flow")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([exe] + flags, capture_output=True, text=True, timeout=1200)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
