@@ -482,15 +482,16 @@ int init_device(int dev) {
     const Params &q = G_.prm;
     const int pnum = q.numCrtPrime, L = q.nttLen, n = q.modLen, cl = q.crtLen;
     // ---- prime tables (preload_crt_p / preload_crt_invp: cuhe/Base.cu:145-160)
-    D.maxW = q.wordsCoeff(0) + 1;
-    std::vector<u32> hp(G_.primes), he(pnum), hpow((size_t)pnum * D.maxW), hinv((size_t)pnum * (pnum - 1) / 2 + 1, 0);
+    // rows padded to a multiple of 8 words and kCrtPB zero rows appended: k_crt reads the table in unguarded blocks
+    D.maxW = (q.wordsCoeff(0) + 1 + 7) & ~7;
+    std::vector<u32> hp(G_.primes), he(pnum), hpow((size_t)(pnum + kCrtPB) * D.maxW, 0), hinv((size_t)pnum * (pnum - 1) / 2 + 1, 0);
     std::vector<u64> hpi(pnum);
     for (int i = 0; i < pnum; ++i) {
         const u32 p = hp[i];
         hpi[i] = (u64)(((host::u128)1 << 64) / p);
         he[i] = (u32)((((host::u128)1) << 64) % p);
         u64 c = 1 % p;
-        for (int k = 0; k < D.maxW; ++k) { hpow[(size_t)i * D.maxW + k] = (u32)c; c = (c << 32) % p; }
+        for (int k = 0; k <= q.wordsCoeff(0); ++k) { hpow[(size_t)i * D.maxW + k] = (u32)c; c = (c << 32) % p; }
     }
     for (int i = 1; i < pnum; ++i)                                 // cuhe/Operations.cu:91-99
         for (int j = 0; j < i; ++j) hinv[(size_t)i * (i - 1) / 2 + j] = host::invmod32(hp[i] % hp[j], hp[j]);
@@ -502,12 +503,13 @@ int init_device(int dev) {
         IcrtLevel &I = D.icrt[lvl];
         I.np = pnum - lvl; I.W = q.wordsCoeff(lvl);
         const BigU &M = G_.coeffModulus[lvl];
-        std::vector<u32> hM(I.W), hmi((size_t)I.np * I.W), hbi(I.np);
+        const int W4 = (I.W + 3) & ~3, np8 = (I.np + 7) & ~7;        // padded for k_icrt's unguarded scalar blocks
+        std::vector<u32> hM(I.W), hmi((size_t)np8 * W4, 0), hbi(I.np);
         std::vector<double> hrp(I.np);
         M.to_words(hM.data(), I.W);
         for (int i = 0; i < I.np; ++i) {
             BigU mi = M.div_small(hp[i]);
-            mi.to_words(&hmi[(size_t)i * I.W], I.W);
+            mi.to_words(&hmi[(size_t)i * W4], I.W);
             hbi[i] = host::invmod32(mi.mod_small(hp[i]), hp[i]);
             hrp[i] = 1.0 / (double)hp[i];
         }
@@ -832,7 +834,7 @@ int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st
     DevCtx &D = G_.dev[dev];
     if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
     const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)W * kCrtCoef * 4, S(st), dst, src, prime_tab(D),
+    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab(D),
                        np, W, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
@@ -1185,7 +1187,7 @@ int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0,
     if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
     DevCtx &D = G_.dev[dev];
     const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)W * kCrtCoef * 4, S(st), dst, src, prime_tab_at(D, prime0),
+    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab_at(D, prime0),
                        count, W, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;

@@ -298,39 +298,64 @@ void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W
 }
 
 // ---------------------------------------------------------------- CRT: raw -> residues (crt, Base.cu:857-879)
-// A 256-thread block owns 32 coefficients: their W words are staged through LDS (coalesced 32*W-word slab
-// load), thread (g, ci) = (tid/32, tid%32) produces the residues of coefficient ci for primes i = g mod 8:
-// residue = (sum_k word_k * (2^(32k) mod p)) mod p with a 96-bit accumulator, i.e. W multiply-adds per
-// (coefficient, prime) instead of W 64-bit `%` (the reference's Horner loop, Base.cu:866-875).
-static constexpr int kCrtCoef = 32, kCrtGroups = 8;
+// residue = (sum_k word_k * (2^(32k) mod p)) mod p with a 96-bit accumulator: W multiply-adds per (coefficient, prime)
+// instead of W 64-bit `%` (the reference's Horner loop, Base.cu:866-875).
+// Work decomposition: a 256-thread block owns 64 coefficients; their W words are staged through LDS (coalesced
+// 64*W-word slab load, transposed to [W][64]).  Wave g takes the primes i = 4g + 16t + j, j < 4, four at a time: the
+// prime index is WAVE-UNIFORM, so the powers 2^(32k) mod p_i come in through scalar loads and every multiply-add is
+// one v_mad_u64_u32 with an SGPR operand plus one carry add; a word is read from LDS once per four primes.
+static constexpr int kCrtCoef = 64, kCrtGroups = 4, kCrtPB = 4;
 __global__ __launch_bounds__(kCrtCoef * kCrtGroups)
 void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W][32]
-    constexpr int CB = kCrtCoef, NG = kCrtGroups;
-    const int ci = threadIdx.x % CB, g = threadIdx.x / CB;
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W8][64], W8 = W rounded up to 8, tail rows zero
+    constexpr int CB = kCrtCoef, NG = kCrtGroups, PB = kCrtPB;
+    const int ci = threadIdx.x % CB;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x / CB);
+    const int W8 = (W + 7) & ~7;
     const long base = (long)blockIdx.x * CB;
     const int nvalid = (int)min((long)CB, (long)mlen - base);
     const long slab = (long)nvalid * W;
+    for (int e = threadIdx.x; e < (W8 - W) * CB; e += CB * NG) sh[W * CB + e] = 0;
     for (long e = threadIdx.x; e < slab; e += CB * NG) {
         const int c2 = (int)(e / W), k = (int)(e % W);
         sh[k * CB + c2] = src[base * W + e];
     }
     __syncthreads();
     if (ci >= nvalid) return;
-    for (int i = g; i < np; i += NG) {
-        const u32 *pw = pt.pow32 + (long)i * pt.maxW;
-        u64 lo = 0; u32 hi = 0;
-        for (int k = 0; k < W; ++k) {
-            u64 pr = (u64)sh[k * CB + ci] * pw[k];
-            u64 nl = lo + pr;
-            hi += (nl < lo);
-            lo = nl;
+    // the table has maxW (a multiple of 8) words per row and kCrtPB zero rows after the last prime: no guards below
+    for (int i0 = g * PB; i0 < np; i0 += NG * PB) {
+        u64 lo[PB]; u32 hi[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) { lo[j] = 0; hi[j] = 0; }
+        const u32 *pw = pt.pow32 + (long)i0 * pt.maxW;
+        for (int k0 = 0; k0 < W8; k0 += 8) {
+            u32 c[PB][8];
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) c[j][kk] = pw[(long)j * pt.maxW + k0 + kk];   // uniform: s_load_dwordx8
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const u32 x = sh[(k0 + kk) * CB + ci];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) {
+                    const u64 nl = (u64)x * c[j][kk] + lo[j];
+                    hi[j] += (nl < lo[j]);
+                    lo[j] = nl;
+                }
+            }
         }
-        const u32 p = pt.p[i];
-        const u64 m = pt.pinv[i];
-        u32 r1 = mod_small(lo, p, m);
-        u64 r2 = (u64)hi * pt.e64[i] + r1;
-        dst[(long)i * clen + base + ci] = mod_small(r2, p, m);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int i = i0 + j;
+            if (i < np) {
+                const u32 p = pt.p[i];
+                const u64 m = pt.pinv[i];
+                const u32 r1 = mod_small(lo[j], p, m);
+                const u64 r2 = (u64)hi[j] * pt.e64[i] + r1;
+                dst[(long)i * clen + base + ci] = mod_small(r2, p, m);
+            }
+        }
     }
 }
 
@@ -341,43 +366,50 @@ void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int 
 // result exact whatever the rounding of the estimate.
 struct IcrtTab {
     const u32 *M;       // [W]
-    const u32 *mi;      // [np][W]
+    const u32 *mi;      // [np8][W4]  m_i = M / p_i, rows padded with zeros to W4 = ceil4(W), zero rows up to np8 = ceil8(np)
     const u32 *bi;      // [np]
     const double *rp;   // [np] 1/p_i
 };
-// Work decomposition: a 256-thread block owns 32 coefficients; thread (g, ci) = (tid/32, tid%32) computes the
-// residue products t_i for primes i = g mod 8 and the 96-bit column sums for output words k = g mod 8 (np
-// multiply-adds each); the 32 threads with g == 0 then ripple the carries, apply the +-M fix-up and the block
-// stores its 32*W-word slab coalesced.  (The reference runs one thread per coefficient with a 104-word
-// register array, Base.cu:884.)
-static constexpr int kIcrtCoef = 32, kIcrtGroups = 8;
+// Work decomposition: a 256-thread block owns 64 coefficients, wave g = tid/64.
+//   phase 1: wave g forms the residue products t_i = ((x_i mod p_i) b_i) mod p_i of the primes i = g mod 4 (the prime
+//            is wave-uniform: p_i, b_i, 1/p_i are scalars) into LDS and its share of alpha = sum t_i / p_i;
+//   phase 2: wave g owns the output words k = 4g + 16t + j, j < 4: the 96-bit column sums  sum_i t_i * m_i[k]  take
+//            one LDS read of t_i per FOUR multiply-adds, the m_i words arrive through scalar loads (8 primes x 4
+//            words per block, unguarded thanks to the zero padding) and a multiply-add is one v_mad_u64_u32 with an
+//            SGPR operand plus a carry add; q*M is folded in, q = floor(alpha);
+//   phase 3: wave 0 ripples the carries and applies the +-M fix-up; the block stores its 64*W-word slab coalesced.
+// (The reference runs one thread per coefficient with a 104-word register array, Base.cu:884.)
+static constexpr int kIcrtCoef = 64, kIcrtGroups = 4, kIcrtKB = 4;
 static inline size_t icrt_lds_bytes(int np, int W) {
-    return (size_t)kIcrtCoef * ((size_t)np * 4 + (size_t)W * 16 + kIcrtGroups * 8);
+    const size_t np8 = (size_t)(np + 7) & ~(size_t)7;
+    return (size_t)kIcrtCoef * (np8 * 4 + (size_t)W * 16 + kIcrtGroups * 8);
 }
 __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
             int np, int W, int mlen, int clen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char shraw[];
-    constexpr int CB = kIcrtCoef, NG = kIcrtGroups;
+    constexpr int CB = kIcrtCoef, NG = kIcrtGroups, KB = kIcrtKB;
+    const int np8 = (np + 7) & ~7, W4 = (W + 3) & ~3;
     u64 *colLo = reinterpret_cast<u64 *>(shraw);                         // [W][CB]
     double *alphaP = reinterpret_cast<double *>(colLo + (size_t)W * CB); // [NG][CB]
     int *colHi = reinterpret_cast<int *>(alphaP + NG * CB);              // [W][CB]
-    u32 *tt = reinterpret_cast<u32 *>(colHi + (size_t)W * CB);           // [np][CB]
-    const int ci = threadIdx.x % CB, g = threadIdx.x / CB;
+    u32 *tt = reinterpret_cast<u32 *>(colHi + (size_t)W * CB);           // [np8][CB]; reused for the result words
+    const int ci = threadIdx.x % CB;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x / CB);
     const long base = (long)blockIdx.x * CB;
     const int nvalid = (int)min((long)CB, (long)mlen - base);
     const bool live = ci < nvalid;
     double a = 0.0;
-    for (int i = g; i < np; i += NG) {
+    for (int i = g; i < np8; i += NG) {
         u32 v = 0;
-        if (live) {
+        if (live && i < np) {
             const u32 p = pt.p[i];
             const u64 m = pt.pinv[i];
-            u32 x = mod_small(src[(long)i * clen + base + ci], p, m);
+            const u32 x = mod_small(src[(long)i * clen + base + ci], p, m);
             v = mod_small((u64)x * it.bi[i], p, m);
+            a += (double)v * it.rp[i];
         }
         tt[i * CB + ci] = v;
-        a += (double)v * it.rp[i];
     }
     alphaP[g * CB + ci] = a;
     __syncthreads();
@@ -385,21 +417,39 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
 #pragma unroll
     for (int gg = 0; gg < NG; ++gg) alpha += alphaP[gg * CB + ci];
     const u32 q = (u32)alpha;            // floor; may be off by one either way -> fixed below
-    for (int k = g; k < W; k += NG) {
-        u64 lo = 0; u32 hi = 0;
-        for (int i = 0; i < np; ++i) {
-            u64 pr = (u64)tt[i * CB + ci] * it.mi[(long)i * W + k];
-            u64 nl = lo + pr;
-            hi += (nl < lo);
-            lo = nl;
+    for (int k0 = g * KB; k0 < W; k0 += NG * KB) {
+        u64 lo[KB]; u32 hi[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) { lo[j] = 0; hi[j] = 0; }
+        for (int i0 = 0; i0 < np8; i0 += 8) {
+            u32 c[8][KB];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                for (int j = 0; j < KB; ++j) c[ii][j] = it.mi[(long)(i0 + ii) * W4 + k0 + j];      // uniform: s_load_dwordx4
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const u32 t = tt[(i0 + ii) * CB + ci];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const u64 nl = (u64)t * c[ii][j] + lo[j];
+                    hi[j] += (nl < lo[j]);
+                    lo[j] = nl;
+                }
+            }
         }
-        const u64 qm = (u64)q * it.M[k];
-        int h = (int)hi - (lo < qm);
-        colLo[k * CB + ci] = lo - qm;
-        colHi[k * CB + ci] = h;          // column value = lo + h * 2^64, h may be -1
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int k = k0 + j;
+            if (k < W) {
+                const u64 qm = (u64)q * it.M[k];
+                colLo[k * CB + ci] = lo[j] - qm;
+                colHi[k * CB + ci] = (int)hi[j] - (lo[j] < qm);      // column value = lo + h * 2^64, h may be -1
+            }
+        }
     }
     __syncthreads();
-    u32 *out = tt + (size_t)np * CB;               // [W][CB] result words
+    u32 *out = tt;                                   // [W][CB] result words (the t_i are no longer needed; W <= np8 + 8)
     if (g == 0) {
         typedef __int128 i128;
         i128 carry = 0;
