@@ -57,6 +57,9 @@ struct NttTab {
 struct Workspace {
     u64 *slab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // pass-1 -> pass-2 slabs per length
     size_t slab_bytes[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    size_t n_barrett = 0, n_alias = 0, n_relin = 0;     // rows / elements the buffers below currently hold
+    // scratch of the batched multiply + relinearise (cuhe_hip_mul_relin_batch), sized by the largest batch seen
+    u64 *bt_ntt = nullptr; u32 *bt_crt = nullptr, *bt_raw = nullptr; size_t n_bt = 0;
     u64 *b_ntt = nullptr;                // Barrett scratch (cuhe/Operations.cu:196-209)
     u32 *b_mq = nullptr, *b_crt = nullptr;  // q (at offset n) and (m - x^n) q
     u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
@@ -175,15 +178,35 @@ int ws_buffer(T **ptr, size_t count) {           // lazily allocated, fixed-size
     if (!*ptr) HIPCHK(hipMalloc((void **)ptr, std::max<size_t>(count, 1) * sizeof(T)));
     return CUHE_OK;
 }
-int ws_barrett(Workspace &w) {
-    const Params &q = G_.prm;
-    const size_t rows = (size_t)q.numCrtPrime * q.nttLen;
-    CHK(ws_buffer(&w.b_mq, rows)); CHK(ws_buffer(&w.b_crt, rows)); CHK(ws_buffer(&w.b_ntt, rows)); CHK(ws_buffer(&w.hold, rows));
+template <typename T>
+int ws_grow(T **ptr, size_t *have, size_t count) {           // grow-only (re-allocation synchronises: sizes settle at once)
+    if (*have >= count && *ptr) return CUHE_OK;
+    if (*ptr) HIPCHK(hipFree(*ptr));
+    *ptr = nullptr; *have = 0;
+    HIPCHK(hipMalloc((void **)ptr, std::max<size_t>(count, 1) * sizeof(T)));
+    *have = count;
     return CUHE_OK;
 }
-int ws_relin(Workspace &w) {
+// Barrett / inttResult scratch for `rows` polynomial rows (at least one level-0 ciphertext)
+int ws_barrett(Workspace &w, int rows = 0) {
     const Params &q = G_.prm;
-    CHK(ws_buffer(&w.relin, (size_t)q.numEvalKey * q.nttLen)); CHK(ws_buffer(&w.win, (size_t)q.numEvalKey * q.crtLen));
+    const size_t need = (size_t)std::max(rows, q.numCrtPrime);
+    if (w.n_barrett >= need && w.hold) return CUHE_OK;
+    size_t a = 0, b = 0, c = 0, d = 0;
+    CHK(ws_grow(&w.b_mq, &a, need * q.nttLen)); CHK(ws_grow(&w.b_crt, &b, need * q.nttLen));
+    CHK(ws_grow(&w.b_ntt, &c, need * q.nttLen)); CHK(ws_grow(&w.hold, &d, need * q.nttLen));
+    w.n_barrett = need;
+    return CUHE_OK;
+}
+// window rows and their transforms for `cts` ciphertexts
+int ws_relin(Workspace &w, int cts = 1) {
+    const Params &q = G_.prm;
+    if (w.n_relin >= (size_t)cts && w.relin) return CUHE_OK;
+    size_t a = 0, b = 0;
+    if (w.relin) { HIPCHK(hipFree(w.relin)); w.relin = nullptr; }
+    if (w.win) { HIPCHK(hipFree(w.win)); w.win = nullptr; }
+    CHK(ws_grow(&w.relin, &a, (size_t)cts * q.numEvalKey * q.nttLen)); CHK(ws_grow(&w.win, &b, (size_t)cts * q.numEvalKey * q.crtLen));
+    w.n_relin = cts;
     return CUHE_OK;
 }
 int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        // grow-only
@@ -198,7 +221,7 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 }
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
-    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win};
+    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     delete w;
@@ -306,12 +329,13 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, lon
 int g_pass2_form = 1;        // 0: 64 values per thread (ntt_pass2), 1: wave-split 16 x 4 (ntt_pass2w)
 template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
-                 const u64 *pinv, int prime0, hipStream_t st) {
+                 const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0) {
     constexpr int N1 = (1 << LG) / 64;
+    if (np_mod > 0 && g_pass2_form != 1) return fail(CUHE_EINVAL, "batched ciphertext operations need the wave-split pass 2");
     if (g_pass2_form == 1) {
         const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
         hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
-                           (OUT == kOutModP || OUT == kOutModPFoldXn1) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0);
+                           (OUT == kOutModP || OUT == kOutModPFoldXn1) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod);
     } else if constexpr (OUT == kOutU64Mul) {
         return fail(CUHE_EINVAL, "the fused table multiply exists in the wave-split pass 2 only");
     } else {
@@ -334,7 +358,7 @@ struct EvTimer {                 // optional per-pass hipEvent timing (bench)
 // one batched transform, chunked so that the pass-1 -> pass-2 slab stays cache resident
 template <int LG>
 int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab) {
+               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod) {
     constexpr int L = 1 << LG;
     NttTab &tab = D.ntt[LG - 14];
     const int chunk = tab.chunk;
@@ -372,11 +396,11 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU64Neg) {
             u32 *d = (u32 *)dst + (long)b0 * dst_stride;
-            if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2)));
-            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2)));
+            if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, np_mod)));
+            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, mul_tab, prime0 + b0, q2)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, mul_tab, prime0 + b0, q2, np_mod)));
             else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
@@ -387,16 +411,16 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
 }
 
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr) {
+            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr, int np_mod = 0) {
     if (batch <= 0) return CUHE_OK;
     CHK(ensure_ntt(dev, len, batch));
     DevCtx &D = G_.dev[dev];
     Workspace *W = nullptr;
     CHK(workspace(dev, st, &W));
     switch (len) {
-        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab);
-        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab);
-        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab);
+        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod);
+        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod);
+        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod);
     }
 }
 
@@ -424,19 +448,20 @@ PrimeTab prime_tab_at(const DevCtx &D, int prime0) {
 }
 
 // reduction modulo the polynomial modulus of rows belonging to primes [prime0, prime0+np)
-int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStream_t st) {
+// np_mod > 0: `np` rows = several ciphertexts of the same np_mod primes (prime0 must be 0)
+int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStream_t st, int np_mod = 0) {
     const Params &q = G_.prm;
     DevCtx &D = G_.dev[dev];
     const int n = q.modLen, L = q.nttLen, cl = q.crtLen;
     PrimeTab pt = prime_tab_at(D, prime0);
     const int kind = G_.force_generic ? 0 : G_.reduce_kind;
     if (kind == 1) {
-        hipLaunchKernelGGL((k_reduce_special<0>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L);
+        hipLaunchKernelGGL((k_reduce_special<0>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L, np_mod);
         HIPCHK(hipGetLastError());
         return CUHE_OK;
     }
     if (kind == 2) {
-        hipLaunchKernelGGL((k_reduce_special<1>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L);
+        hipLaunchKernelGGL((k_reduce_special<1>), dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, pt, n, cl, L, np_mod);
         HIPCHK(hipGetLastError());
         return CUHE_OK;
     }
@@ -454,24 +479,25 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
     WindowArgs wa{0, 0, 0};
     Workspace *Wp = nullptr;
     CHK(workspace(dev, st, &Wp));
-    CHK(ws_barrett(*Wp));
+    CHK(ws_barrett(*Wp, np));
     Workspace &Ws = *Wp;
     const bool fuse_mul = g_pass2_form == 1;
+    if (np_mod > 0 && (!fuse_mul || prime0 != 0)) return fail(CUHE_EINVAL, "batched reduction needs the wave-split pass 2 and a whole level");
     const size_t rows = (size_t)np * L;
     if (dst < src + rows && src < dst + (size_t)np * cl) {      // result rows would overwrite input rows still to be read
-        CHK(ws_buffer(&Ws.b_alias, (size_t)G_.prm.numCrtPrime * L));
+        CHK(ws_grow(&Ws.b_alias, &Ws.n_alias, rows));
         HIPCHK(hipMemcpyAsync(Ws.b_alias, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
         src = Ws.b_alias;
     }
     const long pairs = (long)rows / 2;
     const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
-    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, src + (n - 1), np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? u_ntt : nullptr));   // (f >> (n-1)) * u
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, src + (n - 1), np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? u_ntt : nullptr, np_mod));   // (f >> (n-1)) * u
     if (!fuse_mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, u_ntt, pairs);
-    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));                  // q at [n, 2n-1)
-    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? m_ntt : nullptr));     // q * (m - x^n)
+    CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st, nullptr, nullptr, np_mod));    // q at [n, 2n-1)
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? m_ntt : nullptr, np_mod));     // q * (m - x^n)
     if (!fuse_mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, m_ntt, pairs);
-    CHK(run_ntt(L, kSrcU64Neg, Ws.b_mq, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st));
-    hipLaunchKernelGGL(k_barrett_final, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, Ws.b_crt, Ws.b_mq, m_crt, pt, n, cl, L);
+    CHK(run_ntt(L, kSrcU64Neg, Ws.b_mq, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st, nullptr, nullptr, np_mod));
+    hipLaunchKernelGGL(k_barrett_final, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, Ws.b_crt, Ws.b_mq, m_crt, pt, n, cl, L, np_mod);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -858,7 +884,7 @@ int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *s
         }
     }
     hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef), dim3(kIcrtCoef * kIcrtGroups), lds, S(st), dst,
-                       src, prime_tab(D), it, np, W, q.modLen, q.crtLen);
+                       src, prime_tab(D), it, np, W, q.modLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -1137,17 +1163,88 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     // window rows once (coalesced), then k plain zero-padded transforms (replaces k strided window loads)
     const int W = q.wordsCoeff(lvl);
     hipLaunchKernelGGL(k_extract_windows, dim3((q.crtLen + kWinCoef - 1) / kWinCoef), dim3(kWinCoef * kWinGroups),
-                       (size_t)W * kWinCoef * 4, S(st), Wp->win, src, W, q.logRelin, k, q.crtLen, q.crtLen);
+                       (size_t)W * kWinCoef * 4, S(st), Wp->win, src, W, q.logRelin, k, q.crtLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
     CHK(run_ntt(L, kSrcU32Ext, Wp->relin, Wp->win, k, q.crtLen, L, L, 0, WindowArgs{0, 0, 0}, dev, S(st)));
     constexpr int PB = 4;
-    hipLaunchKernelGGL((k_relin_mac<PB>), dim3(L / 512, (count + PB - 1) / PB), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
-                       D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count);
+    hipLaunchKernelGGL((k_relin_mac<PB, 1>), dim3(L / 512, (count + PB - 1) / PB, 1), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
+                       D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
     return relin_range(dst, src, lvl, 0, G_.prm.numCrtPrimeAt(lvl < 0 ? 0 : lvl), dev, st);
+}
+
+// ---------------------------------------------------------------- batched multiply + relinearise
+// `batch` independent (cAnd ; relin) chains of one level in a single call: NTT-domain operands a, b as
+// u64[batch][np][L], reduced CRT-domain results as u32[batch][np][crtLen].  Same arithmetic as `batch` calls of
+// ntt_mul, intt_mod, icrt, relinearization, intt_mod; what changes is the shape of the work: every stage runs once
+// over batch*np (or batch*k) rows -- several hundred workgroups instead of a few dozen, so the transforms leave their
+// latency floor (profiles/r01_small_batch_latency.txt) -- and the inner product fetches each key value once for
+// kMacBB ciphertexts.  The reference has no batched form: its circuits issue ciphertext operations one at a time.
+int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int batch, int dev, void *st_) {
+    CHK(need_init(dev));
+    if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
+    if (g_pass2_form != 1) return fail(CUHE_EINVAL, "batched operations need the wave-split pass 2");
+    hipStream_t st = S(st_);
+    DevCtx &D = G_.dev[dev];
+    const int np = q.numCrtPrimeAt(lvl), k = q.numEvalKeyAt(lvl), W = q.wordsCoeff(lvl), L = q.nttLen, cl = q.crtLen;
+    const int rows = batch * np;
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, st, &Wp));
+    Workspace &Ws = *Wp;
+    if (Ws.n_bt < (size_t)batch) {
+        size_t x = 0, y = 0, z = 0;
+        if (Ws.bt_ntt) { HIPCHK(hipFree(Ws.bt_ntt)); Ws.bt_ntt = nullptr; }
+        if (Ws.bt_crt) { HIPCHK(hipFree(Ws.bt_crt)); Ws.bt_crt = nullptr; }
+        if (Ws.bt_raw) { HIPCHK(hipFree(Ws.bt_raw)); Ws.bt_raw = nullptr; }
+        CHK(ws_grow(&Ws.bt_ntt, &x, (size_t)batch * q.numCrtPrime * L));
+        CHK(ws_grow(&Ws.bt_crt, &y, (size_t)batch * q.numCrtPrime * cl));
+        CHK(ws_grow(&Ws.bt_raw, &z, (size_t)batch * q.rawLen * q.wordsCoeff(0)));
+        Ws.n_bt = batch;
+    }
+    CHK(ws_relin(Ws, batch));
+    const bool fused = fused_xn1();
+    if (!fused) CHK(ws_barrett(Ws, rows));
+    // reduction of `rows` NTT-domain product rows to CRT rows (n2c with isProd, CuHE.cu:398-408)
+    auto reduce_rows = [&](u32 *out, const u64 *in) -> int {
+        if (fused) return run_ntt(L, kSrcU64Neg, out, in, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np);
+        CHK(run_ntt(L, kSrcU64Neg, Ws.hold, in, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
+        return barrett_impl(out, Ws.hold, 0, rows, dev, st, np);
+    };
+    // 1. pointwise products
+    {
+        const long pairs = (long)rows * L / 2;
+        const int grid = (int)std::min<long>((pairs + 255) / 256, 65535L * 16);
+        hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, st, Ws.bt_ntt, (const u64 *)a, (const u64 *)b, pairs);
+    }
+    // 2. x2r: INTT + reduction, then ICRT of every ciphertext
+    CHK(reduce_rows(Ws.bt_crt, Ws.bt_ntt));
+    if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(Ws.bt_raw, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
+    {
+        const IcrtLevel &I = D.icrt[lvl];
+        IcrtTab it{I.M, I.mi, I.bi, I.rp};
+        const size_t lds = icrt_lds_bytes(np, W);
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, Ws.bt_raw,
+                           Ws.bt_crt, prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
+    }
+    // 3. windows of every ciphertext and their transforms: batch*k rows
+    hipLaunchKernelGGL(k_extract_windows, dim3((cl + kWinCoef - 1) / kWinCoef, batch), dim3(kWinCoef * kWinGroups), (size_t)W * kWinCoef * 4, st,
+                       Ws.win, Ws.bt_raw, W, q.logRelin, k, cl, cl, (long)q.rawLen * W, (long)k * cl);
+    HIPCHK(hipGetLastError());
+    CHK(run_ntt(L, kSrcU32Ext, Ws.relin, Ws.win, batch * k, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));
+    // 4. key-switch inner products: a key value fetched once serves kMacBB ciphertexts
+    constexpr int PB = 4, BB = 2;
+    hipLaunchKernelGGL((k_relin_mac<PB, BB>), dim3(L / 512, (np + PB - 1) / PB, (batch + BB - 1) / BB), dim3(256), 0, st, Ws.bt_ntt, Ws.relin,
+                       D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
+    HIPCHK(hipGetLastError());
+    // 5. n2c of the sums
+    return reduce_rows(dst, Ws.bt_ntt);
 }
 
 // ---------------------------------------------------------------- CRT-prime-sharded variants

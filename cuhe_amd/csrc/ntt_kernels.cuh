@@ -250,7 +250,9 @@ template <int LG, int OUT>
 __global__ __launch_bounds__(256, 4)
 void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
                 long dst_stride, int nbatch, int nstore,
-                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
+                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod) {
+    // np_mod > 0: the rows are several ciphertexts' worth of the same np_mod primes (batched operations); row r of the
+    // whole call belongs to prime r mod np_mod and prime0 carries the row offset of this launch
     constexpr int L = 1 << LG, N1 = L / 64;
     constexpr bool INV = (OUT == kOutModP || OUT == kOutModPFoldXn1);
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -280,7 +282,8 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
     __syncthreads();
     const int w = r;
     u32 p = 0; u64 m = 0;
-    if constexpr (INV) { p = primes[prime0 + batch]; m = pinv[prime0 + batch]; }
+    const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
+    if constexpr (INV) { p = primes[pidx]; m = pinv[pidx]; }
     const int k2full = INV ? nstore / N1 : 64, rem = INV ? nstore % N1 : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -295,7 +298,7 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
             for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(y[bitrev<4>(c)], &dst[(long)(b + 16 * c) * N1]);
         } else if constexpr (OUT == kOutU64Mul) {
             u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
-            const u64 *tab = pinv + (long)(prime0 + batch) * L + k1;
+            const u64 *tab = pinv + (long)pidx * L + k1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const long o = (long)(b + 16 * c) * N1;

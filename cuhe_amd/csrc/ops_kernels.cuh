@@ -155,11 +155,12 @@ void k_gather_rows(u32 *__restrict__ dst, const u32 *__restrict__ src, int clen,
 // does not contribute, and the reference's correction subtracts m once more when the coefficient of x^n is non-zero.
 __global__ __launch_bounds__(256)
 void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32 *__restrict__ qrow, const u32 *__restrict__ mq,
-                     const u32 *__restrict__ m_crt, PrimeTab pt, int mlen, int clen, int nlen) {
+                     const u32 *__restrict__ m_crt, PrimeTab pt, int mlen, int clen, int nlen, int np_mod) {
     const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= clen) return;
     const long base = (long)crt * nlen;
-    const u32 p = pt.p[crt];
+    const int pi = np_mod > 0 ? crt % np_mod : crt;          // batched calls: row -> prime
+    const u32 p = pt.p[pi];
     u32 r = 0;
     if (idx < mlen) {
         u32 a = f[base + idx], b = mq[base + idx];
@@ -169,7 +170,7 @@ void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32
         t = t >= q0 ? t - q0 : t + p - q0;
         t = t >= b2 ? t - b2 : t + p - b2;
         if (t != 0 && idx < mlen - 1) {
-            const u32 s = m_crt[(long)crt * clen + idx];
+            const u32 s = m_crt[(long)pi * clen + idx];
             r = r >= s ? r - s : r + p - s;
         }
     }
@@ -183,11 +184,11 @@ void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32
 // Both give the same residues as the NTT-based Barrett of Operations.cu:460-501.
 template <int KIND>   // 0: x^n+1 ; 1: prime m
 __global__ __launch_bounds__(256)
-void k_reduce_special(u32 *__restrict__ dst, const u32 *__restrict__ f, PrimeTab pt, int n, int clen, int nlen) {
+void k_reduce_special(u32 *__restrict__ dst, const u32 *__restrict__ f, PrimeTab pt, int n, int clen, int nlen, int np_mod) {
     const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= clen) return;
     const u32 *row = f + (long)crt * nlen;
-    const u32 p = pt.p[crt];
+    const u32 p = pt.p[np_mod > 0 ? crt % np_mod : crt];
     u32 r = 0;
     if (idx < n) {
         if (KIND == 0) {
@@ -229,44 +230,57 @@ __device__ __forceinline__ u64 fold192(u64 lo, u64 hi, u32 top) {
     u64 t = (u64)top << 32;             // top < 2^8: canonical
     return subp(r, t);
 }
-// Two adjacent coefficients per thread (16 B/lane loads) and PB primes per block: every window value c[j][idx]
-// fetched once serves PB key streams, so the cache-resident operand costs 1/PB of the HBM key traffic
-// (8*k*L key bytes per prime are the algorithmic bytes of this kernel).
-template <int PB>
+// Two adjacent coefficients per thread (16 B/lane loads), PB primes and BB ciphertexts per block: every window value
+// c[b][j][idx] fetched once serves PB key streams (the cache-resident operand costs 1/PB of the HBM key traffic), and
+// in a batched call every key value fetched once serves BB ciphertexts (8*k*L key bytes per prime are the algorithmic
+// bytes of ONE relinearisation; a batch of B shares them).  blockIdx.z = group of BB ciphertexts.
+template <int PB, int BB>
 __global__ __launch_bounds__(256)
 void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
-                 int k, long ek_prime_stride, int L, int np) {
+                 int k, long ek_prime_stride, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts) {
+    const int b0 = blockIdx.z * BB;
     const int i0 = blockIdx.y * PB;
     const int idx2 = blockIdx.x * blockDim.x + threadIdx.x;    // pair index; L/2 is a multiple of 256
     const long L2 = L / 2;
-    const u64x2 *cc = reinterpret_cast<const u64x2 *>(c) + idx2;
+    const u64x2 *cc[BB];
+#pragma unroll
+    for (int b = 0; b < BB; ++b) cc[b] = reinterpret_cast<const u64x2 *>(c + (long)min(b0 + b, ncts - 1) * c_ct_stride) + idx2;
     const u64x2 *e[PB];
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const int i = min(i0 + q, np - 1);                     // clamp: tail block recomputes the last prime
         e[q] = reinterpret_cast<const u64x2 *>(ek + (long)i * ek_prime_stride) + idx2;
     }
-    u64 lo0[PB], hi0[PB], lo1[PB], hi1[PB]; u32 top0[PB], top1[PB];
+    u64 lo0[BB][PB], hi0[BB][PB], lo1[BB][PB], hi1[BB][PB]; u32 top0[BB][PB], top1[BB][PB];
 #pragma unroll
-    for (int q = 0; q < PB; ++q) { lo0[q] = hi0[q] = lo1[q] = hi1[q] = 0; top0[q] = top1[q] = 0; }
+    for (int b = 0; b < BB; ++b)
+#pragma unroll
+        for (int q = 0; q < PB; ++q) { lo0[b][q] = hi0[b][q] = lo1[b][q] = hi1[b][q] = 0; top0[b][q] = top1[b][q] = 0; }
     for (int j = 0; j < k; ++j) {
-        const u64x2 a = cc[(long)j * L2];
+        u64x2 a[BB];
+#pragma unroll
+        for (int b = 0; b < BB; ++b) a[b] = cc[b][(long)j * L2];
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
-            const u64x2 b = __builtin_nontemporal_load(&e[q][(long)j * L2]);
-            mac192(a.x, b.x, lo0[q], hi0[q], top0[q]);
-            mac192(a.y, b.y, lo1[q], hi1[q], top1[q]);
+            const u64x2 kv = __builtin_nontemporal_load(&e[q][(long)j * L2]);
+#pragma unroll
+            for (int b = 0; b < BB; ++b) {
+                mac192(a[b].x, kv.x, lo0[b][q], hi0[b][q], top0[b][q]);
+                mac192(a[b].y, kv.y, lo1[b][q], hi1[b][q], top1[b][q]);
+            }
         }
     }
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-        if (i0 + q < np) {
-            u64x2 r;
-            r.x = fold192(lo0[q], hi0[q], top0[q]);
-            r.y = fold192(lo1[q], hi1[q], top1[q]);
-            reinterpret_cast<u64x2 *>(dst + (long)(i0 + q) * L)[idx2] = r;
+    for (int b = 0; b < BB; ++b)
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            if (i0 + q < np && b0 + b < ncts) {
+                u64x2 r;
+                r.x = fold192(lo0[b][q], hi0[b][q], top0[b][q]);
+                r.y = fold192(lo1[b][q], hi1[b][q], top1[b][q]);
+                reinterpret_cast<u64x2 *>(dst + (long)(b0 + b) * dst_ct_stride + (long)(i0 + q) * L)[idx2] = r;
+            }
         }
-    }
 }
 
 // ---------------------------------------------------------------- relinearisation windows
@@ -275,7 +289,10 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
 // compact u32 array (the reference re-reads the W-word coefficients with stride W for every window).
 static constexpr int kWinCoef = 64, kWinGroups = 4;
 __global__ __launch_bounds__(kWinCoef * kWinGroups)
-void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W, int w, int k, int ncoef, int clen) {
+void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W, int w, int k, int ncoef, int clen,
+                       long raw_ct_stride, long win_ct_stride) {
+    raw += (long)blockIdx.y * raw_ct_stride;         // blockIdx.y: ciphertext of a batched call
+    win += (long)blockIdx.y * win_ct_stride;
     extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W][64]
     constexpr int CB = kWinCoef, NG = kWinGroups;
     const int ci = threadIdx.x % CB, g = threadIdx.x / CB;
@@ -386,7 +403,9 @@ static inline size_t icrt_lds_bytes(int np, int W) {
 }
 __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
-            int np, int W, int mlen, int clen) {
+            int np, int W, int mlen, int clen, long src_ct_stride, long dst_ct_stride) {
+    src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: ciphertext of a batched call (strides in words)
+    dst += (long)blockIdx.y * dst_ct_stride;
     extern __shared__ __attribute__((aligned(16))) unsigned char shraw[];
     constexpr int CB = kIcrtCoef, NG = kIcrtGroups, KB = kIcrtKB;
     const int np8 = (np + 7) & ~7, W4 = (W + 3) & ~3;

@@ -143,6 +143,12 @@ int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void 
 int cuhe_hip_init_relin(const uint32_t *evalkey_raw_host);
 /* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst ntt u64[np][nttLen] */
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
+/* `batch` independent (cAnd ; CuCtxt::relin) chains of one level in one call (CuHE.cu:101,570-581 issue them one
+   ciphertext at a time): a, b = NTT-domain operands u64[batch][np][nttLen], dst = reduced CRT-domain results
+   u32[batch][np][crtLen], np = primes of `lvl`.  Bit-identical to the single-ciphertext sequence
+   ntt_mul, intt_mod, icrt, relinearization, intt_mod; every stage runs over batch*np rows and the key-switch inner
+   product reads each key value once per two ciphertexts. */
+int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a_ntt, const uint64_t *b_ntt, int lvl, int batch, int dev, void *stream);
 /* binary evaluation-key cache: the NTT-domain keys initRelinearization computes (u64[prime][key][nttLen],
    Relinearization.cu:45-55) behind a 96-byte header naming the parameter set and the CRT primes; import refuses
    an image made for other parameters / primes or with a damaged payload.  cache_size = 0 before init. */

@@ -649,3 +649,39 @@ def test_config4_relin_structured_keys_vs_python(gu):
             assert np.array_equal(got, want), lvl
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 25, 25, 21845)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "prince_ring-generic"])
+def test_mul_relin_batch_equals_single(gu, args):
+    """cuhe_hip_mul_relin_batch (B independent cAnd + relin chains in one call: batch*np rows per stage, key values
+    shared by two ciphertexts in the inner product) is bit-identical to B single-ciphertext sequences, which the other
+    tests pin to the oracle; odd batch sizes exercise the tail of the ciphertext blocking, level 1 the prime tables."""
+    import oracle_lib as O
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE200 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        g.init_relin(ek_raw)
+        for lvl, B in ((0, 1), (0, 3), (1, 5)):
+            npr = o.np_(lvl)
+            a = [_rand_crt(o, npr, 3000 + 10 * lvl + i) for i in range(B)]
+            b = [_rand_crt(o, npr, 4000 + 10 * lvl + i) for i in range(B)]
+            single = [g.mul_relin_crt(a[i], b[i], lvl) for i in range(B)]
+            if B == 1:
+                assert np.array_equal(single[0], o.mul_relin_crt(a[0], b[0], lvl, ek))      # the anchor itself, once
+            na = gu.empty_u64(B * npr, q.nttLen); nb = gu.empty_u64(B * npr, q.nttLen)
+            for i in range(B):
+                gu.ck(gu.lib.cuhe_hip_ntt(na[i * npr:].data_ptr(), gu.to_dev(a[i]).data_ptr(), o.logq(lvl), 0, None))
+                gu.ck(gu.lib.cuhe_hip_ntt(nb[i * npr:].data_ptr(), gu.to_dev(b[i]).data_ptr(), o.logq(lvl), 0, None))
+            out = gu.empty_u32(B * npr, q.crtLen)
+            gu.ck(gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, B, 0, None))
+            got = gu.host_u32(out).reshape(B, npr, q.crtLen)
+            for i in range(B):
+                assert np.array_equal(got[i], single[i]), (lvl, B, i)
+        assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, 0, 0, None) != 0      # batch < 1
+        assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 99, 1, 0, None) != 0     # bad level
+    finally:
+        g.close(); o.close()
