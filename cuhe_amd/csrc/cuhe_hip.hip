@@ -1167,7 +1167,7 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     HIPCHK(hipGetLastError());
     CHK(run_ntt(L, kSrcU32Ext, Wp->relin, Wp->win, k, q.crtLen, L, L, 0, WindowArgs{0, 0, 0}, dev, S(st)));
     constexpr int PB = 4;
-    hipLaunchKernelGGL((k_relin_mac<PB, 1>), dim3(L / 512, (count + PB - 1) / PB, 1), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
+    hipLaunchKernelGGL((k_relin_mac<PB, 1>), dim3((L / 512) * ((count + PB - 1) / PB), 1, 1), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
                        D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
@@ -1182,7 +1182,7 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 // ntt_mul, intt_mod, icrt, relinearization, intt_mod; what changes is the shape of the work: every stage runs once
 // over batch*np (or batch*k) rows -- several hundred workgroups instead of a few dozen, so the transforms leave their
 // latency floor (profiles/r01_small_batch_latency.txt) -- and the inner product fetches each key value once for
-// kMacBB ciphertexts.  The reference has no batched form: its circuits issue ciphertext operations one at a time.
+// four ciphertexts.  The reference has no batched form: its circuits issue ciphertext operations one at a time.
 int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int batch, int dev, void *st_) {
     CHK(need_init(dev));
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
@@ -1238,10 +1238,13 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
                        Ws.win, Ws.bt_raw, W, q.logRelin, k, cl, cl, (long)q.rawLen * W, (long)k * cl);
     HIPCHK(hipGetLastError());
     CHK(run_ntt(L, kSrcU32Ext, Ws.relin, Ws.win, batch * k, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));
-    // 4. key-switch inner products: a key value fetched once serves kMacBB ciphertexts
-    constexpr int PB = 4, BB = 2;
-    hipLaunchKernelGGL((k_relin_mac<PB, BB>), dim3(L / 512, (np + PB - 1) / PB, (batch + BB - 1) / BB), dim3(256), 0, st, Ws.bt_ntt, Ws.relin,
-                       D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
+    // 4. key-switch inner products: a key value fetched once serves four ciphertexts
+    // 2 primes x 4 ciphertexts per workgroup: a key value fetched from HBM serves four ciphertexts.  Measured at
+    // batch 8 of config 4 (profiles/r01_experiments_log.txt): 4x2 0.387, 2x2 0.360, 2x4 0.336, 2x4 XCD-aware 0.326, 1x8 0.404 ms
+    // per ciphertext; the kernel stays bound by the traffic between the L2s and the fabric in every blocking.
+    constexpr int PB = 2, BB = 4;
+    hipLaunchKernelGGL((k_relin_mac<PB, BB, 1>), dim3((L / 512) * ((np + PB - 1) / PB), 1, (batch + BB - 1) / BB), dim3(256), 0, st,
+                       Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
     HIPCHK(hipGetLastError());
     // 5. n2c of the sums
     return reduce_rows(dst, Ws.bt_ntt);

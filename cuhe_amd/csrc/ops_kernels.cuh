@@ -234,13 +234,27 @@ __device__ __forceinline__ u64 fold192(u64 lo, u64 hi, u32 top) {
 // c[b][j][idx] fetched once serves PB key streams (the cache-resident operand costs 1/PB of the HBM key traffic), and
 // in a batched call every key value fetched once serves BB ciphertexts (8*k*L key bytes per prime are the algorithmic
 // bytes of ONE relinearisation; a batch of B shares them).  blockIdx.z = group of BB ciphertexts.
-template <int PB, int BB>
+// blockIdx.x enumerates (column tile, prime block) pairs.  MAP 0: column tile fastest (a prime block's key rows are
+// streamed in address order).  MAP 1, used by the batched call: workgroup ids go round-robin over the 8 XCDs, so
+// id % 8 picks the XCD, and within an XCD the prime block varies fastest for a fixed column tile, which keeps the
+// window tile (BB * k * 512 columns * 8 B) in that XCD's L2 for its np/PB consecutive prime blocks.
+template <int PB, int BB, int MAP = 0>
 __global__ __launch_bounds__(256)
 void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
                  int k, long ek_prime_stride, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts) {
     const int b0 = blockIdx.z * BB;
-    const int i0 = blockIdx.y * PB;
-    const int idx2 = blockIdx.x * blockDim.x + threadIdx.x;    // pair index; L/2 is a multiple of 256
+    const int ny = (np + PB - 1) / PB;
+    int xt, i0;
+    if constexpr (MAP == 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;    // gridDim.x = (L/512) * ny, L/512 a multiple of 8
+        xt = (slot / ny) * 8 + xcd;                                // column tile
+        i0 = (slot % ny) * PB;
+    } else {
+        const int nx = gridDim.x / ny;
+        xt = blockIdx.x % nx;                                      // column tile fastest, then prime block
+        i0 = (blockIdx.x / nx) * PB;
+    }
+    const int idx2 = xt * blockDim.x + threadIdx.x;            // pair index; L/2 is a multiple of 256
     const long L2 = L / 2;
     const u64x2 *cc[BB];
 #pragma unroll

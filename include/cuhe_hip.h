@@ -147,7 +147,7 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
    ciphertext at a time): a, b = NTT-domain operands u64[batch][np][nttLen], dst = reduced CRT-domain results
    u32[batch][np][crtLen], np = primes of `lvl`.  Bit-identical to the single-ciphertext sequence
    ntt_mul, intt_mod, icrt, relinearization, intt_mod; every stage runs over batch*np rows and the key-switch inner
-   product reads each key value once per two ciphertexts. */
+   product reads each key value once per four ciphertexts. */
 int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a_ntt, const uint64_t *b_ntt, int lvl, int batch, int dev, void *stream);
 /* binary evaluation-key cache: the NTT-domain keys initRelinearization computes (u64[prime][key][nttLen],
    Relinearization.cu:45-55) behind a 96-byte header naming the parameter set and the CRT primes; import refuses

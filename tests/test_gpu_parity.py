@@ -655,7 +655,7 @@ def test_config4_relin_structured_keys_vs_python(gu):
                          ids=["toy1155-generic", "pow2_16384-fused", "prince_ring-generic"])
 def test_mul_relin_batch_equals_single(gu, args):
     """cuhe_hip_mul_relin_batch (B independent cAnd + relin chains in one call: batch*np rows per stage, key values
-    shared by two ciphertexts in the inner product) is bit-identical to B single-ciphertext sequences, which the other
+    shared by four ciphertexts in the inner product) is bit-identical to B single-ciphertext sequences, which the other
     tests pin to the oracle; odd batch sizes exercise the tail of the ciphertext blocking, level 1 the prime tables."""
     import oracle_lib as O
     g, o = gu.GpuCtx(*args), O.Ctx(*args)
@@ -665,7 +665,7 @@ def test_mul_relin_batch_equals_single(gu, args):
         ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE200 + j)[0] for j in range(K)])
         ek = o.init_relin(ek_raw)
         g.init_relin(ek_raw)
-        for lvl, B in ((0, 1), (0, 3), (1, 5)):
+        for lvl, B in ((0, 1), (0, 3), (1, 6)):
             npr = o.np_(lvl)
             a = [_rand_crt(o, npr, 3000 + 10 * lvl + i) for i in range(B)]
             b = [_rand_crt(o, npr, 4000 + 10 * lvl + i) for i in range(B)]
