@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--pass1-form", type=int, default=-1, help="-1 library default, 0 = 32 values per thread, 1 = wave-split")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
     ap.add_argument("--relin-batch", type=int, default=8, help="ciphertexts per call of the batched multiply+relinearise leg")
+    ap.add_argument("--mul-batch", type=int, default=16, help="operand pairs per call of the batched full-multiply leg")
     ap.add_argument("--no-mulrelin", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU baseline sample (0 = auto)")
@@ -184,7 +185,7 @@ def main():
         mulrelin = mulfull = None
         if not args.no_mulrelin and world == 1:
             mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args)
-            mulfull = bench_mul_full(lib, ck, torch, np, dev, with_cpu=not args.no_cpu)
+            mulfull = bench_mul_full(lib, ck, torch, np, dev, with_cpu=not args.no_cpu, batch=args.mul_batch)
 
         out = {
             "metric": "64K-point fwd NTT/s (u32[32768] -> u64[65536] over P=2^64-2^32+1)",
@@ -259,7 +260,7 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
             "collective": "1 all-gather of %d B per rank per multiply (RCCL)" % (sh.count * q.crtLen * 4)}
 
 
-def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True):
+def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16):
     """BASELINE config 3: N = 2^15 (64K-point transforms), 32 CRT primes, full multiply of two raw polynomials
     CRT -> NTT -> pointwise -> INTT (+ reduction mod x^n+1) -> ICRT, device resident (mulZZX without the ZZX<->raw staging)."""
     from cuhe_amd import capi
@@ -296,10 +297,29 @@ def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True):
     dt = (time.perf_counter() - t0) / reps
     got = out.cpu().numpy().view(np.uint32)
     ha, hb = ra.cpu().numpy().view(np.uint32), rb.cpu().numpy().view(np.uint32)
+    # ---- the same multiplication for B independent operand pairs per call (cuhe_hip_mul_raw_batch)
+    batched = None
+    try:
+        B = batch
+        rab = ra.repeat(B, 1).contiguous(); rbb = rb.repeat(B, 1).contiguous()
+        outb = torch.empty((B * q.rawLen, W), dtype=torch.int32, device=dev)
+        for _ in range(2):
+            ck(lib.cuhe_hip_mul_raw_batch(outb.data_ptr(), rab.data_ptr(), rbb.data_ptr(), 0, B, 0, None))
+        torch.cuda.synchronize()
+        assert torch.equal(outb[:q.rawLen], out) and torch.equal(outb[(B - 1) * q.rawLen:], out), "batched result differs from the single chain"
+        breps = max(3, 64 // B)
+        t0 = time.perf_counter()
+        for _ in range(breps):
+            ck(lib.cuhe_hip_mul_raw_batch(outb.data_ptr(), rab.data_ptr(), rbb.data_ptr(), 0, B, 0, None))
+        torch.cuda.synchronize()
+        bdt = (time.perf_counter() - t0) / breps / B
+        batched = {"value": round(1.0 / bdt, 1), "unit": "full multiplies/s (raw -> raw)", "ms_per_multiply": round(bdt * 1e3, 4), "batch": B}
+    except Exception as ex:
+        batched = {"error": repr(ex)[:300]}
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
     res = {"value": round(1.0 / dt, 1), "unit": "full multiplies/s (raw -> raw)", "ms": round(dt * 1e3, 4),
            "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "nttLen": L, "coeff_words": W},
-           "transforms_per_multiply": 3 * npn}
+           "transforms_per_multiply": 3 * npn, "batched": batched}
     if with_cpu:
         # the same multiply on ONE host core through the oracle (checker + reported CPU baseline, never the product path)
         sys.path.insert(0, os.path.join(ROOT, "tests"))

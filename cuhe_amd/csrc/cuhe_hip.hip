@@ -60,6 +60,7 @@ struct Workspace {
     size_t n_barrett = 0, n_alias = 0, n_relin = 0;     // rows / elements the buffers below currently hold
     // scratch of the batched multiply + relinearise (cuhe_hip_mul_relin_batch), sized by the largest batch seen
     u64 *bt_ntt = nullptr; u32 *bt_crt = nullptr, *bt_raw = nullptr; size_t n_bt = 0;
+    u64 *mr_ntt = nullptr; u32 *mr_crt = nullptr; size_t n_mr = 0;        // cuhe_hip_mul_raw_batch
     u64 *b_ntt = nullptr;                // Barrett scratch (cuhe/Operations.cu:196-209)
     u32 *b_mq = nullptr, *b_crt = nullptr;  // q (at offset n) and (m - x^n) q
     u32 *hold = nullptr;                 // inttResult (Operations.cu:171-172)
@@ -221,7 +222,7 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 }
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
-    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw};
+    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw, w->mr_ntt, w->mr_crt};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     delete w;
@@ -861,7 +862,7 @@ int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st
     if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
     const Params &q = G_.prm;
     hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab(D),
-                       np, W, q.modLen, q.crtLen);
+                       np, W, q.modLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -1250,6 +1251,66 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
     return reduce_rows(dst, Ws.bt_ntt);
 }
 
+// `batch` independent full multiplications raw -> raw of one level in a single call (mulZZX without the host
+// staging, CuHE.cu:259-268: CRT, NTT, pointwise product, INTT + reduction mod the polynomial modulus, ICRT), operands
+// and results as u32[batch][rawLen][W].  Same arithmetic as `batch` single sequences; every stage runs once over
+// batch (x np) rows.  A single multiplication at config 3 is seven launches of a few megabytes each and sits on
+// launch and latency floors; a batch amortises them.
+int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, int lvl, int batch, int dev, void *st_) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
+    if (g_pass2_form != 1) return fail(CUHE_EINVAL, "batched operations need the wave-split pass 2");
+    hipStream_t st = S(st_);
+    DevCtx &D = G_.dev[dev];
+    const int np = q.numCrtPrimeAt(lvl), W = q.wordsCoeff(lvl), L = q.nttLen, cl = q.crtLen;
+    if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
+    const int rows = batch * np;
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, st, &Wp));
+    Workspace &Ws = *Wp;
+    // scratch: CRT rows of both operands (2*rows), their transforms (2*rows)
+    if (Ws.n_mr < (size_t)batch) {
+        size_t x = 0, y = 0;
+        if (Ws.mr_ntt) { HIPCHK(hipFree(Ws.mr_ntt)); Ws.mr_ntt = nullptr; }
+        if (Ws.mr_crt) { HIPCHK(hipFree(Ws.mr_crt)); Ws.mr_crt = nullptr; }
+        CHK(ws_grow(&Ws.mr_ntt, &x, (size_t)2 * batch * q.numCrtPrime * L));
+        CHK(ws_grow(&Ws.mr_crt, &y, (size_t)2 * batch * q.numCrtPrime * cl));
+        Ws.n_mr = batch;
+    }
+    const bool fused = fused_xn1();
+    if (!fused) CHK(ws_barrett(Ws, rows));
+    u32 *ca = Ws.mr_crt, *cb = Ws.mr_crt + (size_t)rows * cl;
+    u64 *na = Ws.mr_ntt;
+    if (q.modLen < cl) HIPCHK(hipMemsetAsync(Ws.mr_crt, 0, (size_t)2 * rows * cl * sizeof(u32), st));
+    const size_t lds_crt = (size_t)((W + 7) & ~7) * kCrtCoef * 4;
+    const dim3 gcrt((q.modLen + kCrtCoef - 1) / kCrtCoef, batch);
+    hipLaunchKernelGGL(k_crt, gcrt, dim3(kCrtCoef * kCrtGroups), lds_crt, st, ca, a, prime_tab(D), np, W, q.modLen, cl, (long)q.rawLen * W, (long)np * cl);
+    hipLaunchKernelGGL(k_crt, gcrt, dim3(kCrtCoef * kCrtGroups), lds_crt, st, cb, b, prime_tab(D), np, W, q.modLen, cl, (long)q.rawLen * W, (long)np * cl);
+    HIPCHK(hipGetLastError());
+    CHK(run_ntt(L, kSrcU32Ext, na, ca, 2 * rows, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));        // both operands: 2*rows transforms
+    {
+        const long pairs = (long)rows * L / 2;
+        const int grid = (int)std::min<long>((pairs + 255) / 256, 65535L * 16);
+        hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, st, na, (const u64 *)na, (const u64 *)(na + (size_t)rows * L), pairs);
+    }
+    if (fused) CHK(run_ntt(L, kSrcU64Neg, ca, na, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
+    else {
+        CHK(run_ntt(L, kSrcU64Neg, Ws.hold, na, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
+        CHK(barrett_impl(ca, Ws.hold, 0, rows, dev, st, np));
+    }
+    if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(dst, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
+    const IcrtLevel &I = D.icrt[lvl];
+    IcrtTab it{I.M, I.mi, I.bi, I.rp};
+    const size_t lds = icrt_lds_bytes(np, W);
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, dst, ca,
+                       prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
 // ---------------------------------------------------------------- CRT-prime-sharded variants
 int cuhe_hip_relin_range(uint64_t *dst, const uint32_t *raw, int lvl, int prime0, int count, int dev, void *st) {
     return relin_range(dst, raw, lvl, prime0, count, dev, st);
@@ -1288,7 +1349,7 @@ int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0,
     DevCtx &D = G_.dev[dev];
     const Params &q = G_.prm;
     hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab_at(D, prime0),
-                       count, W, q.modLen, q.crtLen);
+                       count, W, q.modLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }

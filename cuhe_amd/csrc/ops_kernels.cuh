@@ -337,7 +337,10 @@ void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W
 // one v_mad_u64_u32 with an SGPR operand plus one carry add; a word is read from LDS once per four primes.
 static constexpr int kCrtCoef = 64, kCrtGroups = 4, kCrtPB = 4;
 __global__ __launch_bounds__(kCrtCoef * kCrtGroups)
-void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen) {
+void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen,
+           long src_ct_stride, long dst_ct_stride) {
+    src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: polynomial of a batched call (strides in words)
+    dst += (long)blockIdx.y * dst_ct_stride;
     extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W8][64], W8 = W rounded up to 8, tail rows zero
     constexpr int CB = kCrtCoef, NG = kCrtGroups, PB = kCrtPB;
     const int ci = threadIdx.x % CB;

@@ -149,6 +149,10 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
    ntt_mul, intt_mod, icrt, relinearization, intt_mod; every stage runs over batch*np rows and the key-switch inner
    product reads each key value once per four ciphertexts. */
 int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a_ntt, const uint64_t *b_ntt, int lvl, int batch, int dev, void *stream);
+/* `batch` independent full multiplications raw -> raw of one level in one call (mulZZX without the host staging,
+   CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the
+   single sequence crt, crt, ntt, ntt, ntt_mul, intt_mod, icrt */
+int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a_raw, const uint32_t *b_raw, int lvl, int batch, int dev, void *stream);
 /* binary evaluation-key cache: the NTT-domain keys initRelinearization computes (u64[prime][key][nttLen],
    Relinearization.cu:45-55) behind a 96-byte header naming the parameter set and the CRT primes; import refuses
    an image made for other parameters / primes or with a damaged payload.  cache_size = 0 before init. */

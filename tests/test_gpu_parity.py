@@ -685,3 +685,27 @@ def test_mul_relin_batch_equals_single(gu, args):
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 99, 1, 0, None) != 0     # bad level
     finally:
         g.close(); o.close()
+
+
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (5, 2, 1, 61, 20, 8191)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "dhs_simple-prime_m"])
+def test_mul_raw_batch_equals_single(gu, args):
+    """cuhe_hip_mul_raw_batch (B full multiplications raw -> raw per call) against the oracle's mulZZX-at-the-raw-level
+    for every ciphertext of the batch, on the three reduction kinds, at two levels, with odd batch sizes."""
+    import oracle_lib as O
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        for lvl, B in ((0, 1), (0, 3), (1, 4)):
+            W, M = o.words(lvl), o.coeff_modulus(lvl)
+            a = [O.random_raw(q.rawLen, q.modLen, W, M, 5000 + 10 * lvl + i)[0] for i in range(B)]
+            b = [O.random_raw(q.rawLen, q.modLen, W, M, 6000 + 10 * lvl + i)[0] for i in range(B)]
+            da, db = gu.to_dev(np.stack(a).reshape(B * q.rawLen, W)), gu.to_dev(np.stack(b).reshape(B * q.rawLen, W))
+            out = gu.empty_u32(B * q.rawLen, W)
+            gu.ck(gu.lib.cuhe_hip_mul_raw_batch(out.data_ptr(), da.data_ptr(), db.data_ptr(), lvl, B, 0, None))
+            got = gu.host_u32(out).reshape(B, q.rawLen, W)
+            for i in range(B):
+                assert np.array_equal(got[i], o.mul_raw(a[i], b[i], lvl)), (lvl, B, i)
+        assert gu.lib.cuhe_hip_mul_raw_batch(out.data_ptr(), da.data_ptr(), db.data_ptr(), 0, 0, 0, None) != 0
+    finally:
+        g.close(); o.close()
