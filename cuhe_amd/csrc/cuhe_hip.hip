@@ -1289,12 +1289,11 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     hipLaunchKernelGGL(k_crt, gcrt, dim3(kCrtCoef * kCrtGroups), lds_crt, st, ca, a, prime_tab(D), np, W, q.modLen, cl, (long)q.rawLen * W, (long)np * cl);
     hipLaunchKernelGGL(k_crt, gcrt, dim3(kCrtCoef * kCrtGroups), lds_crt, st, cb, b, prime_tab(D), np, W, q.modLen, cl, (long)q.rawLen * W, (long)np * cl);
     HIPCHK(hipGetLastError());
-    CHK(run_ntt(L, kSrcU32Ext, na, ca, 2 * rows, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));        // both operands: 2*rows transforms
-    {
-        const long pairs = (long)rows * L / 2;
-        const int grid = (int)std::min<long>((pairs + 255) / 256, 65535L * 16);
-        hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, st, na, (const u64 *)na, (const u64 *)(na + (size_t)rows * L), pairs);
-    }
+    // transforms of the a operands, then those of the b operands with the pointwise product riding on their output
+    // (kOutU64Mul with the a transforms as the table: row r of b times row r of a) -- no separate product pass
+    u64 *nb = na + (size_t)rows * L;
+    CHK(run_ntt(L, kSrcU32Ext, nb, cb, rows, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));
+    CHK(run_ntt(L, kSrcU32Ext, na, ca, rows, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nb));
     if (fused) CHK(run_ntt(L, kSrcU64Neg, ca, na, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
     else {
         CHK(run_ntt(L, kSrcU64Neg, Ws.hold, na, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
