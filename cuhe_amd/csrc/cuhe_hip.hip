@@ -1240,12 +1240,32 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
     HIPCHK(hipGetLastError());
     CHK(run_ntt(L, kSrcU32Ext, Ws.relin, Ws.win, batch * k, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));
     // 4. key-switch inner products: a key value fetched once serves four ciphertexts
-    // 2 primes x 4 ciphertexts per workgroup: a key value fetched from HBM serves four ciphertexts.  Measured at
-    // batch 8 of config 4 (profiles/r01_experiments_log.txt): 4x2 0.387, 2x2 0.360, 2x4 0.336, 2x4 XCD-aware 0.326, 1x8 0.404 ms
-    // per ciphertext; the kernel stays bound by the traffic between the L2s and the fabric in every blocking.
-    constexpr int PB = 2, BB = 4;
-    hipLaunchKernelGGL((k_relin_mac<PB, BB, 1>), dim3((L / 512) * ((np + PB - 1) / PB), 1, (batch + BB - 1) / BB), dim3(256), 0, st,
-                       Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
+    // window tiles of 4 ciphertexts resident in LDS, every key value fetched once per 4 ciphertexts (k_relin_mac_lds);
+    // PB (primes per thread and pass) is the one of 2, 3, 4 that wastes the fewest of the 8 x PB prime slots per pass.
+    // Falls back to the register-blocked kernel (2 primes x 4 ciphertexts per workgroup) when the tile exceeds LDS.
+    {
+        constexpr int BB = 4;
+        const size_t lds = (size_t)BB * k * kMacLdsCols * sizeof(u64);
+        if (lds <= 150 * 1024) {
+            int best = 2; double eff = 0;
+            for (int pb = 2; pb <= 4; ++pb) {
+                const int slots = ((np + 8 * pb - 1) / (8 * pb)) * 8 * pb;
+                const double f = (double)np / slots;
+                if (f >= eff) { eff = f; best = pb; }
+            }
+            const dim3 grid(L / kMacLdsCols, (batch + BB - 1) / BB), block(kMacLdsCols * kMacLdsGroups);
+#define MACL(PB_) do { \
+                if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_relin_mac_lds<PB_, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB>), grid, block, lds, st, Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, \
+                                   (long)k * L, (long)np * L, batch); } while (0)
+            if (best == 2) MACL(2); else if (best == 3) MACL(3); else MACL(4);
+#undef MACL
+        } else {
+            constexpr int PB = 2;
+            hipLaunchKernelGGL((k_relin_mac<PB, BB, 1>), dim3((L / 512) * ((np + PB - 1) / PB), 1, (batch + BB - 1) / BB), dim3(256), 0, st,
+                               Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
+        }
+    }
     HIPCHK(hipGetLastError());
     // 5. n2c of the sums
     return reduce_rows(dst, Ws.bt_ntt);

@@ -297,6 +297,108 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
         }
 }
 
+// ---- batched form with the window tile resident in LDS.
+// The blocking above keeps PB x BB accumulators per thread and re-reads every window value once per prime block; in a
+// batch that traffic (L2 misses: window tiles + keys) and the multiply-add's instruction count bound the kernel
+// together (profiles/r01_experiments_log.txt).  Here a workgroup owns 32 columns of BB ciphertexts: their k window
+// rows (BB * k * 256 B) are loaded into LDS ONCE, then the 8 prime groups of the workgroup (thread = (column, group))
+// walk over all primes, PB at a time: every key value is fetched from HBM exactly once per BB ciphertexts and every
+// window value from global memory exactly once.  With the traffic gone the kernel is VALU-bound, so the multiply-add
+// itself is restructured (AccSplit below): 8 VALU instructions instead of 24.
+// Split accumulator: with a = a0 + a1 2^32, b = b0 + b1 2^32 the sum of products is
+//     S = sum a0 b0  +  2^64 sum a1 b1  +  2^32 (sum a0 b1 + sum a1 b0),
+// three independent 64-bit running sums with a carry counter each.  v_mad_u64_u32 already adds a 64-bit operand and
+// reports the carry, so one multiply-add of the inner product is four {v_mad_u64_u32 ; v_addc_co_u32} pairs = 8 VALU
+// instructions (the 128-bit product + 160-bit add costs 15 with a hand-written carry chain, 24 in C).  The three
+// sums are recombined modulo P once per output.
+struct AccSplit { u64 s00, s11, sx; u32 c00, c11, cx; };
+__device__ __forceinline__ void acc_mad(u64 &sum, u32 &carries, u32 x, u32 y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "+v"(sum), "+v"(carries) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void mac_split(u64 a, u64 b, AccSplit &s) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    acc_mad(s.s00, s.c00, a0, b0);
+    acc_mad(s.s11, s.c11, a1, b1);
+    acc_mad(s.sx, s.cx, a0, b1);
+    acc_mad(s.sx, s.cx, a1, b0);
+}
+// S mod P with 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32:
+//   S = (s00 + c00 2^64) + 2^64 (s11 + c11 2^64) + 2^32 (sx + cx 2^64)
+__device__ __forceinline__ u64 fold_split(const AccSplit &s) {
+    u64 r = reduce128(s.s00, s.s11);                       // s00 + 2^64 s11
+    r = addp(r, shlp<32>(canon(s.sx)));                    // + 2^32 sx
+    r = addp(r, mulp_u32(kEps, s.c00));                    // + c00 2^64
+    r = subp(r, (u64)s.c11 << 32);                         // + c11 2^128 = - c11 2^32   (c11 < 2^32: canonical)
+    r = subp(r, (u64)s.cx);                                // + cx 2^96  = - cx
+    return r;
+}
+static constexpr int kMacLdsCols = 32, kMacLdsGroups = 8;
+template <int PB, int BB>
+__global__ __launch_bounds__(kMacLdsCols * kMacLdsGroups)
+void k_relin_mac_lds(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
+                     int k, long ek_prime_stride, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts) {
+    extern __shared__ __attribute__((aligned(16))) u64 wl[];   // [BB][k][32]
+    constexpr int CB = kMacLdsCols, NG = kMacLdsGroups;
+    const int col = threadIdx.x % CB, pg = threadIdx.x / CB;
+    const long col0 = (long)blockIdx.x * CB;
+    const int b0 = blockIdx.y * BB;
+    for (int e = threadIdx.x; e < BB * k * CB; e += CB * NG) {
+        const int cc = e % CB, j = (e / CB) % k, b = e / (CB * k);
+        wl[e] = c[(long)min(b0 + b, ncts - 1) * c_ct_stride + (long)j * L + col0 + cc];
+    }
+    __syncthreads();
+    const u64 *mine = wl + col;
+    for (int i0 = pg * PB; i0 < np; i0 += NG * PB) {
+        AccSplit s[BB][PB];
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+            for (int q = 0; q < PB; ++q) s[b][q] = AccSplit{0, 0, 0, 0, 0, 0};
+        const u64 *e[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) e[q] = ek + (long)min(i0 + q, np - 1) * ek_prime_stride + col0 + col;
+        // software pipeline over blocks of JB windows: the key values of the NEXT block are requested before the
+        // multiply-adds of the current one, so that JB * PB loads per thread are in flight (two waves per SIMD alone
+        // keep too few bytes in flight to stream the keys at HBM speed: 3.4 TB/s measured with a distance of one)
+        constexpr int JB = 4;
+        u64 kv[JB][PB], kn[JB][PB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+            for (int q = 0; q < PB; ++q) kv[jj][q] = __builtin_nontemporal_load(&e[q][(long)min(jj, k - 1) * L]);
+        for (int j0 = 0; j0 < k; j0 += JB) {
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int q = 0; q < PB; ++q) kn[jj][q] = __builtin_nontemporal_load(&e[q][(long)min(j0 + JB + jj, k - 1) * L]);
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                const int j = j0 + jj;
+                if (j < k) {
+#pragma unroll
+                    for (int b = 0; b < BB; ++b) {
+                        const u64 a = mine[(b * k + j) * CB];
+#pragma unroll
+                        for (int q = 0; q < PB; ++q) mac_split(a, kv[jj][q], s[b][q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int q = 0; q < PB; ++q) kv[jj][q] = kn[jj][q];
+        }
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+            for (int q = 0; q < PB; ++q)
+                if (i0 + q < np && b0 + b < ncts)
+                    dst[(long)(b0 + b) * dst_ct_stride + (long)(i0 + q) * L + col0 + col] = fold_split(s[b][q]);
+    }
+}
+
 // ---------------------------------------------------------------- relinearisation windows
 // win[j][idx] = bits [w*j, w*j + w) of coefficient idx (cuhe/Base.cu:361-371), for all j < k: the raw slab is read
 // ONCE, coalesced, through LDS and every window row is written coalesced, so that the k window transforms run on a
