@@ -19,8 +19,12 @@
  *   - layouts: raw  u32[rawLen][W] coefficient-major LE words,
  *     crt u32[np][crtLen] prime-major, ntt u64[np][nttLen]; level `lvl` uses
  *     the first numCrtPrime-lvl primes; W = wordsCoeff(lvl).
- *   - one operation in flight per device (library-owned scratch), exactly the
- *     reference's contract (cuhe/Operations.cu:171-172,193-195).
+ *   - library-owned scratch is kept per HOST THREAD and device: calls made by one
+ *     thread are ordered (also across the streams that thread uses), different
+ *     threads may drive the same device concurrently on their own streams.  (The
+ *     reference has one scratch set per device: one operation in flight per
+ *     device, cuhe/Operations.cu:171-172,193-195.)  Parameter set-up, init,
+ *     initRelinearization and shutdown are not concurrent with anything.
  */
 #ifndef CUHE_HIP_H
 #define CUHE_HIP_H
