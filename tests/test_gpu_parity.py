@@ -651,12 +651,16 @@ def test_config4_relin_structured_keys_vs_python(gu):
         g.close()
 
 
-@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 25, 25, 21845)],
-                         ids=["toy1155-generic", "pow2_16384-fused", "prince_ring-generic"])
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 25, 25, 21845),
+                                  (5, 2, 1, 61, 20, 8191), (6, 2, 1, 61, 20, 8191)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "prince_ring-generic", "dhs_simple-141keys-lds144K",
+                              "w1-161keys-register-kernel"])
 def test_mul_relin_batch_equals_single(gu, args):
     """cuhe_hip_mul_relin_batch (B independent cAnd + relin chains in one call: batch*np rows per stage, key values
     shared by four ciphertexts in the inner product) is bit-identical to B single-ciphertext sequences, which the other
-    tests pin to the oracle; odd batch sizes exercise the tail of the ciphertext blocking, level 1 the prime tables."""
+    tests pin to the oracle; odd batch sizes exercise the tail of the ciphertext blocking, level 1 the prime tables.  The
+    last two rings have 1-bit windows: 141 keys fill the LDS window tile to 144 KB (one workgroup per CU), 161 keys exceed
+    it and take the register-blocked inner-product kernel."""
     import oracle_lib as O
     g, o = gu.GpuCtx(*args), O.Ctx(*args)
     try:
