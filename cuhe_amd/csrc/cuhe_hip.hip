@@ -1245,20 +1245,21 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
     // Falls back to the register-blocked kernel (2 primes x 4 ciphertexts per workgroup) when the tile exceeds LDS.
     {
         constexpr int BB = 4;
-        const size_t lds = (size_t)BB * k * kMacLdsCols * sizeof(u64);
+        constexpr int CBr = 32, NGr = kMacLdsThreads / CBr;      // 16-column tiles (3 workgroups per CU) measured the same
+        const size_t lds = (size_t)BB * k * CBr * sizeof(u64);
         if (lds <= 150 * 1024) {
             int best = 2; double eff = 0;
             for (int pb = 2; pb <= 4; ++pb) {
-                const int slots = ((np + 8 * pb - 1) / (8 * pb)) * 8 * pb;
+                const int slots = ((np + NGr * pb - 1) / (NGr * pb)) * NGr * pb;
                 const double f = (double)np / slots;
                 if (f >= eff) { eff = f; best = pb; }
             }
-            const dim3 grid(L / kMacLdsCols, (batch + BB - 1) / BB), block(kMacLdsCols * kMacLdsGroups);
-#define MACL(PB_) do { \
-                if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_relin_mac_lds<PB_, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB>), grid, block, lds, st, Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, \
+            const dim3 grid(L / CBr, (batch + BB - 1) / BB), block(kMacLdsThreads);
+#define MACL(PB_, CB_) do { \
+                if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_relin_mac_lds<PB_, BB, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB, CB_>), grid, block, lds, st, Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, \
                                    (long)k * L, (long)np * L, batch); } while (0)
-            if (best == 2) MACL(2); else if (best == 3) MACL(3); else MACL(4);
+            if (best == 2) MACL(2, CBr); else if (best == 3) MACL(3, CBr); else MACL(4, CBr);
 #undef MACL
         } else {
             constexpr int PB = 2;

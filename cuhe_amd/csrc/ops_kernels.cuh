@@ -334,13 +334,13 @@ __device__ __forceinline__ u64 fold_split(const AccSplit &s) {
     r = subp(r, (u64)s.cx);                                // + cx 2^96  = - cx
     return r;
 }
-static constexpr int kMacLdsCols = 32, kMacLdsGroups = 8;
-template <int PB, int BB>
-__global__ __launch_bounds__(kMacLdsCols * kMacLdsGroups)
+static constexpr int kMacLdsThreads = 256;
+template <int PB, int BB, int CB>
+__global__ __launch_bounds__(kMacLdsThreads)
 void k_relin_mac_lds(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
                      int k, long ek_prime_stride, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts) {
-    extern __shared__ __attribute__((aligned(16))) u64 wl[];   // [BB][k][32]
-    constexpr int CB = kMacLdsCols, NG = kMacLdsGroups;
+    extern __shared__ __attribute__((aligned(16))) u64 wl[];   // [BB][k][CB]
+    constexpr int NG = kMacLdsThreads / CB;                  // prime groups per workgroup
     const int col = threadIdx.x % CB, pg = threadIdx.x / CB;
     const long col0 = (long)blockIdx.x * CB;
     const int b0 = blockIdx.y * BB;
