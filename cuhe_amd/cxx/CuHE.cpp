@@ -546,4 +546,40 @@ void mulZZX(ZZX &out, ZZX in0, ZZX in1, int lvl, int dev, cudaStream_t st) {
 	a.swapZRep(out);
 }
 
+void mulZZXBatch(ZZX *x, const ZZX *a, const ZZX *b, int count, int lvl, int dev, cudaStream_t st) {
+	if (count <= 0) return;
+	const int W = (param._logCoeff(lvl) + 31) / 32;
+	const size_t rowBytes = (size_t)W * sizeof(uint32), polyBytes = (size_t)param.rawLen * rowBytes;
+	// staging: [a_0 .. a_{count-1} | b_0 .. b_{count-1}] going up, the products coming back into the first half
+	uint8 *host = (uint8 *)tlsStage.get(2 * count * polyBytes);
+	for (int t = 0; t < 2 * count; t++) {
+		const ZZX &src = t < count ? a[t] : b[t - count];
+		uint8 *dstp = host + (size_t)t * polyBytes;
+		const long top = deg(src);
+		for (long i = 0; i < param.rawLen; i++) {
+			if (i <= top) BytesFromZZ(dstp + (size_t)i * rowBytes, coeff(src, i), (long)rowBytes);
+			else memset(dstp + (size_t)i * rowBytes, 0, rowBytes);
+		}
+	}
+	uint32 *d_in = (uint32 *)devAlloc(dev, 2 * count * polyBytes, st), *d_out = (uint32 *)devAlloc(dev, count * polyBytes, st);
+	CSC(cuhe_hip_memcpy_h2d(dev, d_in, host, 2 * count * polyBytes, st));
+	CSC(cuhe_hip_mul_raw_batch(d_out, d_in, d_in + (size_t)count * param.rawLen * W, lvl, count, dev, st));
+	CSC(cuhe_hip_memcpy_d2h(dev, host, d_out, count * polyBytes, st));
+	CSC(cuhe_hip_stream_sync(dev, st));
+	devFree(dev, d_in, st); devFree(dev, d_out, st);
+	const long n = param.modLen;
+	for (int t = 0; t < count; t++) {
+		ZZX &dst = x[t];
+		clear(dst);
+#ifdef CUHE_MINI_NTL
+		dst.rep.resize(n);
+#else
+		dst.rep.SetLength(n);
+#endif
+		const uint8 *srcp = host + (size_t)t * polyBytes;
+		for (long i = 0; i < n; i++) ZZFromBytes(dst.rep[i], srcp + (size_t)i * rowBytes, (long)rowBytes);
+		dst.normalize();
+	}
+}
+
 } // namespace cuHE

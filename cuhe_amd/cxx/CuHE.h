@@ -134,6 +134,9 @@ void initRelinearization(ZZX *evalkey);
 
 // x = a * b mod (polynomial modulus, q_lvl), host in / host out
 void mulZZX(ZZX &x, ZZX a, ZZX b, int lvl, int dev, cudaStream_t st = 0);
+// (addition) count independent products x[i] = a[i] * b[i] in one call: one packed upload, every device stage once over
+// all count * numCrtPrime rows (cuhe_hip_mul_raw_batch), one download.  Same results as count calls of mulZZX.
+void mulZZXBatch(ZZX *x, const ZZX *a, const ZZX *b, int count, int lvl, int dev, cudaStream_t st = 0);
 
 // gates
 void copy(CuCtxt &x, CuCtxt &a, cudaStream_t st = 0);

@@ -42,6 +42,15 @@ int main() {
 		mulZZX(c, a, b, lvl, 0);
 		CHECK(c == hostMul(a, b, phi, q[lvl], n), lvl == 0 ? "mulZZX level 0" : "mulZZX level 2");
 	}
+	// ---- mulZZXBatch (addition): five independent products in one call, level 1
+	{
+		std::vector<ZZX> a(5), b(5), c(5);
+		bool ok = true;
+		for (int i = 0; i < 5; ++i) { a[i] = randomPoly(n, q[1]); b[i] = randomPoly(n, q[1]); }
+		mulZZXBatch(c.data(), a.data(), b.data(), 5, 1, 0);
+		for (int i = 0; i < 5; ++i) ok = ok && c[i] == hostMul(a[i], b[i], phi, q[1], n);
+		CHECK(ok, "mulZZXBatch equals five host products");
+	}
 	// ---- domain conversions round trip + cXor in CRT and NTT domains (simple_DHS.cu checkXor)
 	{
 		ZZX a = randomPoly(n, q[0]), b = randomPoly(n, q[0]);
