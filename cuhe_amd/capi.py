@@ -87,6 +87,7 @@ SIGNATURES = {
     "cuhe_hip_init_relin": (i32, [vp]),
     "cuhe_hip_relinearization": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_mul_raw_batch": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_relin_batch": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_mul_relin_batch": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_relin_cache_size": (sz, []),
     "cuhe_hip_relin_export": (i32, [vp, sz, i32]),

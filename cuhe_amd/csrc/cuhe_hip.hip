@@ -1184,7 +1184,9 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 // over batch*np (or batch*k) rows -- several hundred workgroups instead of a few dozen, so the transforms leave their
 // latency floor (profiles/r01_small_batch_latency.txt) -- and the inner product fetches each key value once for
 // four ciphertexts.  The reference has no batched form: its circuits issue ciphertext operations one at a time.
-int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int batch, int dev, void *st_) {
+// core of the batched calls: a, b != null -> products of NTT-domain operands first (cAnd ; relin);
+// crt_in != null -> relinearisation of CRT-domain ciphertexts (CuCtxt::relin on a reduced ciphertext)
+static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b, const uint32_t *crt_in, int lvl, int batch, int dev, void *st_) {
     CHK(need_init(dev));
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
     const Params &q = G_.prm;
@@ -1217,14 +1219,17 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
         CHK(run_ntt(L, kSrcU64Neg, Ws.hold, in, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
         return barrett_impl(out, Ws.hold, 0, rows, dev, st, np);
     };
-    // 1. pointwise products
-    {
+    const u32 *crt_rows = crt_in;
+    if (!crt_in) {
+        // 1. pointwise products
         const long pairs = (long)rows * L / 2;
         const int grid = (int)std::min<long>((pairs + 255) / 256, 65535L * 16);
         hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, st, Ws.bt_ntt, (const u64 *)a, (const u64 *)b, pairs);
+        // 2. x2r: INTT + reduction
+        CHK(reduce_rows(Ws.bt_crt, Ws.bt_ntt));
+        crt_rows = Ws.bt_crt;
     }
-    // 2. x2r: INTT + reduction, then ICRT of every ciphertext
-    CHK(reduce_rows(Ws.bt_crt, Ws.bt_ntt));
+    // ICRT of every ciphertext
     if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(Ws.bt_raw, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
     {
         const IcrtLevel &I = D.icrt[lvl];
@@ -1232,7 +1237,7 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
         const size_t lds = icrt_lds_bytes(np, W);
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, Ws.bt_raw,
-                           Ws.bt_crt, prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
+                           crt_rows, prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
     }
     // 3. windows of every ciphertext and their transforms: batch*k rows
     hipLaunchKernelGGL(k_extract_windows, dim3((cl + kWinCoef - 1) / kWinCoef, batch), dim3(kWinCoef * kWinGroups), (size_t)W * kWinCoef * 4, st,
@@ -1270,6 +1275,17 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
     HIPCHK(hipGetLastError());
     // 5. n2c of the sums
     return reduce_rows(dst, Ws.bt_ntt);
+}
+
+int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int batch, int dev, void *st) {
+    if (!a || !b) return fail(CUHE_EINVAL, "null operand");
+    return relin_batch_core(dst, a, b, nullptr, lvl, batch, dev, st);
+}
+// CuCtxt::relin (CuHE.cu:570-581) for `batch` reduced CRT-domain ciphertexts u32[batch][np][crtLen] of one level:
+// ICRT, windows, window transforms, key-switch inner products, INTT + reduction, in one call
+int cuhe_hip_relin_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *st) {
+    if (!src) return fail(CUHE_EINVAL, "null operand");
+    return relin_batch_core(dst, nullptr, nullptr, src, lvl, batch, dev, st);
 }
 
 // `batch` independent full multiplications raw -> raw of one level in a single call (mulZZX without the host

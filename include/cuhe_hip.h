@@ -153,6 +153,9 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
    ntt_mul, intt_mod, icrt, relinearization, intt_mod; every stage runs over batch*np rows and the key-switch inner
    product reads each key value once per four ciphertexts. */
 int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a_ntt, const uint64_t *b_ntt, int lvl, int batch, int dev, void *stream);
+/* CuCtxt::relin for `batch` reduced CRT-domain ciphertexts of one level: src, dst = u32[batch][np][crtLen]
+   (dst may be src); bit-identical to icrt, relinearization, intt_mod per ciphertext */
+int cuhe_hip_relin_batch(uint32_t *dst, const uint32_t *src_crt, int lvl, int batch, int dev, void *stream);
 /* `batch` independent full multiplications raw -> raw of one level in one call (mulZZX without the host staging,
    CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the
    single sequence crt, crt, ntt, ntt, ntt_mul, intt_mod, icrt */

@@ -685,6 +685,13 @@ def test_mul_relin_batch_equals_single(gu, args):
             got = gu.host_u32(out).reshape(B, npr, q.crtLen)
             for i in range(B):
                 assert np.array_equal(got[i], single[i]), (lvl, B, i)
+            # cuhe_hip_relin_batch: relinearise the B results once more (CRT-domain input, in place) against the
+            # single-ciphertext sequence icrt, relinearization, intt_mod
+            again = [g.intt_mod(g.relin(g.icrt(single[i], lvl), lvl), lvl) for i in range(B)]
+            gu.ck(gu.lib.cuhe_hip_relin_batch(out.data_ptr(), out.data_ptr(), lvl, B, 0, None))
+            got2 = gu.host_u32(out).reshape(B, npr, q.crtLen)
+            for i in range(B):
+                assert np.array_equal(got2[i], again[i]), ("relin_batch", lvl, B, i)
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, 0, 0, None) != 0      # batch < 1
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 99, 1, 0, None) != 0     # bad level
     finally:
