@@ -87,6 +87,10 @@ SIGNATURES = {
     "cuhe_hip_init_relin": (i32, [vp]),
     "cuhe_hip_relinearization": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_mul_raw_batch": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_intt_mod_batch": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_crt_mod_switch_batch": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_ntt_mul_pairs": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_crt_combine": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_relin_batch": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_mul_relin_batch": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_relin_cache_size": (sz, []),

@@ -930,7 +930,7 @@ int cuhe_hip_crt_mod_switch(uint32_t *dst, const uint32_t *src, int logq, int de
     const Params &q = G_.prm;
     DevCtx &D = G_.dev[dev];
     hipLaunchKernelGGL(k_modswitch, dim3((q.modLen + 255) / 256, np - 1), dim3(256), 0, S(st), dst, src, prime_tab(D),
-                       D.invp, np, q.modLen, q.crtLen, q.modMsg);
+                       D.invp, np, q.modLen, q.crtLen, q.modMsg, 0L, 0L);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -1286,6 +1286,65 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b
 int cuhe_hip_relin_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *st) {
     if (!src) return fail(CUHE_EINVAL, "null operand");
     return relin_batch_core(dst, nullptr, nullptr, src, lvl, batch, dev, st);
+}
+
+// ---------------------------------------------------------------- gates on arrays of ciphertexts
+// The C++ gates (cAnd, cXor, cNot, modSwitch: CuHE.cu:101-215,545-568) act on one ciphertext per call; a circuit
+// layer (the 16 S-boxes of a PRINCE round) is hundreds of them.  These entry points apply one kind of gate to a whole
+// array u32[count][np][crtLen] / u64[count][np][nttLen] of ciphertexts of one level in a single launch sequence.
+int cuhe_hip_intt_mod_batch(uint32_t *dst, const uint64_t *src, int lvl, int batch, int dev, void *st_) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
+    hipStream_t st = S(st_);
+    const int np = q.numCrtPrimeAt(lvl), L = q.nttLen, cl = q.crtLen, rows = batch * np;
+    if (fused_xn1()) return run_ntt(L, kSrcU64Neg, dst, src, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np);
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, st, &Wp));
+    CHK(ws_barrett(*Wp, rows));
+    CHK(run_ntt(L, kSrcU64Neg, Wp->hold, src, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
+    return barrett_impl(dst, Wp->hold, 0, rows, dev, st, np);
+}
+// modSwitch of `batch` ciphertexts of level lvl: src u32[batch][np][crtLen] -> dst u32[batch][np-1][crtLen] (packed)
+int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl + 1 >= q.depth) return fail(CUHE_EINVAL, "modSwitch from level %d", lvl);
+    if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
+    const int np = q.numCrtPrimeAt(lvl);
+    if (np < 2) return fail(CUHE_EINVAL, "modSwitch needs >= 2 primes");
+    DevCtx &D = G_.dev[dev];
+    hipLaunchKernelGGL(k_modswitch, dim3((q.modLen + 255) / 256, np - 1, batch), dim3(256), 0, S(st), dst, src, prime_tab(D),
+                       D.invp, np, q.modLen, q.crtLen, q.modMsg, (long)np * q.crtLen, (long)(np - 1) * q.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+// dst[t] = src[idx_a[t]] * src[idx_b[t]] (pointwise mod P) for t < npairs; ciphertexts of `np_rows` rows; the index
+// arrays live in device memory
+int cuhe_hip_ntt_mul_pairs(uint64_t *dst, const uint64_t *src, const int32_t *idx_a, const int32_t *idx_b, int npairs, int np_rows, int dev, void *st) {
+    CHK(need_init(dev));
+    if (npairs < 1 || np_rows < 1) return fail(CUHE_EINVAL, "npairs %d rows %d", npairs, np_rows);
+    const long ct_pairs = (long)np_rows * G_.prm.nttLen / 2;
+    const int gx = (int)std::min<long>((ct_pairs + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_ntt_mul_pairs, dim3(gx, npairs), dim3(256), 0, S(st), (u64 *)dst, (const u64 *)src, idx_a, idx_b, ct_pairs);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+// dst[o] = sum over list[off[o] .. off[o+1]) of CRT-domain ciphertexts (entries < nA from src_a, the rest from
+// src_b) + add_const[o] on the constant coefficient, for o < nout, at level lvl; off / list / add_const in device memory
+int cuhe_hip_crt_combine(uint32_t *dst, const uint32_t *src_a, int nA, const uint32_t *src_b, const int32_t *off, const int32_t *list,
+                         const int32_t *add_const, int nout, int lvl, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (nout < 1) return fail(CUHE_EINVAL, "nout %d", nout);
+    const int np = q.numCrtPrimeAt(lvl);
+    DevCtx &D = G_.dev[dev];
+    hipLaunchKernelGGL(k_crt_combine, dim3((q.modLen + 255) / 256, np, nout), dim3(256), 0, S(st), dst, src_a, nA, src_b, off, list, add_const,
+                       prime_tab(D), np, q.modLen, q.crtLen);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
 }
 
 // `batch` independent full multiplications raw -> raw of one level in a single call (mulZZX without the host

@@ -50,6 +50,40 @@ void k_ntt_binop_nx1(u64 *__restrict__ z, const u64 *__restrict__ x, const u64 *
     }
 }
 
+// ---------------------------------------------------------------- batched gate helpers (circuit evaluation on arrays)
+// dst[t] = src[ia[t]] (*) src[ib[t]] for t < npairs: ciphertexts are `rows` rows of L (NTT domain); blockIdx.y = t
+__global__ __launch_bounds__(256)
+void k_ntt_mul_pairs(u64 *__restrict__ dst, const u64 *__restrict__ src, const int *__restrict__ ia, const int *__restrict__ ib, long ct_pairs) {
+    const int t = blockIdx.y;
+    const ulonglong2 *x = reinterpret_cast<const ulonglong2 *>(src) + (long)ia[t] * ct_pairs;
+    const ulonglong2 *y = reinterpret_cast<const ulonglong2 *>(src) + (long)ib[t] * ct_pairs;
+    ulonglong2 *z = reinterpret_cast<ulonglong2 *>(dst) + (long)t * ct_pairs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ct_pairs; i += (long)gridDim.x * blockDim.x) {
+        const ulonglong2 a = x[i], b = y[i];
+        ulonglong2 r; r.x = mulp(a.x, b.x); r.y = mulp(a.y, b.y);
+        z[i] = r;
+    }
+}
+// dst[o] = sum of the CRT-domain ciphertexts srcs[list[t]] for t in [off[o], off[o+1])  (+ addc[o] on the constant
+// coefficient), residues mod p_i.  A list entry e < nA addresses srcA[e], otherwise srcB[e - nA].  blockIdx.y = prime
+// row, blockIdx.z = output.  This is a whole layer of cXor / cNot gates (CuHE.cu:122-215) in one launch.
+__global__ __launch_bounds__(256)
+void k_crt_combine(u32 *__restrict__ dst, const u32 *__restrict__ srcA, int nA, const u32 *__restrict__ srcB,
+                   const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ addc,
+                   PrimeTab pt, int np, int mlen, int clen) {
+    const int o = blockIdx.z, i = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mlen) return;
+    const u32 p = pt.p[i];
+    u64 acc = 0;
+    for (int t = off[o]; t < off[o + 1]; ++t) {
+        const int e = list[t];
+        const u32 *s = e < nA ? srcA + ((long)e * np + i) * clen : srcB + ((long)(e - nA) * np + i) * clen;
+        acc += s[idx];                                   // residues < 2^32, a few dozen terms at most
+    }
+    if (idx == 0) acc += (u32)addc[o];
+    dst[((long)o * np + i) * clen + idx] = mod_small(acc, p, pt.pinv[i]);
+}
+
 // ---------------------------------------------------------------- CRT-domain ops
 // inputs are residues < p_i, so (a+b)%p is one conditional subtract when a,b < p;
 // the reference uses % (Base.cu:1088-1109) which also accepts unreduced inputs --
@@ -93,7 +127,9 @@ __global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict__ x, in
 // and row np-1 is never written).
 __global__ __launch_bounds__(256)
 void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt,
-                 const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg) {
+                 const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg, long src_ct_stride, long dst_ct_stride) {
+    src += (long)blockIdx.z * src_ct_stride;         // blockIdx.z: ciphertext of a batched call (the result has np-1 rows,
+    dst += (long)blockIdx.z * dst_ct_stride;         // so a packed result array has a smaller stride than its source)
     const int i = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mlen) return;
     const u32 ptl = pt.p[np - 1];

@@ -160,6 +160,19 @@ int cuhe_hip_relin_batch(uint32_t *dst, const uint32_t *src_crt, int lvl, int ba
    CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the
    single sequence crt, crt, ntt, ntt, ntt_mul, intt_mod, icrt */
 int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a_raw, const uint32_t *b_raw, int lvl, int batch, int dev, void *stream);
+/* ---- gates on ARRAYS of ciphertexts of one level (no counterpart: the reference's gates, CuHE.cu:101-215,545-568,
+   take one ciphertext per call).  Arrays are u32[count][np][crtLen] (CRT domain) or u64[count][np][nttLen] (NTT domain);
+   index arrays live in device memory.  Each call is bit-identical to the per-ciphertext gates it stands for. */
+/* n2c of products: INTT + reduction modulo the polynomial modulus for `batch` ciphertexts */
+int cuhe_hip_intt_mod_batch(uint32_t *dst_crt, const uint64_t *src_ntt, int lvl, int batch, int dev, void *stream);
+/* modSwitch: src at level lvl (np rows each) -> dst at level lvl+1, packed u32[batch][np-1][crtLen] */
+int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *stream);
+/* cAnd over index pairs: dst[t] = src[idx_a[t]] * src[idx_b[t]], ciphertexts of np_rows rows */
+int cuhe_hip_ntt_mul_pairs(uint64_t *dst, const uint64_t *src, const int32_t *idx_a, const int32_t *idx_b, int npairs, int np_rows, int dev, void *stream);
+/* cXor / cNot over index lists: dst[o] = sum of the listed ciphertexts (+ add_const[o] on the constant coefficient);
+   list entries e < nA address src_a[e], the others src_b[e - nA]; list[off[o] .. off[o+1]) belongs to output o */
+int cuhe_hip_crt_combine(uint32_t *dst, const uint32_t *src_a, int nA, const uint32_t *src_b, const int32_t *off, const int32_t *list,
+                         const int32_t *add_const, int nout, int lvl, int dev, void *stream);
 /* binary evaluation-key cache: the NTT-domain keys initRelinearization computes (u64[prime][key][nttLen],
    Relinearization.cu:45-55) behind a 96-byte header naming the parameter set and the CRT primes; import refuses
    an image made for other parameters / primes or with a damaged payload.  cache_size = 0 before init. */

@@ -720,3 +720,59 @@ def test_mul_raw_batch_equals_single(gu, args):
         assert gu.lib.cuhe_hip_mul_raw_batch(out.data_ptr(), da.data_ptr(), db.data_ptr(), 0, 0, 0, None) != 0
     finally:
         g.close(); o.close()
+
+
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384)], ids=["toy1155-generic", "pow2_16384-fused"])
+def test_array_gates_equal_single_gates(gu, args):
+    """gates on arrays of ciphertexts (cuhe_hip_ntt_mul_pairs, intt_mod_batch, crt_mod_switch_batch, crt_combine) against the
+    per-ciphertext entry points they stand for (ntt_mul, intt_mod, crt_mod_switch, crt_add / crt_add_int), which the
+    other tests pin to the oracle."""
+    import torch
+    import oracle_lib as O
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        lvl, B = 0, 5
+        npr, logq = o.np_(lvl), o.logq(lvl)
+        cts = [_rand_crt(o, npr, 7000 + i) for i in range(B)]
+        arr = gu.to_dev(np.concatenate(cts))                              # u32[B*np][crtLen]
+        # forward transforms of the whole array, then products over index pairs
+        ntt = gu.empty_u64(B * npr, q.nttLen)
+        gu.ck(gu.lib.cuhe_hip_ntt_rows(ntt.data_ptr(), arr.data_ptr(), B * npr, 0, None))
+        pairs = [(0, 1), (2, 2), (4, 0), (3, 1)]
+        ia = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=gu.DEV)
+        ib = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=gu.DEV)
+        prod = gu.empty_u64(len(pairs) * npr, q.nttLen)
+        gu.ck(gu.lib.cuhe_hip_ntt_mul_pairs(prod.data_ptr(), ntt.data_ptr(), ia.data_ptr(), ib.data_ptr(), len(pairs), npr, 0, None))
+        red = gu.empty_u32(len(pairs) * npr, q.crtLen)
+        gu.ck(gu.lib.cuhe_hip_intt_mod_batch(red.data_ptr(), prod.data_ptr(), lvl, len(pairs), 0, None))
+        got = gu.host_u32(red).reshape(len(pairs), npr, q.crtLen)
+        for t, (x, y) in enumerate(pairs):
+            want = g.intt_mod(o.ntt_mul(o.ntt(cts[x]), o.ntt(cts[y])), lvl)
+            assert np.array_equal(got[t], want), ("pairs", t)
+        # modulus switching of the whole array: packed [B][np-1][crtLen]
+        ms = gu.empty_u32(B * (npr - 1), q.crtLen)
+        gu.ck(gu.lib.cuhe_hip_crt_mod_switch_batch(ms.data_ptr(), arr.data_ptr(), lvl, B, 0, None))
+        gotms = gu.host_u32(ms).reshape(B, npr - 1, q.crtLen)
+        for i in range(B):
+            assert np.array_equal(gotms[i], o.modswitch(cts[i])[:npr - 1]), ("modswitch", i)
+        # index-list sums with constants: out0 = c0 + c3 + 1, out1 = c1, out2 = c2 + c4 + c0 (second source array = products)
+        lists = [[0, 3], [1], [2, 4, 0, B + 1]]
+        consts = [1, 0, 0]
+        off = torch.tensor(np.cumsum([0] + [len(l) for l in lists]), dtype=torch.int32, device=gu.DEV)
+        lst = torch.tensor([e for l in lists for e in l], dtype=torch.int32, device=gu.DEV)
+        cst = torch.tensor(consts, dtype=torch.int32, device=gu.DEV)
+        out = gu.empty_u32(len(lists) * npr, q.crtLen)
+        gu.ck(gu.lib.cuhe_hip_crt_combine(out.data_ptr(), arr.data_ptr(), B, red.data_ptr(), off.data_ptr(), lst.data_ptr(), cst.data_ptr(),
+                                        len(lists), lvl, 0, None))
+        gotc = gu.host_u32(out).reshape(len(lists), npr, q.crtLen)
+        primes = np.array(g.crt_primes()[:npr], dtype=np.uint64).reshape(npr, 1)
+        pool = cts + [got[t] for t in range(len(pairs))]
+        for oi, (l, c) in enumerate(zip(lists, consts)):
+            acc = np.zeros((npr, q.crtLen), dtype=np.uint64)
+            for e in l:
+                acc += pool[e].astype(np.uint64)
+            acc[:, 0] += c
+            assert np.array_equal(gotc[oi], (acc % primes).astype(np.uint32)), ("combine", oi)
+    finally:
+        g.close(); o.close()
