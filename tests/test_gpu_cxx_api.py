@@ -64,3 +64,23 @@ def test_prince_known_answer(flags):
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
     assert r.stdout.count("right") == 13
+
+
+def test_prince_known_answer_on_arrays():
+    """The same circuit evaluated layer by layer with the gates on ARRAYS of ciphertexts of include/cuhe_hip.h
+    (tests/cxx/test_prince_batched.cpp: ~12 calls per S-box layer over 64-224 ciphertexts each).  Same known answer and
+    round states as test_prince_known_answer."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    import __graft_entry__ as ge
+    ge.build()
+    cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
+    subprocess.check_call(["make", "-C", cxx, "-s", "test"])
+    exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_batched")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
+    assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
+    assert r.stdout.count("right") == 13
