@@ -116,8 +116,9 @@ struct Machine {
 		CK(cuhe_hip_crt_mod_switch_batch(K, K2, l1, 128, 0, NULL));
 		level += 2;
 	}
-	// state[i] = sum of state[src] for src in from[i]  +  k1[i] if addK1  +  extra key terms  +  constant bit
-	void linear(const std::vector<std::vector<int>> &from, u64x rc, bool addK1, const std::vector<std::vector<int>> *keyTerms) {
+	// table of a linear layer: state[i] = sum of state[src] for src in from[i]  +  k1[i] if addK1  +  extra key terms
+	// +  constant bit.  Entries >= 64 address the key array K = [k1 | k0].
+	static Csr linearTable(const std::vector<std::vector<int>> &from, u64x rc, bool addK1, const std::vector<std::vector<int>> *keyTerms) {
 		std::vector<std::vector<int>> lists(64); std::vector<int> consts(64);
 		for (int i = 0; i < 64; ++i) {
 			lists[i] = from[i];
@@ -126,10 +127,11 @@ struct Machine {
 			consts[i] = (int)((rc >> (63 - i)) & 1);
 		}
 		Csr csr; csr.set(lists, consts);
+		return csr;
+	}
+	void linear(const Csr &csr) {
 		CK(cuhe_hip_crt_combine(S2, S, 64, K, csr.off.p, csr.list.p, csr.add.p, 64, level, 0, NULL));
-		CK(cuhe_hip_stream_sync(0, NULL));                                        // the tables above die with this scope
 		std::swap(S, S2);
-		cuhe_hip_free(0, csr.off.p); cuhe_hip_free(0, csr.list.p); cuhe_hip_free(0, csr.add.p);
 	}
 	u64x decryptState(bool &constant) {
 		CK(cuhe_hip_stream_sync(0, NULL));
@@ -190,28 +192,29 @@ int main(int argc, char **argv) {
 		}
 		++layer;
 	};
+	// the tables of the linear layers (round constants, key additions, M', shift rows) are circuit constants: built once
+	std::vector<std::vector<int>> k0terms(64), k0p(64);
+	for (int i = 0; i < 64; ++i) { k0terms[i] = {64 + i}; k0p[i] = {64 + (i + 63) % 64}; }     // K[64..127] = k0
+	k0p[63].push_back(64 + 0);                                                                   // k0' = (k0 >>> 1) ^ (k0 >> 63)
+	const Csr whitenIn = Machine::linearTable(ident, RC[0], true, &k0terms);
+	std::vector<Csr> fwdRound(6), keyRc(11);
+	for (int i = 1; i <= 5; ++i) fwdRound[i] = Machine::linearTable(mpSr, RC[i], true, NULL);
+	const Csr middle = Machine::linearTable(mp, 0, false, NULL), invMix = Machine::linearTable(srInvMp, 0, false, NULL);
+	for (int i = 6; i <= 10; ++i) keyRc[i] = Machine::linearTable(ident, RC[i], true, NULL);
+	const Csr whitenOut = Machine::linearTable(ident, RC[11], true, &k0p);
 	CK(cuhe_hip_stream_sync(0, NULL));
 	const auto t0 = clk::now();
-	{	// state = m ^ k0 ^ k1 ^ RC0
-		std::vector<std::vector<int>> k0terms(64);
-		for (int i = 0; i < 64; ++i) k0terms[i] = {64 + i};                       // K[64..127] = k0
-		M.linear(ident, RC[0], true, &k0terms);
-	}
-	for (int i = 1; i <= 5; ++i) { M.sboxLayer(M.sboxFwd); check(); M.linear(mpSr, RC[i], true, NULL); }
+	M.linear(whitenIn);                                  // state = m ^ k0 ^ k1 ^ RC0
+	for (int i = 1; i <= 5; ++i) { M.sboxLayer(M.sboxFwd); check(); M.linear(fwdRound[i]); }
 	M.sboxLayer(M.sboxFwd); check();
-	M.linear(mp, 0, false, NULL);
+	M.linear(middle);
 	M.sboxLayer(M.sboxInv); check();
 	for (int i = 6; i <= 10; ++i) {
-		M.linear(ident, RC[i], true, NULL);
-		M.linear(srInvMp, 0, false, NULL);
+		M.linear(keyRc[i]);
+		M.linear(invMix);
 		M.sboxLayer(M.sboxInv); check();
 	}
-	{	// ^ RC11 ^ k1 ^ k0', k0' = (k0 >>> 1) ^ (k0 >> 63)
-		std::vector<std::vector<int>> k0p(64);
-		for (int i = 0; i < 64; ++i) k0p[i] = {64 + (i + 63) % 64};
-		k0p[63].push_back(64 + 0);
-		M.linear(ident, RC[11], true, &k0p);
-	}
+	M.linear(whitenOut);                                 // ^ RC11 ^ k1 ^ k0'
 	CK(cuhe_hip_stream_sync(0, NULL));
 	const double encSeconds = std::chrono::duration<double>(clk::now() - t0).count() - paused;
 	bool constant; const u64x got = M.decryptState(constant);
