@@ -82,6 +82,8 @@ struct DevCtx {
     std::vector<IcrtLevel> icrt;
     // Barrett tables / scratch (cuhe/Operations.cu:193-209, Base.cu:181-223)
     u64 *u_ntt = nullptr, *m_ntt = nullptr;
+    u64 *uh_ntt = nullptr, *mh_ntt = nullptr;      // folded reduction: half-length transforms of U and Phi mod (x^Lh - 1)
+    FoldGeom fold{0, 0, 0, 0, 0}; bool fold_ok = false;
     u32 *m_crt = nullptr;
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *ek = nullptr;
@@ -106,6 +108,7 @@ struct Global {
     std::vector<int32_t> modulus;
     int reduce_kind = 0;                 // 0 generic, 1 x^n+1, 2 prime m
     bool force_generic = false;
+    bool no_fold = false;          // tests: take the five-transform form of the generic reduction
     bool allocator_on = false;
     size_t cache_cap = (size_t)4 << 30;  // with the pooled allocator off, freed blocks are still kept up to this many bytes
     int ntt_chunk = 0;
@@ -490,6 +493,26 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
         HIPCHK(hipMemcpyAsync(Ws.b_alias, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
         src = Ws.b_alias;
     }
+    if (D.fold_ok && fuse_mul && !G_.no_fold) {
+        // Folded form: Phi_m divides x^m - 1, so f is first folded to g = f mod (x^m - 1) (length D = min(m, 2n-1)); the
+        // quotient q = floor(g / Phi) then has only Kq = D - n coefficients and comes from the top Kq coefficients of g
+        // (reversed) times the inverse series of rev(Phi), a product that fits the HALF-length transform; and since
+        // r = g - q Phi has degree < n <= Lh it can be formed modulo x^Lh - 1, i.e. with a half-length cyclic product.
+        // 4 half-length transforms + 3 elementwise kernels instead of 4 full-length transforms + 1.
+        const FoldGeom &Gf = D.fold;
+        const int Lh = Gf.Lh, hl = Lh / 2;
+        u32 *A = Ws.b_crt, *C = Ws.b_mq, *R2 = Ws.b_mq;
+        const dim3 gh((hl + 255) / 256, np);
+        hipLaunchKernelGGL(k_fold_top_rev, gh, dim3(256), 0, st, A, src, pt, Gf, L, np_mod);
+        CHK(run_ntt(Lh, kSrcU32Ext, Ws.b_ntt, A, np, hl, Lh, Lh, 0, wa, dev, st, nullptr, D.uh_ntt + (size_t)prime0 * Lh, np_mod));
+        CHK(run_ntt(Lh, kSrcU64Neg, C, Ws.b_ntt, np, Lh, hl, hl, prime0, wa, dev, st, nullptr, nullptr, np_mod));        // A * U, first Lh/2 coefficients
+        hipLaunchKernelGGL(k_rev_quotient, gh, dim3(256), 0, st, A, C, Gf);                                            // A <- q
+        CHK(run_ntt(Lh, kSrcU32Ext, Ws.b_ntt, A, np, hl, Lh, Lh, 0, wa, dev, st, nullptr, D.mh_ntt + (size_t)prime0 * Lh, np_mod));
+        CHK(run_ntt(Lh, kSrcU64Neg, R2, Ws.b_ntt, np, Lh, Lh, n, prime0, wa, dev, st, nullptr, nullptr, np_mod));       // q * Phi mod (x^Lh - 1)
+        hipLaunchKernelGGL(k_fold_final, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, R2, pt, Gf, cl, L, np_mod);
+        HIPCHK(hipGetLastError());
+        return CUHE_OK;
+    }
     const long pairs = (long)rows / 2;
     const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
     CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, src + (n - 1), np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? u_ntt : nullptr, np_mod));   // (f >> (n-1)) * u
@@ -559,6 +582,32 @@ int init_device(int dev) {
     u32 *tmp = nullptr;
     CHK(upload(&tmp, hu));
     WindowArgs wa{0, 0, 0};
+    // folded form of the generic reduction (barrett_impl): applicable when the half-length transform exists
+    // (Lh >= 16384) and the quotient fits its half-length input
+    {
+        const int m = q.mSize, Lh = L / 2, Dg = (m < 2 * n - 1) ? m : 2 * n - 1, Kq = Dg - n;
+        D.fold_ok = G_.reduce_kind == 0 && lg_index(Lh) >= 0 && Kq >= 1 && Kq <= Lh / 2 && Kq <= n - 1 && n <= Lh;
+        if (D.fold_ok) {
+            D.fold = FoldGeom{n, m, Dg, Kq, Lh};
+            std::vector<u64> huh((size_t)pnum * Lh), hmh((size_t)pnum * Lh);
+            std::vector<uint64_t> a(Lh);
+            for (int i = 0; i < pnum; ++i) {
+                std::fill(a.begin(), a.end(), 0);
+                for (int j = 0; j < Kq; ++j) a[j] = host::smod(u[n - 1 - j], hp[i]);          // inverse series of rev(Phi), Kq terms
+                host::ntt_host(a, Lh);
+                for (int t = 0; t < Lh; ++t) huh[(size_t)i * Lh + t] = (u64)a[t];
+                std::fill(a.begin(), a.end(), 0);
+                for (int k = 0; k <= n; ++k) {                                                // Phi mod (x^Lh - 1)
+                    const uint32_t c = k < n ? host::smod(G_.modulus[k], hp[i]) : 1u;
+                    a[k % Lh] = (a[k % Lh] + c) % hp[i];
+                }
+                host::ntt_host(a, Lh);
+                for (int t = 0; t < Lh; ++t) hmh[(size_t)i * Lh + t] = (u64)a[t];
+            }
+            CHK(upload(&D.uh_ntt, huh)); CHK(upload(&D.mh_ntt, hmh));
+            CHK(ensure_ntt(dev, Lh, pnum));
+        }
+    }
     CHK(run_ntt(L, kSrcU32Ext, D.u_ntt, tmp, pnum, cl, L, L, 0, wa, dev, 0));
     CHK(run_ntt(L, kSrcU32Ext, D.m_ntt, D.m_crt, pnum, cl, L, L, 0, wa, dev, 0));
     HIPCHK(hipDeviceSynchronize());
@@ -691,7 +740,7 @@ int cuhe_hip_shutdown(void) {
         DevCtx &D = G_.dev[d];
         for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
-        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.m_crt, D.ek};
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek};
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);
         for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
@@ -721,7 +770,7 @@ int cuhe_hip_get_crt_primes(uint32_t *out, int cap) {
     return CUHE_OK;
 }
 int cuhe_hip_reduce_kind(void) { return G_.force_generic ? 0 : G_.reduce_kind; }
-int cuhe_hip_force_generic_reduce(int on) { G_.force_generic = on != 0; return CUHE_OK; }
+int cuhe_hip_force_generic_reduce(int on) { G_.force_generic = on != 0; G_.no_fold = on == 2; return CUHE_OK; }
 
 // ---------------------------------------------------------------- allocator
 int cuhe_hip_start_allocator(void) { G_.allocator_on = true; return CUHE_OK; }   // no "grab all VRAM" 

@@ -199,6 +199,29 @@ inline bool barrett_u(const std::vector<int32_t> &mod, std::vector<long long> &u
     return true;
 }
 
+// in-place length-`len` transform X[i] = sum_j a[j] w^(ij), w = G^(65536/len), natural order in and out (the
+// device transform's definition, tests/test_ntt.cu:44-55), for tables built at init time
+inline void ntt_host(std::vector<uint64_t> &a, int len) {
+    int lg = 0; while ((1 << lg) < len) ++lg;
+    for (int i = 0; i < len; ++i) {
+        int r = 0; for (int b = 0; b < lg; ++b) if (i & (1 << b)) r |= 1 << (lg - 1 - b);
+        if (i < r) std::swap(a[i], a[r]);
+    }
+    for (int half = 1; half < len; half <<= 1) {
+        const uint64_t wl = powP(G, (uint64_t)(65536 / (2 * half)));
+        for (int s0 = 0; s0 < len; s0 += 2 * half) {
+            uint64_t w = 1;
+            for (int j = 0; j < half; ++j) {
+                const uint64_t u = a[s0 + j], v = mulP(a[s0 + j + half], w);
+                uint64_t x = u + v; if (x < u || x >= P) x -= P;
+                a[s0 + j] = x;
+                a[s0 + j + half] = u >= v ? u - v : u + (P - v);
+                w = mulP(w, wl);
+            }
+        }
+    }
+}
+
 inline uint32_t smod(long long v, uint32_t p) { long long r = v % (long long)p; return (uint32_t)(r < 0 ? r + p : r); }
 
 }}  // namespace cuhe::host

@@ -81,7 +81,8 @@ int cuhe_hip_get_coeff_modulus(int lvl, uint8_t *le_bytes, size_t cap, size_t *l
 int cuhe_hip_get_crt_primes(uint32_t *out, int cap);
 /* which fused poly-reduction the context selected: 0 = generic NTT Barrett, 1 = x^n+1, 2 = prime m */
 int cuhe_hip_reduce_kind(void);
-/* force the generic Barrett path (tests) */
+/* tests: 1 = force the generic NTT-Barrett path on rings that have a special kernel; 2 = additionally take its
+   five-transform form instead of the folded one; 0 = default */
 int cuhe_hip_force_generic_reduce(int on);
 
 /* ---- allocator: startAllocator / stopAllocator (cuhe/CuHE.h:156,159; DeviceManager.cu:50-138) */

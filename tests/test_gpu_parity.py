@@ -200,13 +200,14 @@ def test_intt_mod_both_paths(ctxpair, gu):
             X = o.ntt_mul(o.ntt(a), o.ntt(b))
             want = o.intt_mod(X)
             assert np.array_equal(g.intt_mod(X, lvl), want)
-            gu.ck(gu.lib.cuhe_hip_force_generic_reduce(1))       # cuhe/Operations.cu:460-501 path
-            try:
-                assert gu.lib.cuhe_hip_reduce_kind() == 0
-                assert np.array_equal(g.intt_mod(X, lvl), want)
-                assert np.array_equal(g.barrett(o.intt_hold(X), lvl), want)
-            finally:
-                gu.ck(gu.lib.cuhe_hip_force_generic_reduce(0))
+            for force in (1, 2):       # 1: generic path (folded form where the ring allows it); 2: the five-transform
+                gu.ck(gu.lib.cuhe_hip_force_generic_reduce(force))       # form of cuhe/Operations.cu:460-501
+                try:
+                    assert gu.lib.cuhe_hip_reduce_kind() == 0
+                    assert np.array_equal(g.intt_mod(X, lvl), want)
+                    assert np.array_equal(g.barrett(o.intt_hold(X), lvl), want)
+                finally:
+                    gu.ck(gu.lib.cuhe_hip_force_generic_reduce(0))
 
 
 def test_modswitch(ctxpair):
