@@ -84,7 +84,8 @@ __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
         "v_mad_u64_u32 %0, vcc, %1, %4, %0"
         : "=&v"(r), "=&v"(f), "=&s"(tmp)
         : "v"(m), "v"(0xffffffffu), "v"(lo), "s"(kPc)
-        : "vcc");
+        : "vcc", "scc");           // s_or_b64 writes SCC: without the clobber a uniform compare-and-branch around
+                                   // the block can be fed a stale flag (seen as unwritten outputs in one kernel variant)
     return r;
 #elif CUHE_MADEPS_VARIANT == 2
     u64 r = (u64)m * 0xffffffffu + lo;
