@@ -151,40 +151,6 @@ void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt
 }
 
 // ---------------------------------------------------------------- polynomial Barrett pieces
-// y[crt][off+idx] = (y - x) mod p for idx < count  (barrett_sub_1: off=mlen,count=mlen; barrett_sub_2: off=0,count=nlen;
-// Base.cu:951-977).  Inputs are residues < p.
-__global__ __launch_bounds__(256)
-void k_barrett_sub(u32 *__restrict__ y, const u32 *__restrict__ x, PrimeTab pt, int off, int count, int nlen) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= count) return;
-    const long o = (long)crt * nlen + off + idx;
-    u32 a = y[o], b = x[o];
-    if (a < b) a += pt.p[crt];
-    y[o] = a - b;
-}
-// barrett_sub_mc (Base.cu:978-1001): if coefficient mlen of row crt is nonzero subtract m (idx < mlen-1)
-__global__ __launch_bounds__(256)
-void k_barrett_sub_mc(u32 *__restrict__ x, const u32 *__restrict__ m_crt, PrimeTab pt, int mlen, int clen, int nlen) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= mlen - 1) return;
-    if (x[(long)crt * nlen + mlen] == 0) return;
-    u32 d = x[(long)crt * nlen + idx], s = m_crt[(long)crt * clen + idx];
-    if (d < s) d += pt.p[crt];
-    x[(long)crt * nlen + idx] = d - s;
-}
-// zero x[crt][0..count)
-__global__ __launch_bounds__(256)
-void k_zero_rows(u32 *__restrict__ x, int count, int nlen) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < count) x[(long)crt * nlen + idx] = 0;
-}
-// dst[crt][0..clen) = src[crt][0..clen) with row strides nlen -> clen
-__global__ __launch_bounds__(256)
-void k_gather_rows(u32 *__restrict__ dst, const u32 *__restrict__ src, int clen, int nlen) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < clen) dst[(long)crt * clen + idx] = src[(long)crt * nlen + idx];
-}
-
 // Last step of the NTT-based Barrett reduction, fused (replaces barrett_sub x2, barrett_sub_mc and the strided gather
 // of Base.cu:951-1001):  f = polynomial to reduce (row stride nlen, residues < p), qrow = quotient q stored at offset
 // mlen of its row, mq = ((m - x^n) q) mod p.  r = f - q x^n - (m - x^n) q has degree <= n; for idx < n the q x^n term
