@@ -777,3 +777,20 @@ def test_array_gates_equal_single_gates(gu, args):
             assert np.array_equal(gotc[oi], (acc % primes).astype(np.uint32)), ("combine", oi)
     finally:
         g.close(); o.close()
+
+
+def test_config2_roundtrip_8_primes(gu):
+    """BASELINE config 2: N = 2^14 (32K-point transforms), 8 CRT primes: forward + inverse round trip is the identity and
+    the forward transform equals the oracle's, for residues spanning the whole range [0, p_i)."""
+    import oracle_lib as O
+    args = (1, 2, 16, 200, 25, 32768)
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        assert (q.modLen, q.nttLen, q.numCrtPrime) == (16384, 32768, 8)
+        a = _rand_crt(o, 8, 77, True)
+        X = g.ntt(a, 0)
+        assert np.array_equal(X, o.ntt(a))
+        assert np.array_equal(g.intt(X, 0), a)
+    finally:
+        g.close(); o.close()
