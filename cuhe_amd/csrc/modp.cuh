@@ -25,10 +25,20 @@ static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
 // profiles/r01_ubench_modp.txt): the add is done as a - (P - b) with a mask-and-subtract fix-up, which
 // needs one compare instead of two compares + s_or.
 #ifndef CUHE_SUBP_VARIANT
-#define CUHE_SUBP_VARIANT 1
+#define CUHE_SUBP_VARIANT 3
 #endif
 __device__ __forceinline__ u64 subp(u64 a, u64 b) {
-#if CUHE_SUBP_VARIANT == 1
+#if CUHE_SUBP_VARIANT == 3
+    // the borrow of the two-instruction 64-bit subtraction comes out as a lane mask in an SGPR pair and is handed to the
+    // compiler through inverse_ballot (written in C the borrow is rebuilt with a 64-bit compare: 6 VALU instead of 5)
+    u32 lo, hi; u64 borrow;
+    asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
+        "v_subb_co_u32_e64 %1, %2, %4, %6, %2"
+        : "=&v"(lo), "=&v"(hi), "=&s"(borrow)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)));
+    const u64 d = ((u64)hi << 32) | lo;
+    return __builtin_amdgcn_inverse_ballot_w64(borrow) ? d - kEps : d;
+#elif CUHE_SUBP_VARIANT == 1
     u64 d;
     const bool borrow = __builtin_usubll_overflow(a, b, &d);   // reuse the borrow of v_sub_co/v_subb_co
     return borrow ? d - kEps : d;      // + P
@@ -70,10 +80,18 @@ __device__ __forceinline__ u64 canon(u64 r) {
 #define CUHE_SHLMID_VARIANT 0
 #endif
 #ifndef CUHE_MADEPS_VARIANT
-#define CUHE_MADEPS_VARIANT 3      /* measured: +7 % transforms/s over variant 2 (profiles/r01_experiments_log.txt) */
+#define CUHE_MADEPS_VARIANT 4      /* measured (profiles/r01_experiments_log.txt) */
 #endif
 __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
-#if CUHE_MADEPS_VARIANT == 3
+#if CUHE_MADEPS_VARIANT == 4
+    // Only the multiply-add is asm: its carry-out lands in an SGPR pair (a lane mask), which inverse_ballot hands back
+    // to the compiler as a per-lane boolean.  The OR with the >= P compare, the select and the final add are then
+    // ordinary code the compiler schedules itself (no SCC / VCC clobbers around a block of instructions).
+    u64 r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(m), "v"(0xffffffffu), "v"(lo));
+    const bool f = __builtin_amdgcn_inverse_ballot_w64(carry) | (r >= kP);
+    return (u64)(f ? 1u : 0u) * 0xffffffffu + r;
+#elif CUHE_MADEPS_VARIANT == 3
     // the multiply-add's own carry-out (vcc) replaces the 64-bit compare that rebuilds it: 4 VALU + 1 SALU instead of 5 + 1
     u64 r; u32 f; u64 tmp;
     const u64 kPc = kP;
@@ -107,8 +125,7 @@ __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u64 r = mad_eps(hl, lo);
-    u64 d = r - hh;
-    return (r < hh) ? d - kEps : d;
+    return subp(r, (u64)hh);           // r - hh, + P on borrow (hh < 2^32 is canonical)
 }
 
 // canonical x canonical -> canonical
