@@ -57,14 +57,6 @@ void Picklable::setValuesString() {
 	}
 	values = buffer.str();
 }
-void Picklable::setSeparator(string s) { separator = s; setValuesString(); }
-string Picklable::getSeparator() { return separator; }
-ZZX Picklable::getPoly() { return poly; }
-ZZ *Picklable::getCoeffs() { return coeffs; }
-int Picklable::getCoeffsLen() { return coeffs_len; }
-string Picklable::getKey() { return key; }
-string Picklable::getValues() { return values; }
-string Picklable::pickle() { return key + separator + values; }
 
 PicklableMap::PicklableMap(vector<Picklable *> ps) : picklables(ps) {}
 PicklableMap::PicklableMap(string data) { fromString(data, ","); }
@@ -78,9 +70,6 @@ void PicklableMap::fromString(const string &data, const string &psep) {
 	picklables.clear();
 	for (const string &entry : splitFields(data, separator)) picklables.push_back(new Picklable(entry, psep));
 }
-void PicklableMap::setSeparator(string sep) { separator = sep; }
-string PicklableMap::getSeparator() { return separator; }
-vector<Picklable *> PicklableMap::getPicklables() { return picklables; }
 string PicklableMap::toString() {
 	string out;
 	for (size_t i = 0; i < picklables.size(); i++) {

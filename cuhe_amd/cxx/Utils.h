@@ -37,17 +37,17 @@ public:
 	Picklable(const Picklable &);
 	~Picklable();
 
-	void setSeparator(string);
-	string getSeparator();
+	void setSeparator(string s) { separator = s; setValuesString(); }
+	string getSeparator() { return separator; }
 
-	ZZX getPoly();
-	ZZ *getCoeffs();
-	int getCoeffsLen();
+	ZZX getPoly() { return poly; }
+	ZZ *getCoeffs() { return coeffs; }             // owned by this entry
+	int getCoeffsLen() { return coeffs_len; }
 
-	string getKey();
-	string getValues();
+	string getKey() { return key; }
+	string getValues() { return values; }
 
-	string pickle();                           // "key,c0,c1,..."
+	string pickle() { return key + separator + values; }      // "key,c0,c1,..."
 
 private:
 	Picklable &operator=(const Picklable &);
@@ -67,10 +67,10 @@ public:
 	PicklableMap(string data, string sep, string psep);
 	~PicklableMap();
 
-	void setSeparator(string);
-	string getSeparator();
+	void setSeparator(string sep) { separator = sep; }
+	string getSeparator() { return separator; }
 
-	vector<Picklable *> getPicklables();
+	vector<Picklable *> getPicklables() { return picklables; }
 	string toString();
 
 	Picklable *get(string key);                // throws (const char *)"not found" (DHS.cu:85-90 relies on it)
