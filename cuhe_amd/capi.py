@@ -37,6 +37,7 @@ SIGNATURES = {
     "cuhe_hip_get_level": (i32, [i32]),
     "cuhe_hip_multi_gpus": (i32, [i32]),
     "cuhe_hip_num_gpus": (i32, []),
+    "cuhe_hip_set_virtual_devices": (i32, [i32]),
     "cuhe_hip_set_device_base": (i32, [i32]),
     "cuhe_hip_init": (i32, [vp, i32]),
     "cuhe_hip_shutdown": (i32, []),

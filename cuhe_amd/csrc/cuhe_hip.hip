@@ -103,6 +103,7 @@ struct Global {
     Params prm;
     bool params_set = false, inited = false, relin_ready = false;
     int ndev = 1, dev_base = 0;
+    bool virtual_devices = false;  // tests: logical devices 0..ndev-1 all live on physical device dev_base
     std::vector<uint32_t> primes;
     std::vector<BigU> coeffModulus;
     std::vector<int32_t> modulus;
@@ -123,7 +124,7 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 int set_dev(int dev) {
     if (dev < 0 || dev >= G_.ndev) return fail(CUHE_EINVAL, "device %d out of range (numGPUs=%d)", dev, G_.ndev);
-    HIPCHK(hipSetDevice(G_.dev_base + dev));
+    HIPCHK(hipSetDevice(G_.virtual_devices ? G_.dev_base : G_.dev_base + dev));
     if ((int)G_.dev.size() < G_.ndev) G_.dev.resize(G_.ndev);
     return CUHE_OK;
 }
@@ -681,13 +682,21 @@ int cuhe_hip_get_level(int logq) { return G_.prm.getLevel(logq); }
 int cuhe_hip_multi_gpus(int num) {
     int cnt = 0;
     HIPCHK(hipGetDeviceCount(&cnt));
-    if (num < 1 || G_.dev_base + num > cnt) return fail(CUHE_EINVAL, "multiGPUs(%d): %d device(s) visible", num, cnt);
+    if (num < 1 || (!G_.virtual_devices && G_.dev_base + num > cnt)) return fail(CUHE_EINVAL, "multiGPUs(%d): %d device(s) visible", num, cnt);
     if (G_.inited) return fail(CUHE_EINVAL, "multiGPUs must precede initCuHE (cuhe/DeviceManager.cu:38-41)");
     G_.ndev = num;
     G_.dev.resize(num);
     return CUHE_OK;
 }
 int cuhe_hip_num_gpus(void) { return G_.ndev; }
+// test hook: with `on`, multi_gpus(n) accepts any n and every logical device is backed by the one physical device,
+// each with its own context (tables, keys, allocator, workspaces) -- the in-process multi-device code paths
+// (per-device indexing, moveTo / copyTo) can then be exercised on a single-GPU box
+int cuhe_hip_set_virtual_devices(int on) {
+    if (G_.inited) return fail(CUHE_EINVAL, "set_virtual_devices must precede init");
+    G_.virtual_devices = on != 0;
+    return CUHE_OK;
+}
 int cuhe_hip_set_device_base(int dev) {
     if (G_.inited) return fail(CUHE_EINVAL, "set_device_base must precede init");
     G_.dev_base = dev;
@@ -724,7 +733,7 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
         int r = init_device(dev);
         if (r != CUHE_OK) { G_.inited = false; return r; }
     }
-    for (int i = 0; i < G_.ndev; ++i) {                             // cuhe/CuHE.cu:42-45 peer access
+    for (int i = 0; i < G_.ndev && !G_.virtual_devices; ++i) {      // cuhe/CuHE.cu:42-45 peer access
         hipSetDevice(G_.dev_base + i);
         for (int j = 0; j < G_.ndev; ++j)
             if (i != j) { int can = 0; hipDeviceCanAccessPeer(&can, G_.dev_base + i, G_.dev_base + j);
@@ -881,7 +890,9 @@ int cuhe_hip_memcpy_d2h(int dev, void *d, const void *s, size_t n, void *st) { C
 int cuhe_hip_memcpy_d2d(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st))); return CUHE_OK; }
 int cuhe_hip_memcpy_peer(void *d, int dd, const void *s, int sd, size_t n, void *st) {
     CHK(set_dev(sd));
-    HIPCHK(hipMemcpyPeerAsync(d, G_.dev_base + dd, s, G_.dev_base + sd, n, S(st)));
+    if (dd < 0 || dd >= G_.ndev) return fail(CUHE_EINVAL, "device %d out of range (numGPUs=%d)", dd, G_.ndev);
+    if (G_.virtual_devices) HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st)));
+    else HIPCHK(hipMemcpyPeerAsync(d, G_.dev_base + dd, s, G_.dev_base + sd, n, S(st)));
     return CUHE_OK;
 }
 int cuhe_hip_stream_create(int dev, void **out) {

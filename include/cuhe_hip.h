@@ -70,6 +70,9 @@ int cuhe_hip_num_gpus(void);
 /* Bind the single-device context to HIP device `dev` (default 0).  Used by the
  * one-process-per-GPU launcher so that rank r drives device r as "dev 0". */
 int cuhe_hip_set_device_base(int dev);
+/* test hook: back every logical device of multi_gpus(n) by the one physical device (own context each), so that the
+   in-process multi-device paths can run on a single-GPU box; before init */
+int cuhe_hip_set_virtual_devices(int on);
 
 /* ---- init: initCuHE (cuhe/CuHE.h:153; CuHE.cu:36-50 = initNtt + initCrt + initBarrett).
  * modulus: monic integer polynomial, modLen+1 coefficients low-to-high

@@ -84,3 +84,21 @@ def test_prince_known_answer_on_arrays():
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
     assert r.stdout.count("right") == 13
+
+
+def test_in_process_multi_device_on_virtual_devices():
+    """multiGPUs(3) on one physical GPU (cuhe_hip_set_virtual_devices): mulZZX on every device, moveTo / copyTo,
+    cAnd + relin with the keys resident on another device, one host thread per device (cuhe/CuHE.cu:217-256,
+    examples/Prince/Prince.cu:194-200)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    import __graft_entry__ as ge
+    ge.build()
+    cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
+    subprocess.check_call(["make", "-C", cxx, "-s", "test"])
+    exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_multi_device")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout
