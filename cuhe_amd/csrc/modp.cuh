@@ -25,10 +25,26 @@ static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
 // profiles/r01_ubench_modp.txt): the add is done as a - (P - b) with a mask-and-subtract fix-up, which
 // needs one compare instead of two compares + s_or.
 #ifndef CUHE_SUBP_VARIANT
-#define CUHE_SUBP_VARIANT 3
+#define CUHE_SUBP_VARIANT 4      /* measured (profiles/r01_experiments_log.txt) */
 #endif
 __device__ __forceinline__ u64 subp(u64 a, u64 b) {
-#if CUHE_SUBP_VARIANT == 3
+#if CUHE_SUBP_VARIANT == 4
+    // a - b, then "- eps on borrow" without a select: - eps = + 1 - 2^32, so with the borrow B as a lane mask the low word
+    // takes B as a carry-in (lo + B, carry C) and the high word loses B & ~C.  4 VALU + 1 SALU instead of 5 VALU.
+    // (d >= 2^32 whenever there was a borrow, so the high word cannot underflow.)
+    u32 lo, hi; u64 bw, t;
+    asm("v_sub_co_u32_e64 %0, %2, %4, %6\n\t"
+        "v_subb_co_u32_e64 %1, %2, %5, %7, %2\n\t"
+        "v_addc_co_u32_e64 %0, %3, %0, 0, %2\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"
+        : "=&v"(lo), "=&v"(hi), "=&s"(bw), "=&s"(t)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "scc");
+    u64 d = ((u64)hi << 32) | lo;
+    asm("" : "+v"(d));              // keep the two words a register PAIR: otherwise 64-bit shifts of d are split into word operations
+    return d;
+#elif CUHE_SUBP_VARIANT == 3
     // the borrow of the two-instruction 64-bit subtraction comes out as a lane mask in an SGPR pair and is handed to the
     // compiler through inverse_ballot (written in C the borrow is rebuilt with a 64-bit compare: 6 VALU instead of 5)
     u32 lo, hi; u64 borrow;
