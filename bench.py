@@ -161,6 +161,17 @@ def main():
                                         "note": "under this instruction mix the chip settles near 1.8 GHz "
                                                 "(profiles/r01_effective_clock.txt): ~29 T/s sustained"}
 
+        # measured device-to-device copy ceiling of this box: 1 GiB read + 1 GiB written per copy
+        ca = torch.empty(1 << 28, dtype=torch.int32, device=dev); cb = torch.empty_like(ca)
+        cb.copy_(ca); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            cb.copy_(ca)
+        e1.record(); torch.cuda.synchronize()
+        roofline["measured_copy_GBs"] = round(5 * 2 * ca.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del ca, cb
+
         # ---- correctness spot check against the oracle (never timed, never shipped)
         cpu = None
         if not args.no_cpu:

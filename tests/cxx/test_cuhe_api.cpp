@@ -4,6 +4,10 @@
 // Runs on a GPU box; exit code 0 = all checks passed.
 #include "CuHE.h"
 #include "Relinearization.h"
+#include "cuhe_hip.h"
+#include "Debug.h"
+#include "DeviceManager.h"
+#include "Operations.h"
 #include <cstdio>
 #include <vector>
 using namespace cuHE;
@@ -139,6 +143,54 @@ int main() {
 			SetCoeff(ms, i, ((v - dl) / pt) % q[1]);
 		}
 		CHECK(keep.zRep() == ms, "modSwitch = (c - delta)/p_t with delta = c mod p_t made even");
+	}
+	// ---- the second tier, cuhe/Operations.h:42-108: raw-pointer drivers called directly, the way cuhe/CuHE.cu strings
+	//      them together (crt / ntt / nttMul / inttMod / icrt = the body of mulZZX, CuHE.cu:259-268 + :350-408), and the
+	//      other two roads to a reduced product: inttDoubleDeg + barrett(dst, src) and inttHold + barrett(dst)
+	{
+		selectDevice(0);
+		ZZX a = randomPoly(n, q[0]), b = randomPoly(n, q[0]);
+		const ZZX want = hostMul(a, b, phi, q[0], n);
+		CuCtxt ca, cb; ca.setLevel(0, 0, a); cb.setLevel(0, 0, b);
+		ca.x2r(); cb.x2r();
+		const int logq = ca.logq(), np = param._numCrtPrime(0);
+		const size_t crtBytes = (size_t)np * param.crtLen * sizeof(uint32), nttBytes = (size_t)np * param.nttLen * sizeof(uint64);
+		uint32 *ac = (uint32 *)deviceMalloc(crtBytes), *bc = (uint32 *)deviceMalloc(crtBytes), *rc = (uint32 *)deviceMalloc(crtBytes);
+		uint32 *dbl = (uint32 *)deviceMalloc((size_t)np * param.nttLen * sizeof(uint32));
+		uint64 *an = (uint64 *)deviceMalloc(nttBytes), *bn = (uint64 *)deviceMalloc(nttBytes), *pn = (uint64 *)deviceMalloc(nttBytes);
+		crt(ac, ca.rRep(), logq, 0); crt(bc, cb.rRep(), logq, 0);
+		ntt(an, ac, logq, 0); ntt(bn, bc, logq, 0);
+		nttMul(pn, an, bn, logq, 0);
+		auto rawToZZX = [&](uint32 *crtRows) { CuCtxt o; o.setLevel(0, 1, 0); icrt(o.rRep(), crtRows, logq, 0); o.x2z(); return o.zRep(); };
+		inttMod(rc, pn, logq, 0);
+		CHECK(rawToZZX(rc) == want, "Operations.h: crt, ntt, nttMul, inttMod, icrt by hand = mulZZX");
+		inttDoubleDeg(dbl, pn, logq, 0);
+		barrett(rc, dbl, 0, 0);
+		CHECK(rawToZZX(rc) == want, "Operations.h: inttDoubleDeg + barrett(dst, src)");
+		inttHold(pn, logq, 0);
+		barrett(rc, 0, 0);
+		CHECK(rawToZZX(rc) == want, "Operations.h: inttHold + barrett(dst)");
+		// sums in both domains, and a product with one polynomial for all primes' rows replaced by a full set (nttAdd)
+		crtAdd(rc, ac, bc, logq, 0);
+		CHECK(rawToZZX(rc) == reduceCoeffs(a + b, q[0], n), "Operations.h: crtAdd");
+		nttAdd(pn, an, bn, logq, 0);
+		intt(rc, pn, logq, 0);
+		CHECK(rawToZZX(rc) == reduceCoeffs(a + b, q[0], n), "Operations.h: nttAdd + intt");
+		crtAddInt(bc, bc, 5, logq, 0);              // writes the constant terms only (cuhe/Base.cu:1096-1100): used in place
+		{ ZZX w5 = b; SetCoeff(w5, 0, (coeff(b, 0) + 5) % q[0]); CHECK(rawToZZX(bc) == w5, "Operations.h: crtAddInt (in place)"); }
+		// single-row forms: _intt(_ntt(row)) gives the row back, zero-padded to nttLen
+		{
+			std::vector<uint32> row(param.crtLen), back(param.nttLen);
+			_ntt(an, ac, 0);
+			_intt(dbl, an, 0, 0);
+			CSC(cuhe_hip_memcpy_d2h(0, row.data(), ac, row.size() * 4, 0));
+			CSC(cuhe_hip_memcpy_d2h(0, back.data(), dbl, back.size() * 4, 0));
+			CSC(cuhe_hip_stream_sync(0, 0));
+			bool same = true;
+			for (int i = 0; i < param.nttLen; ++i) same = same && back[i] == (i < param.crtLen ? row[i] : 0u);
+			CHECK(same, "Operations.h: _intt(_ntt(row)) = row");
+		}
+		for (void *ptr : {(void *)ac, (void *)bc, (void *)rc, (void *)dbl, (void *)an, (void *)bn, (void *)pn}) deviceFree(ptr);
 	}
 	// ---- ownership rules the examples rely on (Prince.cu:298-319: explicit destructor, then scope exit)
 	{
