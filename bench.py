@@ -136,16 +136,17 @@ def main():
         # traffic: corrected FETCH_SIZE + WRITE_SIZE per launch pair from the committed rocprofv3 PMC passes of this
         # same command (profiles/traffic_r*.json); PMC collection cannot run inside the timed process.
         traffic = None
+        per_launch = min(B, args.chunk if args.chunk else (256 << 20) // (L * 8))     # transforms per launch pair (library default: 256 MiB slab)
         try:
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
             if tf and L == 65536:
-                traffic = json.load(open(tf[-1]))["bytes_per_launch_pair"]
+                traffic = json.load(open(tf[-1]))["bytes_per_transform"] * per_launch
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_note": "HBM-side bytes per launch pair (256 transforms) from profiles/traffic_r*.json; algorithmic = 167772160",
+                    "traffic_note": "HBM-side bytes per launch pair (%d transforms) from profiles/traffic_r*.json; algorithmic = %d" % (per_launch, per_launch * alg_bytes),
                     "kernel": "ntt_pass1w<16,0> + ntt_pass2w<16,0> (wave-split forms; one transform = one launch pair)",
                     "algorithmic_bytes_per_transform": alg_bytes,
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),

@@ -281,8 +281,8 @@ int ensure_ntt(int dev, int len, int batch_hint) {
         else if (li == 1) CHK(make_ntt_tables<15>(tab));
         else CHK(make_ntt_tables<16>(tab));
     }
-    // transforms per launch pair: 128 MiB slabs by default (profiles/r01_chunk_sweep.txt)
-    int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (128 << 20) / (len * 8);
+    // transforms per launch pair
+    int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (256 << 20) / (len * 8);     // slab of 256 MiB: profiles/r01_chunk_sweep.txt
     if (chunk < 8) chunk = 8;
     tab.chunk = (chunk + 7) & ~7;
     DevCtx &D = G_.dev[dev];

@@ -28,6 +28,7 @@ static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
 #define CUHE_SUBP_VARIANT 4      /* measured (profiles/r01_experiments_log.txt) */
 #endif
 __device__ __forceinline__ u64 subp(u64 a, u64 b) {
+    if (__builtin_constant_p(b) && b == 0) return a;     // e.g. the bits above 2^96 of a shifted 32-bit sample: the asm below would hide the zero
 #if CUHE_SUBP_VARIANT == 4
     // a - b, then "- eps on borrow" without a select: - eps = + 1 - 2^32, so with the borrow B as a lane mask the low word
     // takes B as a carry-in (lo + B, carry C) and the high word loses B & ~C.  4 VALU + 1 SALU instead of 5 VALU.
@@ -99,6 +100,7 @@ __device__ __forceinline__ u64 canon(u64 r) {
 #define CUHE_MADEPS_VARIANT 4      /* measured (profiles/r01_experiments_log.txt) */
 #endif
 __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
+    if (__builtin_constant_p(m) && m == 0) return canon(lo);      // small shifts of 32-bit samples: nothing above 2^64 (canon folds too)
 #if CUHE_MADEPS_VARIANT == 4
     // Only the multiply-add is asm: its carry-out lands in an SGPR pair (a lane mask), which inverse_ballot hands back
     // to the compiler as a per-lane boolean.  The OR with the >= P compare, the select and the final add are then
