@@ -152,10 +152,10 @@ def main():
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),
                     "pass1_ms_per_batch": round(ms1.value / iters, 4), "pass2_ms_per_batch": round(ms2.value / iters, 4)}
         if L == 65536:
-            # the limiter that actually binds: the pair executes 11.27 M VALU lane-instructions per
-            # transform (SQ_INSTS_VALU x 64, profiles/r01_final4_ntt64k_pmc.txt); every instruction of the mix issues at
+            # the limiter that actually binds: the pair executes 10.33 M VALU lane-instructions per
+            # transform (SQ_INSTS_VALU x 64, profiles/r01_final5_ntt64k_pmc.txt); every instruction of the mix issues at
             # ~60 lanes/clk/CU (profiles/r01_ubench_valu.txt), i.e. 256 CU x 64 lanes x clock lane-instructions/s
-            lane_instr = 11.27e6
+            lane_instr = 10.33e6
             got = n_tr * lane_instr / pair_s / 1e12
             roofline["valu_ceiling"] = {"lane_instructions_per_transform": lane_instr, "achieved_T_per_s": round(got, 2),
                                         "peak_T_per_s_at_2.4GHz": 39.3, "frac_of_2.4GHz_peak": round(got / 39.3, 3),
