@@ -22,7 +22,7 @@
 // --async switches the library to asynchronous gates (setAsynchronous, an addition to the reference API): the ~100
 // gates and conversions of an S-box are enqueued back to back and synchronised once.
 //
-// usage: test_prince_flow [--no-round-checks] [--threads T] [--async]
+// usage: test_prince_flow [--no-round-checks] [--threads T] [--async] [--devices N [--virtual]]
 #include "dhs_client.hpp"
 #include "prince_common.hpp"
 #include <atomic>
@@ -38,18 +38,23 @@ typedef std::chrono::steady_clock clk;
 
 // ------------------------------------------------------------------ T persistent host threads, one stream each
 struct Pool {
-	typedef std::function<void(int, cudaStream_t)> Job;
-	int T;
+	typedef std::function<void(int, cudaStream_t, int)> Job;          // (item, stream, device of the thread that runs it)
+	int T, ndev;
 	std::vector<std::thread> threads;
-	std::vector<void *> streams;
+	std::vector<void *> streams, home;           // per thread: a stream on its own device, and one on device 0 (where the state lives)
 	std::mutex m;
 	std::condition_variable cvStart, cvDone;
-	Job job; int count = 0, gen = 0, running = 0; bool stop = false;
+	Job job; int count = 0, gen = 0, running = 0; bool stop = false, spread = false;
 	std::atomic<int> next{0};
-	explicit Pool(int t) : T(t) {
+	Pool(int t, int devices) : T(t), ndev(devices) {
 		if (T <= 1) return;
 		streams.resize(T, NULL);
-		for (int i = 0; i < T; ++i) if (cuhe_hip_stream_create(0, &streams[i]) != 0) { printf("cannot create a stream\n"); exit(2); }
+		home.resize(T, NULL);
+		for (int i = 0; i < T; ++i) {
+			if (cuhe_hip_stream_create(i % ndev, &streams[i]) != 0) { printf("cannot create a stream\n"); exit(2); }
+			if (i % ndev == 0) home[i] = streams[i];
+			else if (cuhe_hip_stream_create(0, &home[i]) != 0) { printf("cannot create a stream\n"); exit(2); }
+		}
 		for (int i = 0; i < T; ++i) threads.emplace_back([this, i] { worker(i); });
 	}
 	~Pool() {
@@ -57,23 +62,30 @@ struct Pool {
 		{ std::lock_guard<std::mutex> lk(m); stop = true; }
 		cvStart.notify_all();
 		for (auto &t : threads) t.join();
-		for (void *s : streams) cuhe_hip_stream_destroy(0, s);
+		for (int i = 0; i < T; ++i) { cuhe_hip_stream_destroy(i % ndev, streams[i]); if (home[i] != streams[i]) cuhe_hip_stream_destroy(0, home[i]); }
 	}
 	void worker(int t) {
 		int seen = 0;
 		for (;;) {
 			{ std::unique_lock<std::mutex> lk(m); cvStart.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
-			for (int i; (i = next.fetch_add(1)) < count;) { job(i, (cudaStream_t)streams[t]); finish((cudaStream_t)streams[t]); }
+			const int dev = spread ? t % ndev : 0;
+			const cudaStream_t st = (cudaStream_t)(spread ? streams[t] : home[t]);
+			for (int i; (i = next.fetch_add(1)) < count;) { job(i, st, dev); finish(st, dev); }
 			{ std::lock_guard<std::mutex> lk(m); if (--running == 0) cvDone.notify_one(); }
 		}
 	}
 	// with asynchronous gates an item's work is only enqueued when job() returns: wait for it before the item's results
 	// can be used from another stream (one synchronisation per S-box instead of one per gate)
-	static void finish(cudaStream_t st) { if (isAsynchronous() && cuhe_hip_stream_sync(0, st) != 0) { printf("stream sync failed\n"); exit(2); } }
-	// job(i, stream) for i in [0, n), on the pool's threads (inline on the default stream when T = 1)
-	void run(int n, Job f) {
-		if (T <= 1) { for (int i = 0; i < n; ++i) f(i, (cudaStream_t)0); finish((cudaStream_t)0); return; }
-		{ std::lock_guard<std::mutex> lk(m); job = f; count = n; next = 0; running = T; ++gen; }
+	static void finish(cudaStream_t st, int dev = 0) { if (isAsynchronous() && cuhe_hip_stream_sync(dev, st) != 0) { printf("stream sync failed\n"); exit(2); } }
+	// job(i, stream, device) for i in [0, n), on the pool's threads (inline on the default streams when T = 1).
+	// onDevices = false: every item on device 0; true: items go to the device of the thread that picks them up
+	void run(int n, Job f, bool onDevices = false) {
+		if (T <= 1) {
+			for (int i = 0; i < n; ++i) f(i, (cudaStream_t)0, onDevices ? i % ndev : 0);
+			for (int d = 0; d < (onDevices ? ndev : 1); ++d) finish((cudaStream_t)0, d);
+			return;
+		}
+		{ std::lock_guard<std::mutex> lk(m); job = f; count = n; next = 0; running = T; spread = onDevices; ++gen; }
 		cvStart.notify_all();
 		std::unique_lock<std::mutex> lk(m);
 		cvDone.wait(lk, [&] { return running == 0; });
@@ -160,12 +172,12 @@ struct Evaluator {
 		}
 		++layer;
 	}
-	void addConstant(u64x rc) { pool.run(64, [&](int i, cudaStream_t st) { if ((rc >> (63 - i)) & 1) cNot(*state[i], *state[i], st); }); }
-	void addKey(std::vector<Ct> &k) { pool.run(64, [&](int i, cudaStream_t st) { cXor(*state[i], *state[i], *k[i], st); }); }
+	void addConstant(u64x rc) { pool.run(64, [&](int i, cudaStream_t st, int) { if ((rc >> (63 - i)) & 1) cNot(*state[i], *state[i], st); }); }
+	void addKey(std::vector<Ct> &k) { pool.run(64, [&](int i, cudaStream_t st, int) { cXor(*state[i], *state[i], *k[i], st); }); }
 	void mPrime() {
 		static const auto src = mPrimeSources();
 		std::vector<Ct> next(64);
-		pool.run(64, [&](int i, cudaStream_t st) {
+		pool.run(64, [&](int i, cudaStream_t st, int) {
 			next[i].reset(new CuCtxt);
 			copy(*next[i], *state[src[i][0]], st);
 			for (size_t k = 1; k < src[i].size(); ++k) cXor(*next[i], *next[i], *state[src[i][k]], st);
@@ -181,9 +193,16 @@ struct Evaluator {
 		state.swap(next);
 	}
 	void sboxLayer(const Anf &f) {
-		pool.run(16, [&](int i, cudaStream_t st) { sboxNibble(&state[4 * i], f, st); });
+		// the reference's distribution (Prince.cu:194-200): the 16 S-boxes of a layer go to the devices' threads; the state
+		// lives on device 0 between layers (the linear layers mix bits of different nibbles), so a nibble travels to the
+		// device of the thread that picked it and its four outputs travel back
+		pool.run(16, [&](int i, cudaStream_t st, int dev) {
+			for (int k = 0; k < 4; ++k) moveTo(*state[4 * i + k], dev, st);
+			sboxNibble(&state[4 * i], f, st);
+			for (int k = 0; k < 4; ++k) moveTo(*state[4 * i + k], 0, st);
+		}, true);
 		level += 2;
-		pool.run(64, [&](int i, cudaStream_t st) { modSwitchCt(*k1[i], st); modSwitchCt(*k1[i], st); });
+		pool.run(64, [&](int i, cudaStream_t st, int) { modSwitchCt(*k1[i], st); modSwitchCt(*k1[i], st); });
 	}
 	void encrypt(std::vector<Ct> &k0) {
 		int inv[16]; for (int i = 0; i < 16; ++i) inv[SBOX[i]] = i;
@@ -204,9 +223,9 @@ struct Evaluator {
 		}
 		addConstant(RC[11]); addKey(k1);
 		// k0' = (k0 >>> 1) ^ (k0 >> 63), brought down to the final level
-		pool.run(64, [&](int i, cudaStream_t st) { for (int l = 0; l < level; ++l) modSwitchCt(*k0[i], st); });
+		pool.run(64, [&](int i, cudaStream_t st, int) { for (int l = 0; l < level; ++l) modSwitchCt(*k0[i], st); });
 		std::vector<Ct> k0p(64);
-		pool.run(64, [&](int i, cudaStream_t st) { k0p[i].reset(new CuCtxt); copy(*k0p[i], *k0[(i + 63) % 64], st); });
+		pool.run(64, [&](int i, cudaStream_t st, int) { k0p[i].reset(new CuCtxt); copy(*k0p[i], *k0[(i + 63) % 64], st); });
 		cXor(*k0p[63], *k0p[63], *k0[0]);
 		Pool::finish((cudaStream_t)0);
 		addKey(k0p);
@@ -214,12 +233,16 @@ struct Evaluator {
 };
 
 int main(int argc, char **argv) {
-	bool checkRounds = true, async = false; int threads = 8;
+	bool checkRounds = true, async = false, virtualDevices = false; int threads = 8, devices = 1;
 	for (int i = 1; i < argc; ++i) {
 		if (std::string(argv[i]) == "--no-round-checks") checkRounds = false;
 		else if (std::string(argv[i]) == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (std::string(argv[i]) == "--async") async = true;
+		else if (std::string(argv[i]) == "--devices" && i + 1 < argc) devices = atoi(argv[++i]);
+		else if (std::string(argv[i]) == "--virtual") virtualDevices = true;      // logical devices on one physical GPU
 	}
+	if (devices < 1 || (threads > 1 && threads < devices)) { printf("need at least one host thread per device\n"); return 2; }
+	if (virtualDevices) cuhe_hip_set_virtual_devices(1);
 	// the cipher itself, against the test vectors of the PRINCE paper (plaintext, k0, k1, ciphertext)
 	const u64x F = ~0ULL;
 	const u64x tv[5][4] = {{0, 0, 0, 0x818665aa0d02dfdaULL}, {F, 0, 0, 0x604ae6ca03c20adaULL}, {0, F, 0, 0x9fb51935fc3df524ULL},
@@ -229,7 +252,7 @@ int main(int argc, char **argv) {
 
 	const u64x pt = 0, key0 = F, key1 = 0;                  // the reference's run (Prince.cu:69-74)
 	const auto t0 = clk::now();
-	multiGPUs(1);
+	multiGPUs(devices);
 	Dhs dhs;
 	dhs.setup(25, 2, 16, 25, 25, 21845);                    // Prince.cu:49
 	startAllocator();
@@ -237,7 +260,7 @@ int main(int argc, char **argv) {
 	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d   key generation %.2f s\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey,
 	       std::chrono::duration<double>(t1 - t0).count());
 
-	Pool pool(threads);
+	Pool pool(threads, devices);
 	Evaluator ev(dhs, checkRounds, pool);
 	plainPrince(pt, key0, key1, &ev.expect);
 	std::vector<Ct> k0(64);
@@ -261,7 +284,7 @@ int main(int argc, char **argv) {
 	if (!(constant && got == want && want == 0x9fb51935fc3df524ULL)) ++failures;
 	printf("circuit: %ld cAnd, %ld relin, %ld modSwitch, final level %d\n", numAnd.load(), numRelin.load(), numModSwitch.load(), ev.level);
 	if (numAnd != 1920 || numRelin != 1152 || ev.level != 24) { printf("unexpected operation counts\n"); ++failures; }
-	printf("Prince Encryption: %.3f s on 1 GPU with %d host thread(s), %s gates (round checks excluded)\n", encSeconds, threads, async ? "asynchronous" : "synchronous");
+	printf("Prince Encryption: %.3f s on %d %sdevice(s) with %d host thread(s), %s gates (round checks excluded)\n", encSeconds, devices, virtualDevices ? "virtual " : "", threads, async ? "asynchronous" : "synchronous");
 	stopAllocator();
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;

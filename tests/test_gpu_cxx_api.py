@@ -42,14 +42,17 @@ def test_dhs_scheme_flow(params):
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
 
 
-@pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"]],
-                         ids=["sync-8-threads", "async-4-threads", "async-1-thread"])
+@pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"],
+                                   ["--threads", "6", "--async", "--devices", "3", "--virtual"]],
+                         ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices"])
 def test_prince_known_answer(flags):
     """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
     reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
     (Prince.cu:108-145) must decrypt bit for bit; 1920 cAnd / 1152 relin / depth 24 as in the reference's circuit.
     Run with the reference's synchronous gate semantics on 8 host threads / streams, and with asynchronous gates
-    (setAsynchronous: stream-ordered buffers, one synchronisation per S-box) on 4 threads and on the default stream."""
+    (setAsynchronous: stream-ordered buffers, one synchronisation per S-box) on 4 threads and on the default stream;
+    and in the reference's multi-GPU arrangement (Prince.cu:194-200: the S-boxes of a layer spread over the devices'
+    threads, moveTo to and from the device that holds the state) on three virtual devices of the one GPU."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
