@@ -40,6 +40,15 @@ def test_modp_ops(gu):
     y = rng.integers(0, 1 << 64, n, dtype=np.uint64)
     edge = np.array([0, 1, O.P - 1, O.P, O.P + 1, (1 << 64) - 1, 0xFFFFFFFF, 1 << 32, (1 << 32) - 1], dtype=np.uint64)
     x[:81] = np.repeat(edge, 9); y[:81] = np.tile(edge, 9)
+    # borrow with the low word of the difference all ones (the fix-up's carry chain crosses the word boundary: the path a
+    # random pair takes with probability 2^-32), and the neighbours of it
+    for i in range(1024):
+        hi_a, hi_b = int(rng.integers(0, 0xFFFFFFFF)), int(rng.integers(0, 0xFFFFFFFF))
+        if hi_a > hi_b:
+            hi_a, hi_b = hi_b, hi_a
+        lo_a = int(rng.integers(0, 0xFFFFFFFF)); delta = (-1, 0, 1, 2)[i & 3]
+        x[100 + i] = (hi_a << 32) | lo_a
+        y[100 + i] = (hi_b << 32) | ((lo_a + 1 + delta) & 0xFFFFFFFF)
     dx, dy, dz = gu.to_dev(x), gu.to_dev(y), gu.empty_u64(n)
     xi = [int(v) for v in x[:4096]]; yi = [int(v) for v in y[:4096]]
     P = O.P
