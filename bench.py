@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL (already exported on the GPU boxes)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -42,7 +44,8 @@ def main():
     ap.add_argument("--pass2-form", type=int, default=-1, help="-1 library default, 0 = 64 values per thread, 1 = wave-split 16x4")
     ap.add_argument("--pass1-form", type=int, default=-1, help="-1 library default, 0 = 32 values per thread, 1 = wave-split")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
-    ap.add_argument("--relin-batch", type=int, default=8, help="ciphertexts per call of the batched multiply+relinearise leg")
+    ap.add_argument("--relin-batch", type=int, default=24, help="ciphertexts per call of the batched multiply+relinearise leg")
+    ap.add_argument("--relin-threads", type=int, default=4, help="host threads of the concurrent multiply+relinearise leg (4 ciphertexts per call each)")
     ap.add_argument("--mul-batch", type=int, default=16, help="operand pairs per call of the batched full-multiply leg")
     ap.add_argument("--no-mulrelin", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -401,7 +404,7 @@ def bench_mulrelin(lib, ck, torch, np, dev, args):
             ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), nab.data_ptr(), nbb.data_ptr(), 0, B, 0, None))
         torch.cuda.synchronize()
         assert torch.equal(out[:npn], cr) and torch.equal(out[(B - 1) * npn:], cr), "batched result differs from the single chain"
-        breps = max(3, 40 // B)
+        breps = max(6, 40 // B)
         t0 = time.perf_counter()
         for _ in range(breps):
             ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), nab.data_ptr(), nbb.data_ptr(), 0, B, 0, None))
@@ -409,15 +412,49 @@ def bench_mulrelin(lib, ck, torch, np, dev, args):
         bdt = (time.perf_counter() - t0) / breps / B
         batched = {"value": round(1.0 / bdt, 2), "unit": "mul+relin/s", "ms_per_ciphertext": round(bdt * 1e3, 4), "batch": B,
                    "key_bytes_per_ciphertext": key_bytes // 4,
-                   "note": "B independent chains per call; each key value read once per 4 ciphertexts"}
+                   "note": "B independent chains per call; each key value read once per 4 ciphertexts; groups of 4 on 3 streams of the calling thread"}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
+    # ---- the batched call from several host threads at once (own stream and own scratch each: the library is
+    # re-entrant): the HBM-bound inner product of one call overlaps the instruction-bound transforms of another
+    concurrent = None
+    try:
+        import threading
+        T, Bc, creps = args.relin_threads, 4, 10
+        bufs = []
+        for _ in range(T):
+            st = C.c_void_p(); ck(lib.cuhe_hip_stream_create(0, C.byref(st)))
+            bufs.append((st, na.repeat(Bc, 1).contiguous(), nb.repeat(Bc, 1).contiguous(),
+                         torch.empty((Bc * npn, q.crtLen), dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+
+        def work(t, n):
+            st, x, y, o = bufs[t]
+            for _ in range(n):
+                ck(lib.cuhe_hip_mul_relin_batch(o.data_ptr(), x.data_ptr(), y.data_ptr(), 0, Bc, 0, st))
+            ck(lib.cuhe_hip_stream_sync(0, st))
+        for t in range(T):
+            work(t, 1)
+        th = [threading.Thread(target=work, args=(t, creps)) for t in range(T)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        cdt = (time.perf_counter() - t0) / (T * Bc * creps)
+        assert all(torch.equal(bf[3][:npn], cr) and torch.equal(bf[3][(Bc - 1) * npn:], cr) for bf in bufs), "concurrent result differs from the single chain"
+        for bf in bufs:
+            ck(lib.cuhe_hip_stream_destroy(0, bf[0]))
+        concurrent = {"value": round(1.0 / cdt, 2), "unit": "mul+relin/s", "ms_per_ciphertext": round(cdt * 1e3, 4), "host_threads": T, "batch": Bc,
+                      "note": "T host threads, one stream each, batched calls of 4 ciphertexts"}
+    except Exception as ex:
+        concurrent = {"error": repr(ex)[:300]}
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s", "ms": round(dt * 1e3, 3),
             "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "numEvalKey": K, "nttLen": L},
             "algorithmic_bytes": key_bytes, "achieved_GBs": round(key_bytes / dt / 1e9, 1),
             "frac_hbm": round(key_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "key_upload_s": round(init_s, 2),
-            "batched": batched}
+            "batched": batched, "concurrent": concurrent}
 
 
 if __name__ == "__main__":

@@ -69,6 +69,8 @@ struct Workspace {
     u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows
     hipStream_t last = nullptr; bool used = false;
     hipEvent_t ev = nullptr;             // orders this thread's work when it moves to another stream
+    // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
+    hipStream_t lane_stream = nullptr; hipEvent_t ev_lane = nullptr, ev_in = nullptr;
 };
 struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0; };
 
@@ -130,23 +132,31 @@ int set_dev(int dev) {
 }
 
 // the calling thread's workspace on `dev`, ordered after whatever this thread last enqueued with it
+// A thread has kLanes workspaces per device: lane 0 is the one every entry point uses; lanes 1.. exist only while a
+// batched relinearisation spreads groups of ciphertexts over helper streams (tls_lane selects the lane for everything
+// the group's stages fetch through workspace_of_thread).
+constexpr int kLanes = 4;
+thread_local int tls_lane = 0;
+struct LaneReset { ~LaneReset() { tls_lane = 0; } };
 struct TlsSpaces {
     uint64_t gen = 0;
-    std::vector<Workspace *> per_dev;
+    std::vector<Workspace *> lanes[kLanes];
     ~TlsSpaces();                                 // a finished thread hands its workspaces to later threads
 };
 TlsSpaces::~TlsSpaces() {
     std::lock_guard<std::mutex> lk(G_.mu);
     if (gen != G_.generation) return;             // the library was shut down since: already freed
-    for (size_t d = 0; d < per_dev.size() && d < G_.dev.size(); ++d)
-        if (per_dev[d]) G_.dev[d].idle.push_back(per_dev[d]);
+    for (auto &per_dev : lanes)
+        for (size_t d = 0; d < per_dev.size() && d < G_.dev.size(); ++d)
+            if (per_dev[d]) G_.dev[d].idle.push_back(per_dev[d]);
 }
 thread_local TlsSpaces tls_spaces;
 int workspace_of_thread(int dev, Workspace **out) {
     TlsSpaces &T = tls_spaces;
-    if (T.gen != G_.generation) { T.per_dev.clear(); T.gen = G_.generation; }
-    if ((int)T.per_dev.size() <= dev) T.per_dev.resize(dev + 1, nullptr);
-    Workspace *w = T.per_dev[dev];
+    if (T.gen != G_.generation) { for (auto &v : T.lanes) v.clear(); T.gen = G_.generation; }
+    std::vector<Workspace *> &per_dev = T.lanes[tls_lane];
+    if ((int)per_dev.size() <= dev) per_dev.resize(dev + 1, nullptr);
+    Workspace *w = per_dev[dev];
     if (!w) {
         {
             std::lock_guard<std::mutex> lk(G_.mu);
@@ -162,7 +172,7 @@ int workspace_of_thread(int dev, Workspace **out) {
             std::lock_guard<std::mutex> lk(G_.mu);
             G_.dev[dev].spaces.push_back(w);
         }
-        T.per_dev[dev] = w;
+        per_dev[dev] = w;
     }
     *out = w;
     return CUHE_OK;
@@ -229,6 +239,9 @@ void free_workspace(Workspace *w) {
     void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw, w->mr_ntt, w->mr_crt};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
+    if (w->ev_lane) hipEventDestroy(w->ev_lane);
+    if (w->ev_in) hipEventDestroy(w->ev_in);
+    if (w->lane_stream) hipStreamDestroy(w->lane_stream);
     delete w;
 }
 
@@ -1246,7 +1259,7 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 // four ciphertexts.  The reference has no batched form: its circuits issue ciphertext operations one at a time.
 // core of the batched calls: a, b != null -> products of NTT-domain operands first (cAnd ; relin);
 // crt_in != null -> relinearisation of CRT-domain ciphertexts (CuCtxt::relin on a reduced ciphertext)
-static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b, const uint32_t *crt_in, int lvl, int batch, int dev, void *st_) {
+static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, const uint32_t *crt_in, int lvl, int batch, int dev, void *st_) {
     CHK(need_init(dev));
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
     const Params &q = G_.prm;
@@ -1335,6 +1348,60 @@ static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b,
     HIPCHK(hipGetLastError());
     // 5. n2c of the sums
     return reduce_rows(dst, Ws.bt_ntt);
+}
+
+// Groups of four ciphertexts (the unit that shares key fetches) go round-robin to `lanes` streams: the caller's and
+// helper streams of the calling thread, each with its own scratch.  The inner product of one group streams keys from
+// HBM while the transforms of another keep the vector units busy; the caller's stream waits for the helpers at the
+// end.  Short groups matter: with one long chunk per stream all streams run the same stage at the same time and nothing
+// overlaps.  Only where a group is substantial work (>= 1 GiB of keys per level, e.g. 64K-point rings with dozens of
+// primes): on small rings one launch sequence over the whole batch is faster (profiles/r01_experiments_log.txt).
+static int g_relin_lanes = 3;
+static bool g_relin_lanes_any_size = false;          // -n: n lanes whatever the ring size (tests)
+int cuhe_hip_set_relin_lanes(int n) {
+    const int m = n < 0 ? -n : n;
+    if (m < 1 || m > kLanes) return fail(CUHE_EINVAL, "lanes %d (1..%d)", n, kLanes);
+    g_relin_lanes = m; g_relin_lanes_any_size = n < 0;
+    return CUHE_OK;
+}
+static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b, const uint32_t *crt_in, int lvl, int batch, int dev, void *st_) {
+    constexpr int GB = 4;
+    const int groups = (batch + GB - 1) / GB, lanes = std::min(g_relin_lanes, groups);
+    const Params &q = G_.prm;
+    if (lanes <= 1 || !G_.inited || lvl < 0 || lvl >= q.depth ||
+        (!g_relin_lanes_any_size && (size_t)q.numEvalKeyAt(lvl) * q.numCrtPrimeAt(lvl) * q.nttLen * sizeof(u64) < ((size_t)1 << 30)))
+        return relin_batch_run(dst, a, b, crt_in, lvl, batch, dev, st_);
+    CHK(need_init(dev));
+    const size_t np = q.numCrtPrimeAt(lvl), L = q.nttLen, cl = q.crtLen;
+    hipStream_t st = S(st_);
+    Workspace *W0 = nullptr, *LW[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    CHK(workspace(dev, st, &W0));
+    if (!W0->ev_in) HIPCHK(hipEventCreateWithFlags(&W0->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(W0->ev_in, st));                         // whatever produced the operands on `st` is before this
+    LaneReset reset;
+    for (int g = 0; g < groups; ++g) {
+        const int lane = g % lanes, b0 = g * GB, nb = std::min(GB, batch - b0);
+        tls_lane = lane;
+        hipStream_t s = st;
+        if (lane) {
+            Workspace *w = nullptr;
+            CHK(workspace_of_thread(dev, &w));
+            if (!w->lane_stream) {
+                HIPCHK(hipStreamCreateWithFlags(&w->lane_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&w->ev_lane, hipEventDisableTiming));
+            }
+            if (!LW[lane]) { LW[lane] = w; HIPCHK(hipStreamWaitEvent(w->lane_stream, W0->ev_in, 0)); }
+            s = w->lane_stream;
+        }
+        CHK(relin_batch_run(dst + (size_t)b0 * np * cl, a ? a + (size_t)b0 * np * L : nullptr, b ? b + (size_t)b0 * np * L : nullptr,
+                            crt_in ? crt_in + (size_t)b0 * np * cl : nullptr, lvl, nb, dev, (void *)s));
+    }
+    tls_lane = 0;
+    for (int lane = 1; lane < kLanes; ++lane) if (LW[lane]) {
+        HIPCHK(hipEventRecord(LW[lane]->ev_lane, LW[lane]->lane_stream));
+        HIPCHK(hipStreamWaitEvent(st, LW[lane]->ev_lane, 0));
+    }
+    return CUHE_OK;
 }
 
 int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int batch, int dev, void *st) {

@@ -679,7 +679,11 @@ def test_mul_relin_batch_equals_single(gu, args):
         ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE200 + j)[0] for j in range(K)])
         ek = o.init_relin(ek_raw)
         g.init_relin(ek_raw)
-        for lvl, B in ((0, 1), (0, 3), (1, 6)):
+        # groups of four ciphertexts go round-robin to `lanes` streams of the calling thread (forced for these small rings
+        # by the negative count): 6 = two lanes, 13 = four groups on four lanes with a one-ciphertext tail, 9 = three
+        # groups on two lanes (a lane used twice)
+        for lvl, B, lanes in ((0, 1, -3), (0, 3, -3), (1, 6, -3), (1, 13, -4), (1, 9, -2)):
+            gu.ck(gu.lib.cuhe_hip_set_relin_lanes(lanes))
             npr = o.np_(lvl)
             a = [_rand_crt(o, npr, 3000 + 10 * lvl + i) for i in range(B)]
             b = [_rand_crt(o, npr, 4000 + 10 * lvl + i) for i in range(B)]
@@ -702,6 +706,8 @@ def test_mul_relin_batch_equals_single(gu, args):
             got2 = gu.host_u32(out).reshape(B, npr, q.crtLen)
             for i in range(B):
                 assert np.array_equal(got2[i], again[i]), ("relin_batch", lvl, B, i)
+        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(3))
+        assert gu.lib.cuhe_hip_set_relin_lanes(0) != 0 and gu.lib.cuhe_hip_set_relin_lanes(5) != 0 and gu.lib.cuhe_hip_set_relin_lanes(-5) != 0
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, 0, 0, None) != 0      # batch < 1
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 99, 1, 0, None) != 0     # bad level
     finally:

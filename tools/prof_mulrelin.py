@@ -5,6 +5,6 @@ import argparse
 import numpy as np, torch
 import bench
 from cuhe_amd import capi
-args = argparse.Namespace()
+args = argparse.Namespace(relin_batch=8, relin_threads=4)
 r = bench.bench_mulrelin(capi.lib, capi.check, torch, np, torch.device("cuda", 0), args)
 print(r)
