@@ -185,6 +185,7 @@ def main():
             got = dst[:4].cpu().numpy().view(np.uint64)
             for b in range(2):
                 assert np.array_equal(got[b], O.ntt_ext(xs[b], L)), "GPU NTT differs from the oracle"
+        if not args.no_cpu and world == 1:              # rank 0 at N = 1 only (torchrun pins OMP_NUM_THREADS=1 per rank)
             # ---- CPU baseline: the oracle's O(L log L) transform on the host cores, bounded sample
             cores = os.cpu_count() or 1
             sample = args.cpu_sample or max(cores * 24, 64)          # ~3 s wall on all host cores
