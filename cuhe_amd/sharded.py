@@ -31,6 +31,14 @@ def all_gather_rows(own_rows, num_primes, world, group=None):
     if world == 1:
         return own_rows
     width = own_rows.shape[1]
+    if num_primes % world == 0:
+        # equal shards: one flat collective straight into the result, no padding and no reassembly copies
+        out = torch.empty((num_primes, width), dtype=own_rows.dtype, device=own_rows.device)
+        try:
+            dist.all_gather_into_tensor(out, own_rows.contiguous(), group=group)
+            return out
+        except (RuntimeError, NotImplementedError, AttributeError):
+            pass                                    # backend without the flat form: the general path below
     maxc = (num_primes + world - 1) // world
     pad = torch.zeros((maxc, width), dtype=own_rows.dtype, device=own_rows.device)
     pad[: own_rows.shape[0]] = own_rows
