@@ -122,6 +122,23 @@ def main():
             sharded = {"error": repr(ex)[:300]}
         ck(lib.cuhe_hip_ntt_prepare(L, 0))
 
+    # ---- third figure at N > 1: every rank multiplies + relinearises its OWN ciphertexts (keys replicated, no exchange):
+    # the throughput form of multi-GPU use, next to the latency form above
+    replicated = None
+    if world > 1 and not args.no_mulrelin:
+        barrier()
+        mr, err = None, None
+        try:
+            mr = bench_mulrelin(lib, ck, torch, np, dev, args)
+            vals = [mr["value"], (mr["batched"] or {}).get("value", 0.0), (mr["concurrent"] or {}).get("value", 0.0), 1.0]
+        except Exception as ex:                      # every rank still joins the reduction below
+            err, vals = repr(ex)[:300], [0.0, 0.0, 0.0, 0.0]
+        v = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        replicated = {"unit": "mul+relin/s, all GPUs (independent ciphertexts per GPU, keys replicated)", "one_at_a_time": round(float(v[0]), 1),
+                      "batched": round(float(v[1]), 1), "concurrent": round(float(v[2]), 1), "ranks_reporting": int(v[3]), "rank0": mr if err is None else {"error": err}}
+        ck(lib.cuhe_hip_ntt_prepare(L, 0))
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel pair, timed live with hipEvents on the launch stream
@@ -217,7 +234,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
                                          "source": "doc/Perf_NTT.txt:14 (bundle 512)"},
-            "mul_relin": mulrelin, "mul_relin_sharded": sharded, "mul_full": mulfull,
+            "mul_relin": mulrelin, "mul_relin_sharded": sharded, "mul_relin_replicated": replicated, "mul_full": mulfull,
         }
     if world > 1:
         dist.barrier()
