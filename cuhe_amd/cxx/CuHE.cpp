@@ -80,10 +80,16 @@ void deviceFree(void *ptr) { CSC(cuhe_hip_free(tlsDevice, ptr)); }
 static bool asyncGates = false;
 void setAsynchronous(bool on) { asyncGates = on; }
 bool isAsynchronous() { return asyncGates; }
-#define GATE_SYNC(dev, st) do { if (!asyncGates) CSC(cuhe_hip_stream_sync(dev, st)); } while (0)
+// A public operation that is a CHAIN of steps on one stream (relin = x2r ; relinearization ; n2c, the x2* conversions,
+// modSwitch) synchronises once, at its end: inside a GateScope the steps only enqueue and release their buffers in stream
+// order, exactly like asynchronous gates; the operation as a whole keeps the reference's "returns synchronised" contract.
+static thread_local int gateDepth = 0;
+struct GateScope { GateScope() { ++gateDepth; } ~GateScope() { --gateDepth; } };
+static inline bool streamOrdered() { return asyncGates || gateDepth > 0; }
+#define GATE_SYNC(dev, st) do { if (!streamOrdered()) CSC(cuhe_hip_stream_sync(dev, st)); } while (0)
 
 static void *devAlloc(int dev, size_t bytes, cudaStream_t st = 0) {
-	void *p = asyncGates ? cuhe_hip_malloc_stream(dev, bytes, st) : cuhe_hip_malloc(dev, bytes);
+	void *p = streamOrdered() ? cuhe_hip_malloc_stream(dev, bytes, st) : cuhe_hip_malloc(dev, bytes);
 	if (!p) CSC(CUHE_EHIP);
 	return p;
 }
@@ -253,7 +259,7 @@ void CuPolynomial::cRepAlloc(cudaStream_t st) {
 void CuPolynomial::nRepAlloc(cudaStream_t st) {
 	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize(), stream_ = st);
 }
-static void devFree(int dev, void *p, cudaStream_t st) { CSC(asyncGates ? cuhe_hip_free_stream(dev, p, st) : cuhe_hip_free(dev, p)); }
+static void devFree(int dev, void *p, cudaStream_t st) { CSC(streamOrdered() ? cuhe_hip_free_stream(dev, p, st) : cuhe_hip_free(dev, p)); }
 void CuPolynomial::rRepFree() { devFree(device_, rRep_, stream_); rRep_ = NULL; }
 void CuPolynomial::cRepFree() { devFree(device_, cRep_, stream_); cRep_ = NULL; }
 void CuPolynomial::nRepFree() { devFree(device_, nRep_, stream_); nRep_ = NULL; }
@@ -358,23 +364,24 @@ void CuPolynomial::n2c(cudaStream_t st) {
 	domain_ = 2;
 }
 void CuPolynomial::x2z(cudaStream_t st) {
+	GateScope chain;                                           // r2z ends with the copy to the host and its own synchronise
 	if (domain_ == 3) n2c(st);
 	if (domain_ == 2) c2r(st);
 	if (domain_ == 1) r2z(st);
 }
 void CuPolynomial::x2r(cudaStream_t st) {
-	if (domain_ == 0) z2r(st);
-	else { if (domain_ == 3) n2c(st); if (domain_ == 2) c2r(st); }
+	if (domain_ == 0) { z2r(st); return; }
+	{ GateScope chain; if (domain_ == 3) n2c(st); if (domain_ == 2) c2r(st); }
+	GATE_SYNC(device_, st);
 }
 void CuPolynomial::x2c(cudaStream_t st) {
 	if (domain_ == 3) { n2c(st); return; }
-	if (domain_ == 0) z2r(st);
-	if (domain_ == 1) r2c(st);
+	{ GateScope chain; if (domain_ == 0) z2r(st); if (domain_ == 1) r2c(st); }
+	GATE_SYNC(device_, st);
 }
 void CuPolynomial::x2n(cudaStream_t st) {
-	if (domain_ == 0) z2r(st);
-	if (domain_ == 1) r2c(st);
-	if (domain_ == 2) c2n(st);
+	{ GateScope chain; if (domain_ == 0) z2r(st); if (domain_ == 1) r2c(st); if (domain_ == 2) c2n(st); }
+	GATE_SYNC(device_, st);
 }
 
 // ------------------------------------------------------------------ CuCtxt / CuPtxt
@@ -402,9 +409,7 @@ size_t CuCtxt::cRepSize() { return (size_t)param._numCrtPrime(level_) * param.cr
 size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * param.nttLen * sizeof(uint64); }
 void CuCtxt::modSwitch(cudaStream_t st) {
 	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
-	x2c(st);
-	stream_ = st;
-	crtModSwitch(cRep_, cRep_, logq_, device_, st);
+	{ GateScope chain; x2c(st); stream_ = st; crtModSwitch(cRep_, cRep_, logq_, device_, st); }
 	GATE_SYNC(device_, st);
 	logq_ -= param.logCoeffCut;
 	level_++;
@@ -414,14 +419,16 @@ void CuCtxt::modSwitch(int lvl, cudaStream_t st) {
 	while (level_ < lvl) modSwitch(st);       // (the reference's loop never advances level_: SURVEY A.7)
 }
 void CuCtxt::relin(cudaStream_t st) {
-	x2r(st);
-	nRepAlloc(st);
-	relinearization(nRep_, rRep_, level_, device_, st);
-	GATE_SYNC(device_, st);
-	rRepFree();
-	isProd_ = true;
-	domain_ = 3;
-	n2c(st);
+	{
+		GateScope chain;
+		x2r(st);
+		nRepAlloc(st);
+		relinearization(nRep_, rRep_, level_, device_, st);
+		rRepFree();
+		isProd_ = true;
+		domain_ = 3;
+		n2c(st);
+	}
 	GATE_SYNC(device_, st);
 }
 void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
