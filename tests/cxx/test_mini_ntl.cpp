@@ -62,7 +62,7 @@ int main() {
 		poly("zzxmod", a * b); poly("", m); std::cout << " ="; poly("", (a * b) % m); std::cout << '\n';
 	}
 	// ZZ_pE: inverse in Z_q[x]/(P) for a prime q and for a product of two primes (per-prime inverses + CRT lift)
-	for (const char *qs : {"1048573", "1099509530641"}) {            // a prime, and a product of three primes (1048573 * 17 * 61681)
+	for (const char *qs : {"1048573", "4397987791019", "1099509530641"}) {   // a prime; 2097143 * 2097133 (two CRT primes of the DHS example); 197 * 5581266653 (a factor above 2^32)
 		ZZ q = to_ZZ(0); for (const char *c = qs; *c; ++c) q = q * 10 + (*c - '0');
 		ZZ_p::init(q);
 		ZZX Pz; SetCoeff(Pz, 0, 1); SetCoeff(Pz, 1, 1); SetCoeff(Pz, 3, 1); SetCoeff(Pz, 4, 1); SetCoeff(Pz, 8, 1);      // x^8+x^4+x^3+x+1
