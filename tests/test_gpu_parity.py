@@ -613,6 +613,44 @@ def test_reentrant_host_threads(gu):
         for t in range(T):
             for r in range(REPS):
                 assert np.array_equal(gu.host_u32(bufs[t][r]["cr"]), want[t][r]), (t, r)
+
+        # second round: every thread issues ONE batched call over its REPS operands with the lanes forced on (groups of
+        # four ciphertexts on the thread's own stream and its helper streams), several times, all threads at once
+        B2 = 9
+        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(-3))
+        stacks = []
+        for t in range(T):
+            na = gu.empty_u64(B2 * npr, q.nttLen); nb = gu.empty_u64(B2 * npr, q.nttLen)
+            for i in range(B2):
+                d = bufs[t][i % REPS]
+                gu.ck(gu.lib.cuhe_hip_ntt(na[i * npr:].data_ptr(), d["ca"].data_ptr(), logq, 0, None))
+                gu.ck(gu.lib.cuhe_hip_ntt(nb[i * npr:].data_ptr(), d["cb"].data_ptr(), logq, 0, None))
+            stacks.append((na, nb, gu.empty_u32(B2 * npr, q.crtLen)))
+        torch.cuda.synchronize()
+        barrier2 = threading.Barrier(T)
+
+        def work2(t):
+            try:
+                st = ctypes.c_void_p()
+                gu.ck(gu.lib.cuhe_hip_stream_create(0, ctypes.byref(st)))
+                barrier2.wait()
+                na, nb, out = stacks[t]
+                for _ in range(3):
+                    gu.ck(gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, B2, 0, st))
+                gu.ck(gu.lib.cuhe_hip_stream_sync(0, st))
+                gu.ck(gu.lib.cuhe_hip_stream_destroy(0, st))
+            except Exception as e:
+                errors.append((t, repr(e)))
+
+        threads = [threading.Thread(target=work2, args=(t,)) for t in range(T)]
+        for th in threads: th.start()
+        for th in threads: th.join()
+        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(3))
+        assert not errors, errors
+        for t in range(T):
+            got = gu.host_u32(stacks[t][2]).reshape(B2, npr, q.crtLen)
+            for i in range(B2):
+                assert np.array_equal(got[i], want[t][i % REPS]), ("batched, lanes", t, i)
     finally:
         g.close(); o.close()
 
