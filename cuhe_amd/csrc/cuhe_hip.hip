@@ -345,17 +345,23 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, lon
     return CUHE_OK;
 }
 int g_pass2_form = 1;        // 0: 64 values per thread (ntt_pass2), 1: wave-split 16 x 4 (ntt_pass2w)
+// store epilogue of an inverse transform beyond "mod p": kind 1 = reversed quotient, 2 = final subtraction of the folded
+// reduction (aux = the product rows f, aux_stride their row length); see ntt_kernels.cuh
+struct Epilogue { int kind = 0; const u32 *aux = nullptr; long aux_stride = 0; FoldGeom fg{0, 0, 0, 0, 0}; };
 template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
-                 const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0) {
+                 const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0, const Epilogue *ep = nullptr) {
     constexpr int N1 = (1 << LG) / 64;
     if (np_mod > 0 && g_pass2_form != 1) return fail(CUHE_EINVAL, "batched ciphertext operations need the wave-split pass 2");
     if (g_pass2_form == 1) {
         const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
+        const Epilogue none;
+        const Epilogue &e = ep ? *ep : none;
         hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
-                           (OUT == kOutModP || OUT == kOutModPFoldXn1) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod);
-    } else if constexpr (OUT == kOutU64Mul) {
-        return fail(CUHE_EINVAL, "the fused table multiply exists in the wave-split pass 2 only");
+                           out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
+                           e.aux, e.aux_stride, e.fg);
+    } else if constexpr (OUT == kOutU64Mul || OUT == kOutModPRevQ || OUT == kOutFoldFinal) {
+        return fail(CUHE_EINVAL, "this fused store exists in the wave-split pass 2 only");
     } else {
         const int tiles = N1 / p2_threads<LG>();
         const int grid = ((nb + 7) / 8) * 8 * tiles;
@@ -376,7 +382,8 @@ struct EvTimer {                 // optional per-pass hipEvent timing (bench)
 // one batched transform, chunked so that the pass-1 -> pass-2 slab stays cache resident
 template <int LG>
 int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod) {
+               int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod,
+               const Epilogue *ep) {
     constexpr int L = 1 << LG;
     NttTab &tab = D.ntt[LG - 14];
     const int chunk = tab.chunk;
@@ -414,7 +421,12 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU64Neg) {
             u32 *d = (u32 *)dst + (long)b0 * dst_stride;
-            if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, np_mod)));
+            if (ep && ep->kind) {
+                Epilogue e = *ep;
+                if (e.aux) e.aux += (long)b0 * e.aux_stride;
+                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod, &e)));
+                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod, &e)));
+            } else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, np_mod)));
             else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
@@ -429,16 +441,17 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
 }
 
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr, int np_mod = 0) {
+            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr, int np_mod = 0,
+            const Epilogue *ep = nullptr) {
     if (batch <= 0) return CUHE_OK;
     CHK(ensure_ntt(dev, len, batch));
     DevCtx &D = G_.dev[dev];
     Workspace *W = nullptr;
     CHK(workspace(dev, st, &W));
     switch (len) {
-        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod);
-        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod);
-        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod);
+        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
+        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
+        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
     }
 }
 
@@ -512,18 +525,20 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
         // quotient q = floor(g / Phi) then has only Kq = D - n coefficients and comes from the top Kq coefficients of g
         // (reversed) times the inverse series of rev(Phi), a product that fits the HALF-length transform; and since
         // r = g - q Phi has degree < n <= Lh it can be formed modulo x^Lh - 1, i.e. with a half-length cyclic product.
-        // 4 half-length transforms + 3 elementwise kernels instead of 4 full-length transforms + 1.
+        // 4 half-length transforms + 1 elementwise kernel instead of 4 full-length transforms + 1: the quotient reversal
+        // and the final subtraction are done in the stores of the two inverse transforms (kOutModPRevQ, kOutFoldFinal).
         const FoldGeom &Gf = D.fold;
         const int Lh = Gf.Lh, hl = Lh / 2;
-        u32 *A = Ws.b_crt, *C = Ws.b_mq, *R2 = Ws.b_mq;
+        if (cl > Lh) return fail(CUHE_EINVAL, "folded reduction: crtLen %d > %d", cl, Lh);
+        u32 *A = Ws.b_crt, *Q = Ws.b_mq;
         const dim3 gh((hl + 255) / 256, np);
         hipLaunchKernelGGL(k_fold_top_rev, gh, dim3(256), 0, st, A, src, pt, Gf, L, np_mod);
         CHK(run_ntt(Lh, kSrcU32Ext, Ws.b_ntt, A, np, hl, Lh, Lh, 0, wa, dev, st, nullptr, D.uh_ntt + (size_t)prime0 * Lh, np_mod));
-        CHK(run_ntt(Lh, kSrcU64Neg, C, Ws.b_ntt, np, Lh, hl, hl, prime0, wa, dev, st, nullptr, nullptr, np_mod));        // A * U, first Lh/2 coefficients
-        hipLaunchKernelGGL(k_rev_quotient, gh, dim3(256), 0, st, A, C, Gf);                                            // A <- q
-        CHK(run_ntt(Lh, kSrcU32Ext, Ws.b_ntt, A, np, hl, Lh, Lh, 0, wa, dev, st, nullptr, D.mh_ntt + (size_t)prime0 * Lh, np_mod));
-        CHK(run_ntt(Lh, kSrcU64Neg, R2, Ws.b_ntt, np, Lh, Lh, n, prime0, wa, dev, st, nullptr, nullptr, np_mod));       // q * Phi mod (x^Lh - 1)
-        hipLaunchKernelGGL(k_fold_final, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, R2, pt, Gf, cl, L, np_mod);
+        Epilogue rev; rev.kind = 1; rev.fg = Gf;
+        CHK(run_ntt(Lh, kSrcU64Neg, Q, Ws.b_ntt, np, Lh, hl, hl, prime0, wa, dev, st, nullptr, nullptr, np_mod, &rev));   // q = rev(first Kq of A * U), zero padded
+        CHK(run_ntt(Lh, kSrcU32Ext, Ws.b_ntt, Q, np, hl, Lh, Lh, 0, wa, dev, st, nullptr, D.mh_ntt + (size_t)prime0 * Lh, np_mod));
+        Epilogue fin; fin.kind = 2; fin.aux = src; fin.aux_stride = L; fin.fg = Gf;
+        CHK(run_ntt(Lh, kSrcU64Neg, dst, Ws.b_ntt, np, Lh, cl, cl, prime0, wa, dev, st, nullptr, nullptr, np_mod, &fin)); // g - q * Phi mod (x^Lh - 1)
         HIPCHK(hipGetLastError());
         return CUHE_OK;
     }

@@ -162,7 +162,24 @@ void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
 
 // kOutU64Mul (wave-split pass 2 only): forward transform whose outputs are multiplied by a table row on the way out
 // (the pointwise product with a precomputed NTT-domain constant, fused: `pinv` carries the table, u64[prime][L])
-enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2, kOutU64Mul = 3 };
+// kOutModPRevQ / kOutFoldFinal (wave-split pass 2 only): the two inverse transforms of the folded generic reduction
+// (cuhe_hip.hip: barrett_impl) with the elementwise step that follows each of them done in the store:
+//   RevQ      : the first Kq coefficients come out REVERSED (q[t] = C[Kq-1-t]) and zero up to Lh/2 -- the quotient, ready
+//               as input of the next forward transform;
+//   FoldFinal : r[i] = (g mod (x^Lh - 1))[i] - (q Phi mod (x^Lh - 1))[i] for i < n, zero up to the row length, with g the
+//               fold of the product row f (`aux`) modulo x^m - 1.
+enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2, kOutU64Mul = 3, kOutModPRevQ = 4, kOutFoldFinal = 5 };
+__host__ __device__ constexpr bool out_is_inverse(int out) { return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPRevQ || out == kOutFoldFinal; }
+
+// ---- folded form of the generic reduction.  f = product of two reduced polynomials (degree <= 2n-2, row stride nlen,
+// residues < p).  g = f mod (x^m - 1) when m < 2n-1 (Phi_m divides x^m - 1), else g = f; D = length of g;
+// Kq = D - n = length of the quotient q = floor(g / Phi); Lh = length of the half-length transforms.
+struct FoldGeom { int n, m, D, Kq, Lh; };
+__device__ __forceinline__ u32 fold_g(const u32 *row, int i, const FoldGeom &G, u32 p) {      // g[i], i < D
+    u32 a = row[i];
+    if (G.D == G.m && i + G.m <= 2 * G.n - 2) { a += row[i + G.m]; if (a >= p) a -= p; }
+    return a;
+}
 
 template <int LG, int OUT>
 __global__ __launch_bounds__(p2_threads<LG>(), 2)
@@ -250,11 +267,12 @@ template <int LG, int OUT>
 __global__ __launch_bounds__(256, 4)
 void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
                 long dst_stride, int nbatch, int nstore,
-                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod) {
+                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
+                const u32 *__restrict__ aux, long aux_stride, FoldGeom fg) {
     // np_mod > 0: the rows are several ciphertexts' worth of the same np_mod primes (batched operations); row r of the
     // whole call belongs to prime r mod np_mod and prime0 carries the row offset of this launch
     constexpr int L = 1 << LG, N1 = L / 64;
-    constexpr bool INV = (OUT == kOutModP || OUT == kOutModPFoldXn1);
+    constexpr bool INV = out_is_inverse(OUT);
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     int batch, tile;
     xcd_map(N1 / kP2wCols, batch, tile);
@@ -310,6 +328,27 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
             for (int c = 0; c < 4; ++c) {
                 const int k2 = b + 16 * c;
                 if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[(long)k2 * N1] = mod_small(y[bitrev<4>(c)], p, m);
+            }
+        } else if constexpr (OUT == kOutModPRevQ) {
+            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int idx = (b + 16 * c) * N1 + k1;
+                if (idx < fg.Kq) dst[fg.Kq - 1 - idx] = mod_small(y[bitrev<4>(c)], p, m);
+                else if (idx < nstore) dst[idx] = 0u;
+            }
+        } else if constexpr (OUT == kOutFoldFinal) {
+            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride;
+            const u32 *frow = aux + (long)batch * aux_stride;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int idx = (b + 16 * c) * N1 + k1;
+                if (idx < fg.n) {
+                    u32 a = fold_g(frow, idx, fg, p);
+                    if (idx + fg.Lh < fg.D) { a += fold_g(frow, idx + fg.Lh, fg, p); if (a >= p) a -= p; }
+                    const u32 qphi = mod_small(y[bitrev<4>(c)], p, m);
+                    dst[idx] = a >= qphi ? a - qphi : a + p - qphi;
+                } else if (idx < nstore) dst[idx] = 0u;
             }
         } else {
             // fused reduction modulo x^(L/2)+1: pairs (k2, k2 + 32) = (c, c + 2), see ntt_pass2

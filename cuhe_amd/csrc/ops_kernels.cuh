@@ -179,15 +179,7 @@ void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32
     dst[(long)crt * clen + idx] = r;
 }
 
-// ---- folded form of the generic reduction (cuhe_hip.hip: barrett_impl).  f = product of two reduced polynomials
-// (degree <= 2n-2, row stride nlen, residues < p).  g = f mod (x^m - 1) when m < 2n-1 (Phi_m divides x^m - 1), else
-// g = f; D = length of g; Kq = D - n = length of the quotient q = floor(g / Phi).
-struct FoldGeom { int n, m, D, Kq, Lh; };
-__device__ __forceinline__ u32 fold_g(const u32 *row, int i, const FoldGeom &G, u32 p) {      // g[i], i < D
-    u32 a = row[i];
-    if (G.D == G.m && i + G.m <= 2 * G.n - 2) { a += row[i + G.m]; if (a >= p) a -= p; }
-    return a;
-}
+// ---- folded form of the generic reduction (cuhe_hip.hip: barrett_impl; FoldGeom and fold_g live in ntt_kernels.cuh)
 // A[j] = g[D-1-j] for j < Kq (the top of g, reversed), zero up to Lh/2: input of the half-length forward transform
 __global__ __launch_bounds__(256)
 void k_fold_top_rev(u32 *__restrict__ A, const u32 *__restrict__ f, PrimeTab pt, FoldGeom G, int nlen, int np_mod) {
@@ -196,30 +188,7 @@ void k_fold_top_rev(u32 *__restrict__ A, const u32 *__restrict__ f, PrimeTab pt,
     const u32 p = pt.p[np_mod > 0 ? crt % np_mod : crt];
     A[(long)crt * (G.Lh / 2) + j] = j < G.Kq ? fold_g(f + (long)crt * nlen, G.D - 1 - j, G, p) : 0u;
 }
-// q[t] = C[Kq-1-t] for t < Kq, zero up to Lh/2  (C = first Kq coefficients of A * U = the reversed quotient)
-__global__ __launch_bounds__(256)
-void k_rev_quotient(u32 *__restrict__ q, const u32 *__restrict__ C, FoldGeom G) {
-    const int crt = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= G.Lh / 2) return;
-    q[(long)crt * (G.Lh / 2) + t] = t < G.Kq ? C[(long)crt * (G.Lh / 2) + G.Kq - 1 - t] : 0u;
-}
-// r[i] = (g mod (x^Lh - 1))[i] - (q * Phi mod (x^Lh - 1))[i] for i < n (r = g - q Phi has degree < n <= Lh)
-__global__ __launch_bounds__(256)
-void k_fold_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32 *__restrict__ qphi, PrimeTab pt, FoldGeom G,
-                  int clen, int nlen, int np_mod) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= clen) return;
-    u32 r = 0;
-    if (idx < G.n) {
-        const u32 p = pt.p[np_mod > 0 ? crt % np_mod : crt];
-        const u32 *row = f + (long)crt * nlen;
-        u32 a = fold_g(row, idx, G, p);
-        if (idx + G.Lh < G.D) { a += fold_g(row, idx + G.Lh, G, p); if (a >= p) a -= p; }
-        const u32 b = qphi[(long)crt * G.Lh + idx];
-        r = a >= b ? a - b : a + p - b;
-    }
-    dst[(long)crt * clen + idx] = r;
-}
+// (the quotient reversal and the final subtraction are store epilogues of the inverse transforms: kOutModPRevQ, kOutFoldFinal)
 
 // fast exact reduction when the modulus is x^n + 1 (m = 2n a power of two):
 //   r[i] = f[i] - f[i+n]           (f has degree <= 2n-2)
