@@ -137,7 +137,9 @@ __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
 #if CUHE_MADEPS_VARIANT == 4
     // Only the multiply-add is asm: its carry-out lands in an SGPR pair (a lane mask), which inverse_ballot hands back
     // to the compiler as a per-lane boolean.  The OR with the >= P compare, the select and the final add are then
-    // ordinary code the compiler schedules itself (no SCC / VCC clobbers around a block of instructions).
+    // ordinary code the compiler schedules itself (no SCC / VCC clobbers around a block of instructions).  The mask is
+    // consumed by the s_or_b64 of that OR (an SALU read, interlocked), never directly by a VALU instruction, so the
+    // "VALU writes an SGPR pair -> VALU reads it" wait states that nothing would insert after an asm statement do not arise.
     u64 r, carry;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(m), "v"(0xffffffffu), "v"(lo));
     const bool f = __builtin_amdgcn_inverse_ballot_w64(carry) | (r >= kP);
