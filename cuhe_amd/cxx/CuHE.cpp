@@ -590,3 +590,124 @@ void mulZZXBatch(ZZX *x, const ZZX *a, const ZZX *b, int count, int lvl, int dev
 }
 
 } // namespace cuHE
+
+// ------------------------------------------------------------------ gates on arrays of ciphertexts (CuHEArray.h)
+#include "CuHEArray.h"
+namespace cuHE {
+
+CuIndexTable::~CuIndexTable() { if (data_) cuhe_hip_free(device_, data_); }
+void CuIndexTable::set(const std::vector<int> &values, int device) {
+	if (data_) { CSC(cuhe_hip_free(device_, data_)); data_ = NULL; }
+	device_ = device; size_ = values.size();
+	data_ = (int *)cuhe_hip_malloc(device_, (size_ ? size_ : 1) * sizeof(int));
+	if (!data_) CSC(CUHE_EHIP);
+	if (size_) CSC(cuhe_hip_memcpy_h2d(device_, data_, values.data(), size_ * sizeof(int), 0));
+	CSC(cuhe_hip_stream_sync(device_, 0));                     // `values` may go out of scope
+}
+
+static size_t arrayCtWords(int lvl) { return (size_t)param._numCrtPrime(lvl) * param.crtLen; }     // u32 per CRT ciphertext
+static size_t arrayCtElems(int lvl) { return (size_t)param._numCrtPrime(lvl) * param.nttLen; }     // u64 per NTT ciphertext
+static void arrayMisuse(const char *msg) { printf("Error: %s\n", msg); terminate(); }
+
+void CuCtxtArray::release() {
+	if (cRep_) { devFree(device_, cRep_, 0); cRep_ = NULL; }
+	if (nRep_) { devFree(device_, nRep_, 0); nRep_ = NULL; }
+	count_ = 0; level_ = -1; domain_ = -1; isProd_ = false;
+}
+void CuCtxtArray::create(int count, int lvl, int domain, int device, cudaStream_t st) {
+	if (count < 1 || lvl < 0 || lvl >= param.depth || (domain != 2 && domain != 3)) arrayMisuse("CuCtxtArray::create: bad count, level or domain");
+	release();
+	count_ = count; level_ = lvl; domain_ = domain; device_ = device; isProd_ = false;
+	if (domain == 2) cRep_ = (uint32 *)devAlloc(device, count * arrayCtWords(lvl) * sizeof(uint32), st);
+	else nRep_ = (uint64 *)devAlloc(device, count * arrayCtElems(lvl) * sizeof(uint64), st);
+}
+uint32 *CuCtxtArray::cRep(int i) { return cRep_ ? cRep_ + (size_t)i * arrayCtWords(level_) : NULL; }
+uint64 *CuCtxtArray::nRep(int i) { return nRep_ ? nRep_ + (size_t)i * arrayCtElems(level_) : NULL; }
+
+void CuCtxtArray::put(int i, CuCtxt &src, cudaStream_t st) {
+	if (i < 0 || i >= count_ || src.level() != level_ || src.domain() != domain_ || src.device() != device_)
+		arrayMisuse("CuCtxtArray::put: index, level, domain or device mismatch");
+	if (domain_ == 2) CSC(cuhe_hip_memcpy_d2d(device_, cRep(i), src.cRep(), src.cRepSize(), st));
+	else { CSC(cuhe_hip_memcpy_d2d(device_, nRep(i), src.nRep(), src.nRepSize(), st)); isProd_ = isProd_ || src.isProd(); }
+	GATE_SYNC(device_, st);
+}
+void CuCtxtArray::get(CuCtxt &dst, int i, cudaStream_t st) {
+	if (i < 0 || i >= count_) arrayMisuse("CuCtxtArray::get: index out of range");
+	dst.reset();
+	dst.setLevelForOutput(level_, domain_, device_, st);
+	if (domain_ == 2) CSC(cuhe_hip_memcpy_d2d(device_, dst.cRep(), cRep(i), dst.cRepSize(), st));
+	else { CSC(cuhe_hip_memcpy_d2d(device_, dst.nRep(), nRep(i), dst.nRepSize(), st)); dst.isProd(isProd_); }
+	GATE_SYNC(device_, st);
+}
+void CuCtxtArray::x2n(cudaStream_t st) {
+	if (domain_ == 3) return;
+	if (domain_ != 2) arrayMisuse("CuCtxtArray::x2n: empty array");
+	{
+		GateScope chain;
+		nRep_ = (uint64 *)devAlloc(device_, count_ * arrayCtElems(level_) * sizeof(uint64), st);
+		CSC(cuhe_hip_ntt_rows(U64P(nRep_), cRep_, count_ * param._numCrtPrime(level_), device_, st));
+		devFree(device_, cRep_, st); cRep_ = NULL;
+	}
+	domain_ = 3; isProd_ = false;
+	GATE_SYNC(device_, st);
+}
+void CuCtxtArray::x2c(cudaStream_t st) {
+	if (domain_ == 2) return;
+	if (domain_ != 3) arrayMisuse("CuCtxtArray::x2c: empty array");
+	{
+		GateScope chain;
+		cRep_ = (uint32 *)devAlloc(device_, count_ * arrayCtWords(level_) * sizeof(uint32), st);
+		if (isProd_) CSC(cuhe_hip_intt_mod_batch(cRep_, U64P(nRep_), level_, count_, device_, st));
+		else for (int i = 0; i < count_; ++i) CSC(cuhe_hip_intt(cRep(i), U64P(nRep(i)), param._logCoeff(level_), device_, st));
+		devFree(device_, nRep_, st); nRep_ = NULL;
+	}
+	domain_ = 2; isProd_ = false;
+	GATE_SYNC(device_, st);
+}
+void CuCtxtArray::relin(cudaStream_t st) {
+	{
+		GateScope chain;
+		x2c(st);
+		CSC(cuhe_hip_relin_batch(cRep_, cRep_, level_, count_, device_, st));
+	}
+	GATE_SYNC(device_, st);
+}
+void CuCtxtArray::modSwitch(cudaStream_t st) {
+	if (level_ + 1 >= param.depth) arrayMisuse("Cannot do modSwitch on last level!");
+	{
+		GateScope chain;
+		x2c(st);
+		uint32 *next = (uint32 *)devAlloc(device_, count_ * arrayCtWords(level_ + 1) * sizeof(uint32), st);
+		CSC(cuhe_hip_crt_mod_switch_batch(next, cRep_, level_, count_, device_, st));
+		devFree(device_, cRep_, st);
+		cRep_ = next;
+	}
+	level_++;
+	GATE_SYNC(device_, st);
+}
+void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuIndexTable &b, cudaStream_t st) {
+	if (in.domain() != 3 || a.size() != b.size() || a.size() == 0 || &out == &in) arrayMisuse("cAnd on arrays: operands must be in the NTT domain, index tables of equal length");
+	{
+		GateScope chain;
+		out.create((int)a.size(), in.level(), 3, in.device(), st);
+		CSC(cuhe_hip_ntt_mul_pairs(U64P(out.nRep_), U64P(in.nRep_), a.data(), b.data(), (int)a.size(), param._numCrtPrime(in.level()), in.device(), st));
+		out.isProd_ = true;
+	}
+	GATE_SYNC(in.device(), st);
+}
+void cXor(CuCtxtArray &out, CuCtxtArray &in0, CuCtxtArray *in1, const CuIndexTable &offsets, const CuIndexTable &list,
+          const CuIndexTable &addOne, cudaStream_t st) {
+	if (in0.domain() != 2 || (in1 && (in1->domain() != 2 || in1->level() != in0.level())) || offsets.size() < 2 || addOne.size() + 1 != offsets.size()
+	    || &out == &in0 || &out == in1)
+		arrayMisuse("cXor on arrays: operands must be in the CRT domain at one level, offsets = outputs + 1 entries");
+	const int nout = (int)offsets.size() - 1;
+	{
+		GateScope chain;
+		out.create(nout, in0.level(), 2, in0.device(), st);
+		CSC(cuhe_hip_crt_combine(out.cRep_, in0.cRep_, in0.count(), in1 ? in1->cRep_ : NULL, offsets.data(), list.data(), addOne.data(), nout,
+		                         in0.level(), in0.device(), st));
+	}
+	GATE_SYNC(in0.device(), st);
+}
+
+} // namespace cuHE

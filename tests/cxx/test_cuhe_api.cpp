@@ -4,6 +4,7 @@
 // Runs on a GPU box; exit code 0 = all checks passed.
 #include "CuHE.h"
 #include "Relinearization.h"
+#include "CuHEArray.h"
 #include "cuhe_hip.h"
 #include "Debug.h"
 #include "DeviceManager.h"
@@ -143,6 +144,47 @@ int main() {
 			SetCoeff(ms, i, ((v - dl) / pt) % q[1]);
 		}
 		CHECK(keep.zRep() == ms, "modSwitch = (c - delta)/p_t with delta = c mod p_t made even");
+	}
+	// ---- gates on arrays of ciphertexts (CuHEArray.h, addition) against the single-ciphertext gates
+	{
+		const int C = 5;
+		std::vector<ZZX> z(C), w(C);
+		CuCtxtArray arr, other;
+		arr.create(C, 0, 2); other.create(C, 0, 2);
+		for (int i = 0; i < C; ++i) {
+			z[i] = randomPoly(n, q[0]); w[i] = randomPoly(n, q[0]);
+			CuCtxt c; c.setLevel(0, 0, z[i]); c.x2c(); arr.put(i, c);
+			CuCtxt d; d.setLevel(0, 0, w[i]); d.x2c(); other.put(i, d);
+		}
+		// cXor / cNot over index lists: out[0] = z0 + z2 + w1 + 1, out[1] = z1 + z4
+		CuIndexTable off, list, one;
+		off.set({0, 3, 5}); list.set({0, 2, C + 1, 1, 4}); one.set({1, 0});
+		CuCtxtArray sums;
+		cXor(sums, arr, &other, off, list, one);
+		CuCtxt s0, s1; sums.get(s0, 0); sums.get(s1, 1); s0.x2z(); s1.x2z();
+		ZZX want0 = z[0] + z[2] + w[1]; SetCoeff(want0, 0, coeff(want0, 0) + 1);
+		CHECK(s0.zRep() == reduceCoeffs(want0, q[0], n) && s1.zRep() == reduceCoeffs(z[1] + z[4], q[0], n), "arrays: cXor / cNot over index lists");
+		// cAnd over index pairs, relin, modSwitch: four chains in three calls
+		arr.x2n();
+		CuIndexTable ia, ib; ia.set({0, 1, 2, 3}); ib.set({1, 2, 3, 4});
+		CuCtxtArray prod;
+		cAnd(prod, arr, ia, ib);
+		prod.relin();
+		prod.modSwitch();
+		bool same = prod.level() == 1 && prod.domain() == 2 && prod.count() == 4;
+		for (int t = 0; t < 4 && same; ++t) {
+			CuCtxt a, b, p;
+			a.setLevel(0, 0, z[t]); b.setLevel(0, 0, z[t + 1]);
+			a.x2n(); b.x2n();
+			cAnd(p, a, b); p.relin(); p.modSwitch(); p.x2z();
+			CuCtxt g; prod.get(g, t); g.x2z();
+			same = same && g.level() == 1 && g.zRep() == p.zRep();
+		}
+		CHECK(same, "arrays: cAnd over index pairs + relin + modSwitch = four single-ciphertext chains");
+		// plain conversion round trip of the whole array
+		arr.x2c();
+		CuCtxt back; arr.get(back, 3); back.x2z();
+		CHECK(back.zRep() == z[3], "arrays: CRT -> NTT -> CRT round trip");
 	}
 	// ---- the second tier, cuhe/Operations.h:42-108: raw-pointer drivers called directly, the way cuhe/CuHE.cu strings
 	//      them together (crt / ntt / nttMul / inttMod / icrt = the body of mulZZX, CuHE.cu:259-268 + :350-408), and the
