@@ -618,8 +618,10 @@ void CuCtxtArray::create(int count, int lvl, int domain, int device, cudaStream_
 	if (count < 1 || lvl < 0 || lvl >= param.depth || (domain != 2 && domain != 3)) arrayMisuse("CuCtxtArray::create: bad count, level or domain");
 	release();
 	count_ = count; level_ = lvl; domain_ = domain; device_ = device; isProd_ = false;
-	if (domain == 2) cRep_ = (uint32 *)devAlloc(device, count * arrayCtWords(lvl) * sizeof(uint32), st);
-	else nRep_ = (uint64 *)devAlloc(device, count * arrayCtElems(lvl) * sizeof(uint64), st);
+	// storage is sized for level 0 whatever the level: a circuit walks down the levels with arrays of the same few
+	// counts, and blocks of the same size come back from the library's block cache instead of hipMalloc / hipFree
+	if (domain == 2) cRep_ = (uint32 *)devAlloc(device, count * arrayCtWords(0) * sizeof(uint32), st);
+	else nRep_ = (uint64 *)devAlloc(device, count * arrayCtElems(0) * sizeof(uint64), st);
 }
 uint32 *CuCtxtArray::cRep(int i) { return cRep_ ? cRep_ + (size_t)i * arrayCtWords(level_) : NULL; }
 uint64 *CuCtxtArray::nRep(int i) { return nRep_ ? nRep_ + (size_t)i * arrayCtElems(level_) : NULL; }
@@ -644,7 +646,7 @@ void CuCtxtArray::x2n(cudaStream_t st) {
 	if (domain_ != 2) arrayMisuse("CuCtxtArray::x2n: empty array");
 	{
 		GateScope chain;
-		nRep_ = (uint64 *)devAlloc(device_, count_ * arrayCtElems(level_) * sizeof(uint64), st);
+		nRep_ = (uint64 *)devAlloc(device_, count_ * arrayCtElems(0) * sizeof(uint64), st);
 		CSC(cuhe_hip_ntt_rows(U64P(nRep_), cRep_, count_ * param._numCrtPrime(level_), device_, st));
 		devFree(device_, cRep_, st); cRep_ = NULL;
 	}
@@ -656,7 +658,7 @@ void CuCtxtArray::x2c(cudaStream_t st) {
 	if (domain_ != 3) arrayMisuse("CuCtxtArray::x2c: empty array");
 	{
 		GateScope chain;
-		cRep_ = (uint32 *)devAlloc(device_, count_ * arrayCtWords(level_) * sizeof(uint32), st);
+		cRep_ = (uint32 *)devAlloc(device_, count_ * arrayCtWords(0) * sizeof(uint32), st);
 		if (isProd_) CSC(cuhe_hip_intt_mod_batch(cRep_, U64P(nRep_), level_, count_, device_, st));
 		else for (int i = 0; i < count_; ++i) CSC(cuhe_hip_intt(cRep(i), U64P(nRep(i)), param._logCoeff(level_), device_, st));
 		devFree(device_, nRep_, st); nRep_ = NULL;
@@ -677,7 +679,7 @@ void CuCtxtArray::modSwitch(cudaStream_t st) {
 	{
 		GateScope chain;
 		x2c(st);
-		uint32 *next = (uint32 *)devAlloc(device_, count_ * arrayCtWords(level_ + 1) * sizeof(uint32), st);
+		uint32 *next = (uint32 *)devAlloc(device_, count_ * arrayCtWords(0) * sizeof(uint32), st);
 		CSC(cuhe_hip_crt_mod_switch_batch(next, cRep_, level_, count_, device_, st));
 		devFree(device_, cRep_, st);
 		cRep_ = next;
@@ -685,6 +687,28 @@ void CuCtxtArray::modSwitch(cudaStream_t st) {
 	level_++;
 	GATE_SYNC(device_, st);
 }
+void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStream_t st) {
+	if (parts.empty() || !parts[0]) arrayMisuse("concat: no parts");
+	const int lvl = parts[0]->level(), dom = parts[0]->domain(), dev = parts[0]->device();
+	int total = 0; bool prod = false;
+	for (CuCtxtArray *p : parts) {
+		if (!p || p == &dst || p->level() != lvl || p->domain() != dom || p->device() != dev) arrayMisuse("concat: parts must share level, domain and device");
+		total += p->count(); prod = prod || p->isProd();
+	}
+	{
+		GateScope chain;
+		dst.create(total, lvl, dom, dev, st);
+		int at = 0;
+		for (CuCtxtArray *p : parts) {
+			if (dom == 2) CSC(cuhe_hip_memcpy_d2d(dev, dst.cRep(at), p->cRep_, p->count() * arrayCtWords(lvl) * sizeof(uint32), st));
+			else CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(at), p->nRep_, p->count() * arrayCtElems(lvl) * sizeof(uint64), st));
+			at += p->count();
+		}
+		dst.isProd_ = prod;
+	}
+	GATE_SYNC(dev, st);
+}
+void copy(CuCtxtArray &dst, CuCtxtArray &src, cudaStream_t st) { concat(dst, std::vector<CuCtxtArray *>(1, &src), st); }
 void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuIndexTable &b, cudaStream_t st) {
 	if (in.domain() != 3 || a.size() != b.size() || a.size() == 0 || &out == &in) arrayMisuse("cAnd on arrays: operands must be in the NTT domain, index tables of equal length");
 	{

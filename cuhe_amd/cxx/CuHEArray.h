@@ -49,6 +49,8 @@ public:
 private:
 	CuCtxtArray(const CuCtxtArray &);
 	CuCtxtArray &operator=(const CuCtxtArray &);
+	friend void copy(CuCtxtArray &, CuCtxtArray &, cudaStream_t);
+	friend void concat(CuCtxtArray &, const std::vector<CuCtxtArray *> &, cudaStream_t);
 	friend void cAnd(CuCtxtArray &, CuCtxtArray &, const CuIndexTable &, const CuIndexTable &, cudaStream_t);
 	friend void cXor(CuCtxtArray &, CuCtxtArray &, CuCtxtArray *, const CuIndexTable &, const CuIndexTable &, const CuIndexTable &, cudaStream_t);
 	int count_, level_, domain_, device_;
@@ -57,6 +59,9 @@ private:
 	uint64 *nRep_;
 };
 
+// dst = a copy of src; dst = the ciphertexts of all parts in order (parts of one level, domain and device)
+void copy(CuCtxtArray &dst, CuCtxtArray &src, cudaStream_t st = 0);
+void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStream_t st = 0);
 // out[t] = in[a[t]] * in[b[t]]  (NTT domain; `out` is created with a.size() ciphertexts; relin / x2c follow as for cAnd)
 void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuIndexTable &b, cudaStream_t st = 0);
 // out[o] = sum of the ciphertexts listed in list[offsets[o] .. offsets[o+1]) (+ 1 on the constant coefficient where

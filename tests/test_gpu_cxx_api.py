@@ -105,3 +105,24 @@ def test_in_process_multi_device_on_virtual_devices():
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout
+
+
+@pytest.mark.parametrize("flags", [[], ["--async"]], ids=["sync", "async"])
+def test_prince_known_answer_on_cxx_array_classes(flags):
+    """The same circuit through the C++ array classes of cuhe_amd/cxx/CuHEArray.h (CuCtxtArray / CuIndexTable: cAnd over
+    index pairs, cXor over index lists, relin / modSwitch / x2n / x2c on whole arrays, copy / concat): known answer and
+    the 12 round states, with the reference's synchronise-per-operation semantics and with asynchronous gates."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    import __graft_entry__ as ge
+    ge.build()
+    cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
+    subprocess.check_call(["make", "-C", cxx, "-s", "test"])
+    exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_arrays_cxx")
+    r = subprocess.run([exe] + flags, capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
+    assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
+    assert r.stdout.count("right") == 13
