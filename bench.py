@@ -41,8 +41,6 @@ def main():
     ap.add_argument("--len", type=int, default=65536, dest="length")
     ap.add_argument("--chunk", type=int, default=0, help="transforms per launch pair (0 = library default)")
     ap.add_argument("--overlap", type=int, default=0, help="1: pass-1/pass-2 two-stream pipeline, 0: serial launches (default)")
-    ap.add_argument("--pass2-form", type=int, default=-1, help="-1 library default, 0 = 64 values per thread, 1 = wave-split 16x4")
-    ap.add_argument("--pass1-form", type=int, default=-1, help="-1 library default, 0 = 32 values per thread, 1 = wave-split")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
     ap.add_argument("--relin-batch", type=int, default=24, help="ciphertexts per call of the batched multiply+relinearise leg")
     ap.add_argument("--relin-threads", type=int, default=4, help="host threads of the concurrent multiply+relinearise leg (4 ciphertexts per call each)")
@@ -78,10 +76,6 @@ def main():
     if args.chunk:
         ck(lib.cuhe_hip_set_ntt_chunk(args.chunk))
     ck(lib.cuhe_hip_set_ntt_overlap(args.overlap))
-    if args.pass1_form >= 0:
-        ck(lib.cuhe_hip_set_pass1_form(args.pass1_form))
-    if args.pass2_form >= 0:
-        ck(lib.cuhe_hip_set_pass2_form(args.pass2_form))
 
     L, B = args.length, args.batch
     # synthetic input: uniform 32-bit words, generated on the device

@@ -61,6 +61,7 @@ SIGNATURES = {
     "cuhe_hip_memcpy_peer": (i32, [vp, i32, vp, i32, sz, vp]),
     "cuhe_hip_stream_create": (i32, [i32, vp]),
     "cuhe_hip_stream_destroy": (i32, [i32, vp]),
+    "cuhe_hip_device_sync": (i32, [i32]),
     "cuhe_hip_stream_sync": (i32, [i32, vp]),
     "cuhe_hip_crt": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_icrt": (i32, [vp, vp, i32, i32, vp]),
@@ -108,8 +109,6 @@ SIGNATURES = {
     "cuhe_hip_ntt_prepare": (i32, [i32, i32]),
     "cuhe_hip_set_ntt_chunk": (i32, [i32]),
     "cuhe_hip_set_ntt_overlap": (i32, [i32]),
-    "cuhe_hip_set_pass2_form": (i32, [i32]),
-    "cuhe_hip_set_pass1_form": (i32, [i32]),
     "cuhe_hip_time_ntt_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp] + [C.POINTER(C.c_float)] * 3),
     "cuhe_hip_modp_add": (i32, [vp, vp, vp, sz, i32, vp]),
     "cuhe_hip_modp_sub": (i32, [vp, vp, vp, sz, i32, vp]),

@@ -47,7 +47,7 @@ int fail(int code, const char *fmt, ...) {
 
 // ------------------------------------------------------------------ state
 struct NttTab {
-    u64 *T1 = nullptr, *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of the wave-split pass 1
+    u64 *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of pass 1; T2 / T2inv: outer twiddles (x L^-1)
     int chunk = 0;                             // transforms per launch pair (slab size / transform size)
 };
 // Mutable scratch of ONE host thread on one device.  The reference keeps a single set per device and is therefore
@@ -124,10 +124,14 @@ struct Global {
 inline int lg_index(int len) { return len == 16384 ? 0 : len == 32768 ? 1 : len == 65536 ? 2 : -1; }
 inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
+inline int phys_dev(int dev) { return G_.virtual_devices ? G_.dev_base : G_.dev_base + dev; }
 int set_dev(int dev) {
     if (dev < 0 || dev >= G_.ndev) return fail(CUHE_EINVAL, "device %d out of range (numGPUs=%d)", dev, G_.ndev);
-    HIPCHK(hipSetDevice(G_.virtual_devices ? G_.dev_base : G_.dev_base + dev));
-    if ((int)G_.dev.size() < G_.ndev) G_.dev.resize(G_.ndev);
+    HIPCHK(hipSetDevice(phys_dev(dev)));
+    if ((int)G_.dev.size() < G_.ndev) {            // (multi_gpus / init size it already; kept for callers that skip them)
+        std::lock_guard<std::mutex> lk(G_.mu);
+        if ((int)G_.dev.size() < G_.ndev) G_.dev.resize(G_.ndev);
+    }
     return CUHE_OK;
 }
 
@@ -255,15 +259,12 @@ int upload(T **dptr, const std::vector<T> &h) {
 // ------------------------------------------------------------------ NTT tables + launch
 template <int LG>
 int make_ntt_tables(NttTab &tab) {
-    using Gm = NttGeom<LG>;
-    constexpr int L = 1 << LG, N1 = L / 64, R1 = Gm::R1, R2 = Gm::R2;
+    constexpr int L = 1 << LG, N1 = L / 64, RA = N1 / 64;
     std::vector<u64> r(L);
     const u64 w = host::powP(host::G, 65536 / L);                 // cuhe/Base.cu:63-70
     r[0] = 1;
     for (int i = 1; i < L; ++i) r[i] = host::mulP(r[i - 1], w);
-    std::vector<u64> t1((size_t)R1 * R2), t2(L), t2i(L);
-    for (int c = 0; c < R1; ++c)
-        for (int b = 0; b < R2; ++b) t1[(size_t)c * R2 + b] = r[(64L * b * c) % L];
+    std::vector<u64> t2(L), t2i(L);
     const u64 linv = host::powP((u64)L, host::P - 2);             // cuhe/Base.cu:489,656,841
     for (int j2 = 0; j2 < 64; ++j2)
         for (int k1 = 0; k1 < N1; ++k1) {
@@ -271,13 +272,11 @@ int make_ntt_tables(NttTab &tab) {
             t2[(size_t)j2 * N1 + k1] = v;
             t2i[(size_t)j2 * N1 + k1] = host::mulP(v, linv);
         }
-    // wave-split pass 1: N1 = RA x 64, t1w[c*64 + b] = w_N1^(b*c), b < 64, c < RA
-    constexpr int RA = N1 / 64;
+    // pass 1: N1 = RA x 64, t1w[c*64 + b] = w_N1^(b*c), b < 64, c < RA
     std::vector<u64> t1w((size_t)N1);
     for (int c = 0; c < RA; ++c)
         for (int b = 0; b < 64; ++b) t1w[(size_t)c * 64 + b] = r[(64L * b * c) % L];
     CHK(upload(&tab.T1w, t1w));
-    CHK(upload(&tab.T1, t1));
     CHK(upload(&tab.T2, t2));
     CHK(upload(&tab.T2inv, t2i));
     return CUHE_OK;
@@ -289,7 +288,7 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     if (li < 0) return fail(CUHE_EINVAL, "unsupported transform length %d (16384/32768/65536 only)", len);
     std::lock_guard<std::mutex> lk(G_.mu);
     NttTab &tab = G_.dev[dev].ntt[li];
-    if (!tab.T1) {
+    if (!tab.T1w) {
         if (li == 0) CHK(make_ntt_tables<14>(tab));
         else if (li == 1) CHK(make_ntt_tables<15>(tab));
         else CHK(make_ntt_tables<16>(tab));
@@ -311,40 +310,31 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     return CUHE_OK;
 }
 
-int g_pass1_form = 1;        // 0: 32 values per thread (ntt_pass1), 1: wave-split RA x 16 x 4 (ntt_pass1w)
-template <int LG, int MODE>
-int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, bool inv, long src_stride, int nb,
-                 WindowArgs wa, hipStream_t st) {
-    (void)inv;
-    int cur = 0;
-    HIPCHK(hipGetDevice(&cur));
-    if (g_pass1_form == 1) {
-        using Gw = P1wGeom<LG>;
-        static bool attr_done[64] = {false};
-        auto kern = ntt_pass1w<LG, MODE>;
-        if (!attr_done[cur & 63]) {
-            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gw::bytes));
-            attr_done[cur & 63] = true;
+// hipFuncSetAttribute once per (kernel instantiation, device); host threads may race to be first
+struct AttrOnce {
+    std::mutex mu; bool done[64] = {false};
+    template <typename K> int set(K kern, int bytes) {
+        int cur = 0;
+        HIPCHK(hipGetDevice(&cur));
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[cur & 63]) {
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            done[cur & 63] = true;
         }
-        const int grid = ((nb + 7) / 8) * 8 * (64 / Gw::NC);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa);
-    } else {
-        using Gm = NttGeom<LG>;
-        static bool attr_done[64] = {false};
-        auto kern = ntt_pass1<LG, MODE>;
-        if (!attr_done[cur & 63]) {
-            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)NttLds<LG>::bytes));
-            attr_done[cur & 63] = true;
-        }
-        const int tiles = 64 / Gm::NC;
-        const int grid = ((nb + 7) / 8) * 8 * tiles;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNttThreads), NttLds<LG>::bytes, st, src, scratch, tab.T1, src_stride, nb, wa);
+        return CUHE_OK;
     }
+};
+template <int LG, int MODE>
+int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st) {
+    using Gw = P1wGeom<LG>;
+    static AttrOnce once;
+    auto kern = ntt_pass1w<LG, MODE>;
+    CHK(once.set(kern, (int)Gw::bytes));
+    const int grid = ((nb + 7) / 8) * 8 * (64 / Gw::NC);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
-int g_pass2_form = 1;        // 0: 64 values per thread (ntt_pass2), 1: wave-split 16 x 4 (ntt_pass2w)
 // store epilogue of an inverse transform beyond "mod p": kind 1 = reversed quotient, 2 = final subtraction of the folded
 // reduction (aux = the product rows f, aux_stride their row length); see ntt_kernels.cuh
 struct Epilogue { int kind = 0; const u32 *aux = nullptr; long aux_stride = 0; FoldGeom fg{0, 0, 0, 0, 0}; };
@@ -352,24 +342,19 @@ template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
                  const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0, const Epilogue *ep = nullptr) {
     constexpr int N1 = (1 << LG) / 64;
-    if (np_mod > 0 && g_pass2_form != 1) return fail(CUHE_EINVAL, "batched ciphertext operations need the wave-split pass 2");
-    if (g_pass2_form == 1) {
-        const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
-        const Epilogue none;
-        const Epilogue &e = ep ? *ep : none;
-        hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
-                           out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
-                           e.aux, e.aux_stride, e.fg);
-    } else if constexpr (OUT == kOutU64Mul || OUT == kOutModPRevQ || OUT == kOutFoldFinal) {
-        return fail(CUHE_EINVAL, "this fused store exists in the wave-split pass 2 only");
-    } else {
-        const int tiles = N1 / p2_threads<LG>();
-        const int grid = ((nb + 7) / 8) * 8 * tiles;
-        hipLaunchKernelGGL((ntt_pass2<LG, OUT>), dim3(grid), dim3(p2_threads<LG>()), 0, st, dst, scratch,
-                           OUT != kOutU64 ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0);
-    }
+    const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
+    const Epilogue none;
+    const Epilogue &e = ep ? *ep : none;
+    hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
+                       out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
+                       e.aux, e.aux_stride, e.fg);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
+}
+
+int icrt_lds_attr(size_t lds) {                 // k_icrt needs the large-LDS attribute for many primes
+    static AttrOnce once;
+    return lds > 64 * 1024 ? once.set(k_icrt, 160 * 1024) : CUHE_OK;
 }
 
 constexpr int kFoldXn1 = -1;     // nstore sentinel: inverse transform fused with the reduction mod x^(L/2)+1
@@ -409,13 +394,13 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU32Ext) {
             const u32 *s = (const u32 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU32Ext>(s, slab, tab, false, src_stride, nb, wa, q1)));
+            CHK((launch_pass1<LG, kSrcU32Ext>(s, slab, tab, src_stride, nb, wa, q1)));
         } else if (mode == kSrcWindow) {
             WindowArgs w2 = wa; w2.wid0 += b0;
-            CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, false, 0, nb, w2, q1)));
+            CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, 0, nb, w2, q1)));
         } else {
             const u64 *s = (const u64 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU64Neg>(s, slab, tab, true, src_stride, nb, wa, q1)));
+            CHK((launch_pass1<LG, kSrcU64Neg>(s, slab, tab, src_stride, nb, wa, q1)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p1[sl], q1)); HIPCHK(hipStreamWaitEvent(q2, D.ev_p1[sl], 0)); }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
@@ -512,15 +497,14 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
     CHK(workspace(dev, st, &Wp));
     CHK(ws_barrett(*Wp, np));
     Workspace &Ws = *Wp;
-    const bool fuse_mul = g_pass2_form == 1;
-    if (np_mod > 0 && (!fuse_mul || prime0 != 0)) return fail(CUHE_EINVAL, "batched reduction needs the wave-split pass 2 and a whole level");
+    if (np_mod > 0 && prime0 != 0) return fail(CUHE_EINVAL, "batched reduction needs a whole level");
     const size_t rows = (size_t)np * L;
     if (dst < src + rows && src < dst + (size_t)np * cl) {      // result rows would overwrite input rows still to be read
         CHK(ws_grow(&Ws.b_alias, &Ws.n_alias, rows));
         HIPCHK(hipMemcpyAsync(Ws.b_alias, src, rows * sizeof(u32), hipMemcpyDeviceToDevice, st));
         src = Ws.b_alias;
     }
-    if (D.fold_ok && fuse_mul && !G_.no_fold) {
+    if (D.fold_ok && !G_.no_fold) {
         // Folded form: Phi_m divides x^m - 1, so f is first folded to g = f mod (x^m - 1) (length D = min(m, 2n-1)); the
         // quotient q = floor(g / Phi) then has only Kq = D - n coefficients and comes from the top Kq coefficients of g
         // (reversed) times the inverse series of rev(Phi), a product that fits the HALF-length transform; and since
@@ -542,13 +526,9 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
         HIPCHK(hipGetLastError());
         return CUHE_OK;
     }
-    const long pairs = (long)rows / 2;
-    const int eb = (int)std::min<long>((pairs + 255) / 256, 8192);
-    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, src + (n - 1), np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? u_ntt : nullptr, np_mod));   // (f >> (n-1)) * u
-    if (!fuse_mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, u_ntt, pairs);
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, src + (n - 1), np, L, L, L, 0, wa, dev, st, nullptr, u_ntt, np_mod));   // (f >> (n-1)) * u
     CHK(run_ntt(L, kSrcU64Neg, Ws.b_crt, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st, nullptr, nullptr, np_mod));    // q at [n, 2n-1)
-    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st, nullptr, fuse_mul ? m_ntt : nullptr, np_mod));     // q * (m - x^n)
-    if (!fuse_mul) hipLaunchKernelGGL((k_ntt_binop<true>), dim3(eb), dim3(256), 0, st, Ws.b_ntt, Ws.b_ntt, m_ntt, pairs);
+    CHK(run_ntt(L, kSrcU32Ext, Ws.b_ntt, Ws.b_crt + n, np, L, L, L, 0, wa, dev, st, nullptr, m_ntt, np_mod));     // q * (m - x^n)
     CHK(run_ntt(L, kSrcU64Neg, Ws.b_mq, Ws.b_ntt, np, L, L, L, prime0, wa, dev, st, nullptr, nullptr, np_mod));
     hipLaunchKernelGGL(k_barrett_final, dim3((cl + 255) / 256, np), dim3(256), 0, st, dst, src, Ws.b_crt, Ws.b_mq, m_crt, pt, n, cl, L, np_mod);
     HIPCHK(hipGetLastError());
@@ -772,16 +752,19 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
 }
 
 int cuhe_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(G_.mu);
     for (int d = 0; d < (int)G_.dev.size(); ++d) {
-        hipSetDevice(G_.dev_base + d);
+        if (hipSetDevice(phys_dev(d)) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipDeviceSynchronize();
         DevCtx &D = G_.dev[d];
-        for (auto &t : D.ntt) { hipFree(t.T1); hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); t = NttTab(); }
+        for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek};
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);
         for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
         for (auto &kv : D.freeBlocks) hipFree(kv.second);
+        for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) hipFree(kv.second);     // parked in stream order
         for (auto &kv : D.allocated) hipFree(kv.first);
         D = DevCtx();
     }
@@ -828,8 +811,9 @@ static void settle_stream_blocks(DevCtx &D, hipStream_t st) {
 }
 int cuhe_hip_stop_allocator(void) {
     G_.allocator_on = false;
+    std::lock_guard<std::mutex> lk(G_.mu);
     for (int d = 0; d < (int)G_.dev.size(); ++d) {
-        hipSetDevice(G_.dev_base + d);
+        if (hipSetDevice(phys_dev(d)) != hipSuccess) { (void)hipGetLastError(); continue; }
         drop_cached(G_.dev[d]);
     }
     return CUHE_OK;
@@ -938,7 +922,18 @@ int cuhe_hip_stream_destroy(int dev, void *st) {
 int cuhe_hip_stream_sync(int dev, void *st) {
     CHK(set_dev(dev));
     HIPCHK(hipStreamSynchronize(S(st)));
-    if (!G_.dev[dev].streamBlocks.empty()) settle_stream_blocks(G_.dev[dev], S(st));
+    settle_stream_blocks(G_.dev[dev], S(st));
+    return CUHE_OK;
+}
+
+// waits for everything enqueued on the device; every block freed in stream order becomes an ordinary free block
+int cuhe_hip_device_sync(int dev) {
+    CHK(set_dev(dev));
+    HIPCHK(hipDeviceSynchronize());
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) D.freeBlocks.insert(kv);
+    D.streamBlocks.clear();
     return CUHE_OK;
 }
 
@@ -963,15 +958,7 @@ int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *s
     const IcrtLevel &I = D.icrt[lvl];
     IcrtTab it{I.M, I.mi, I.bi, I.rp};
     const size_t lds = icrt_lds_bytes(np, W);
-    if (lds > 64 * 1024) {
-        static bool attr_done[64] = {false};
-        int cur = 0;
-        HIPCHK(hipGetDevice(&cur));
-        if (!attr_done[cur & 63]) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done[cur & 63] = true;
-        }
-    }
+    CHK(icrt_lds_attr(lds));
     hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef), dim3(kIcrtCoef * kIcrtGroups), lds, S(st), dst,
                        src, prime_tab(D), it, np, W, q.modLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
@@ -1170,12 +1157,15 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
 // ---- binary evaluation-key cache.  initRelinearization costs numEvalKey * numCrtPrime forward
 // transforms plus the upload of the raw keys; the NTT-domain keys it produces depend only on the parameter set,
 // the CRT primes and the key polynomials, so a deployment computes them once and reloads this image.
-//   header (96 bytes, little endian): magic "CUHEEK\0\1", u32 version, i32 d,p,w,min,cut,m, i32 numCrtPrime,
-//   i32 numEvalKey, i32 nttLen, 2 x u32 0, u64 FNV-1a of the CRT primes, u64 payload bytes, u64 XOR of the payload words, 2 x u64 0;
-//   payload: u64[prime][key][nttLen], canonical residues mod P  (the HBM layout, cuhe/Relinearization.cu:45-55)
+//   header (96 bytes, little endian): magic "CUHEEK\0\1", u32 version (2), i32 d,p,w,min,cut,m, i32 numCrtPrime,
+//   i32 numEvalKey, i32 row length, 2 x u32 0, u64 FNV-1a of the CRT primes, u64 payload bytes, u64 payload hash (a
+//   position-dependent multiply-rotate hash over the payload words: swapped words and paired bit flips change it),
+//   u64 FNV-1a of the polynomial modulus coefficients, u64 key representation (0 = cyclic rows of nttLen, 1 = negacyclic rows of modLen);
+//   payload: u64[prime][key][row length], canonical residues mod P  (the HBM layout, cuhe/Relinearization.cu:45-55);
+//   import also refuses any word >= P (the field arithmetic assumes canonical operands).
 struct EkHeader {
     char magic[8]; uint32_t version; int32_t set[6]; int32_t np, k, L; uint32_t zero[2];
-    uint64_t primes_fnv, payload_bytes, payload_xor; uint64_t pad[2];
+    uint64_t primes_fnv, payload_bytes, payload_hash, modulus_fnv, key_rep;
 };
 static_assert(sizeof(EkHeader) == 96, "cache header layout");
 static const char kEkMagic[8] = {'C', 'U', 'H', 'E', 'E', 'K', 0, 1};
@@ -1184,20 +1174,33 @@ static uint64_t fnv1a(const void *p, size_t n) {
     for (size_t i = 0; i < n; ++i) { h ^= ((const uint8_t *)p)[i]; h *= 1099511628211ULL; }
     return h;
 }
-static uint64_t xor_words(const uint64_t *p, size_t n) {
-    uint64_t a = 0, b = 0, c = 0, d = 0; size_t i = 0;
-    for (; i + 4 <= n; i += 4) { a ^= p[i]; b ^= p[i + 1]; c ^= p[i + 2]; d ^= p[i + 3]; }
-    for (; i < n; ++i) a ^= p[i];
-    return a ^ b ^ c ^ d;
+// four independent lanes of (h ^ word) * odd, rotated: position dependent, ~10 GB/s; returns canonical = false if a word is >= P
+static uint64_t hash_words(const uint64_t *p, size_t n, bool *canonical) {
+    uint64_t h[4] = {0x9E3779B97F4A7C15ULL, 0xC2B2AE3D27D4EB4FULL, 0x165667B19E3779F9ULL, 0x27D4EB2F165667C5ULL};
+    bool ok = true;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int l = 0; l < 4; ++l) {
+            const uint64_t w = p[i + l];
+            ok &= w < host::P;
+            uint64_t x = (h[l] ^ w) * 0x9FB21C651E98DF25ULL;
+            h[l] = (x << 29) | (x >> 35);
+        }
+    for (; i < n; ++i) { const uint64_t w = p[i]; ok &= w < host::P; uint64_t x = (h[0] ^ w) * 0x9FB21C651E98DF25ULL; h[0] = (x << 29) | (x >> 35); }
+    if (canonical) *canonical = ok;
+    uint64_t r = n;
+    for (int l = 0; l < 4; ++l) { r = (r ^ h[l]) * 0xD6E8FEB86659FD93ULL; r ^= r >> 32; }
+    return r;
 }
 static EkHeader ek_header_now() {
     const Params &q = G_.prm;
     EkHeader h; memset(&h, 0, sizeof h);
-    memcpy(h.magic, kEkMagic, 8); h.version = 1;
+    memcpy(h.magic, kEkMagic, 8); h.version = 2;
     const int set[6] = {q.depth, q.modMsg, q.logRelin, q.logCoeffMin, q.logCoeffCut, q.mSize};
     memcpy(h.set, set, sizeof set);
     h.np = q.numCrtPrime; h.k = q.numEvalKey; h.L = q.nttLen;
     h.primes_fnv = fnv1a(G_.primes.data(), G_.primes.size() * sizeof(uint32_t));
+    h.modulus_fnv = fnv1a(G_.modulus.data(), G_.modulus.size() * sizeof(int32_t));
     h.payload_bytes = (uint64_t)q.numCrtPrime * q.numEvalKey * q.nttLen * sizeof(u64);
     return h;
 }
@@ -1212,7 +1215,7 @@ int cuhe_hip_relin_export(void *dst, size_t cap, int dev) {
     if (!dst || cap < sizeof h + h.payload_bytes) return fail(CUHE_EINVAL, "export buffer too small: %zu < %zu", cap, sizeof h + (size_t)h.payload_bytes);
     uint8_t *out = (uint8_t *)dst;
     HIPCHK(hipMemcpy(out + sizeof h, G_.dev[dev].ek, h.payload_bytes, hipMemcpyDeviceToHost));
-    h.payload_xor = xor_words((const uint64_t *)(out + sizeof h), h.payload_bytes / 8);
+    h.payload_hash = hash_words((const uint64_t *)(out + sizeof h), h.payload_bytes / 8, nullptr);
     memcpy(out, &h, sizeof h);
     return CUHE_OK;
 }
@@ -1221,13 +1224,16 @@ int cuhe_hip_relin_import(const void *src, size_t bytes) {
     if (!src || bytes < sizeof(EkHeader)) return fail(CUHE_EINVAL, "evaluation-key cache: truncated header");
     EkHeader h; memcpy(&h, src, sizeof h);
     const EkHeader want = ek_header_now();
-    if (memcmp(h.magic, kEkMagic, 8) != 0 || h.version != 1) return fail(CUHE_EINVAL, "evaluation-key cache: bad magic / version");
+    if (memcmp(h.magic, kEkMagic, 8) != 0 || h.version != 2) return fail(CUHE_EINVAL, "evaluation-key cache: bad magic / version");
     if (memcmp(h.set, want.set, sizeof h.set) != 0 || h.np != want.np || h.k != want.k || h.L != want.L)
         return fail(CUHE_EINVAL, "evaluation-key cache was made for other parameters");
     if (h.primes_fnv != want.primes_fnv) return fail(CUHE_EINVAL, "evaluation-key cache was made for other CRT primes");
+    if (h.modulus_fnv != want.modulus_fnv || h.key_rep != want.key_rep) return fail(CUHE_EINVAL, "evaluation-key cache was made for another polynomial modulus / key representation");
     if (h.payload_bytes != want.payload_bytes || bytes < sizeof h + h.payload_bytes) return fail(CUHE_EINVAL, "evaluation-key cache: truncated payload");
     const uint8_t *payload = (const uint8_t *)src + sizeof h;
-    if (xor_words((const uint64_t *)payload, h.payload_bytes / 8) != h.payload_xor) return fail(CUHE_EINVAL, "evaluation-key cache: payload checksum mismatch");
+    bool canonical = true;
+    if (hash_words((const uint64_t *)payload, h.payload_bytes / 8, &canonical) != h.payload_hash) return fail(CUHE_EINVAL, "evaluation-key cache: payload checksum mismatch");
+    if (!canonical) return fail(CUHE_EINVAL, "evaluation-key cache: payload holds a word >= P");
     const Params &q = G_.prm;
     for (int dev = 0; dev < G_.ndev; ++dev) {
         CHK(set_dev(dev));
@@ -1280,7 +1286,6 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     const Params &q = G_.prm;
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
-    if (g_pass2_form != 1) return fail(CUHE_EINVAL, "batched operations need the wave-split pass 2");
     hipStream_t st = S(st_);
     DevCtx &D = G_.dev[dev];
     const int np = q.numCrtPrimeAt(lvl), k = q.numEvalKeyAt(lvl), W = q.wordsCoeff(lvl), L = q.nttLen, cl = q.crtLen;
@@ -1323,7 +1328,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
         const IcrtLevel &I = D.icrt[lvl];
         IcrtTab it{I.M, I.mi, I.bi, I.rp};
         const size_t lds = icrt_lds_bytes(np, W);
-        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CHK(icrt_lds_attr(lds));
         hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, Ws.bt_raw,
                            crt_rows, prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
     }
@@ -1499,7 +1504,6 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     const Params &q = G_.prm;
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
-    if (g_pass2_form != 1) return fail(CUHE_EINVAL, "batched operations need the wave-split pass 2");
     hipStream_t st = S(st_);
     DevCtx &D = G_.dev[dev];
     const int np = q.numCrtPrimeAt(lvl), W = q.wordsCoeff(lvl), L = q.nttLen, cl = q.crtLen;
@@ -1541,7 +1545,7 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     const IcrtLevel &I = D.icrt[lvl];
     IcrtTab it{I.M, I.mi, I.bi, I.rp};
     const size_t lds = icrt_lds_bytes(np, W);
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_icrt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHK(icrt_lds_attr(lds));
     hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, dst, ca,
                        prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
     HIPCHK(hipGetLastError());
@@ -1601,8 +1605,6 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     return CUHE_OK;
 }
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
-int cuhe_hip_set_pass1_form(int form) { if (form < 0 || form > 1) return fail(CUHE_EINVAL, "pass-1 form %d", form); g_pass1_form = form; return CUHE_OK; }
-int cuhe_hip_set_pass2_form(int form) { if (form < 0 || form > 1) return fail(CUHE_EINVAL, "pass-2 form %d", form); g_pass2_form = form; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {
     CHK(set_dev(dev));
     if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);

@@ -21,54 +21,21 @@ typedef unsigned int u32;
 static constexpr u64 kP = 0xffffffff00000001ULL;
 static constexpr u64 kEps = 0xffffffffULL;   // 2^64 mod P
 
-// canonical -> canonical.  Instruction selection was chosen by measurement (tools/ubench_modp.hip,
-// profiles/r01_ubench_modp.txt): the add is done as a - (P - b) with a mask-and-subtract fix-up, which
-// needs one compare instead of two compares + s_or.
-#ifndef CUHE_SUBP_VARIANT
-#define CUHE_SUBP_VARIANT 5      /* measured (profiles/r01_experiments_log.txt); 4 is 2 % faster but leans on undocumented forwarding */
-#endif
+// canonical - canonical -> canonical.  a - b, then "+ P on borrow" without a select: + P = - eps = + 1 - 2^32, so with
+// the borrow B as a lane mask the low word takes B as a carry-in (lo + B, carry C) and the high word loses B & ~C
+// (d >= 2^32 whenever there was a borrow, so the high word cannot underflow): 4 VALU + 1 SALU, against 6 VALU for the
+// compare-and-select form.  The carries travel in SGPR pairs; LLVM pads "VALU writes an SGPR pair / VCC -> VALU reads it"
+// with two wait states on gfx940/950 (GCNHazardRecognizer, VALUWriteSGPRVALURead) and nothing pads the inside of an asm
+// string, so the two places where that happens carry their own s_nop 1 (tools/asm_hazard_check.py verifies every asm
+// site of the generated code, VCC included).  Chosen by A/B on the 64K transform (profiles/r02_field_arith_ab.txt):
+// same speed as the unpadded chain, faster than every SALU-free formulation.
 __device__ __forceinline__ u64 subp(u64 a, u64 b) {
     if (__builtin_constant_p(b) && b == 0) return a;     // e.g. the bits above 2^96 of a shifted 32-bit sample: the asm below would hide the zero
-#if CUHE_SUBP_VARIANT == 5
-    // same arithmetic as variant 4 with every carry in VCC and the implicit-VCC (e32) encodings, i.e. the instruction
-    // pattern the compiler itself emits for multi-word arithmetic: no VALU reads an SGPR pair that the VALU instruction
-    // before it wrote (LLVM pads that case with two wait states on gfx940/950; nothing pads the inside of an asm string)
-    u32 lo, hi; u64 bw;
-    asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"
-        "v_subb_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
-        "s_mov_b64 %2, vcc\n\t"
-        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
-        "s_andn2_b64 vcc, %2, vcc\n\t"
-        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
-        : "=&v"(lo), "=&v"(hi), "=&s"(bw)
-        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
-        : "vcc", "scc");
-    u64 d = ((u64)hi << 32) | lo;
-    asm("" : "+v"(d));
-    return d;
-#elif CUHE_SUBP_VARIANT == 6
-    // variant 4 with the two wait states between a VALU write of an SGPR pair and the VALU read of it
     u32 lo, hi; u64 bw, t;
     asm("v_sub_co_u32_e64 %0, %2, %4, %6\n\t"
         "s_nop 1\n\t"
         "v_subb_co_u32_e64 %1, %2, %5, %7, %2\n\t"
         "s_nop 1\n\t"
-        "v_addc_co_u32_e64 %0, %3, %0, 0, %2\n\t"
-        "s_andn2_b64 %2, %2, %3\n\t"
-        "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"
-        : "=&v"(lo), "=&v"(hi), "=&s"(bw), "=&s"(t)
-        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
-        : "scc");
-    u64 d = ((u64)hi << 32) | lo;
-    asm("" : "+v"(d));
-    return d;
-#elif CUHE_SUBP_VARIANT == 4
-    // a - b, then "- eps on borrow" without a select: - eps = + 1 - 2^32, so with the borrow B as a lane mask the low word
-    // takes B as a carry-in (lo + B, carry C) and the high word loses B & ~C.  4 VALU + 1 SALU instead of 5 VALU.
-    // (d >= 2^32 whenever there was a borrow, so the high word cannot underflow.)
-    u32 lo, hi; u64 bw, t;
-    asm("v_sub_co_u32_e64 %0, %2, %4, %6\n\t"
-        "v_subb_co_u32_e64 %1, %2, %5, %7, %2\n\t"
         "v_addc_co_u32_e64 %0, %3, %0, 0, %2\n\t"
         "s_andn2_b64 %2, %2, %3\n\t"
         "v_subbrev_co_u32_e64 %1, %3, 0, %1, %2"
@@ -78,43 +45,15 @@ __device__ __forceinline__ u64 subp(u64 a, u64 b) {
     u64 d = ((u64)hi << 32) | lo;
     asm("" : "+v"(d));              // keep the two words a register PAIR: otherwise 64-bit shifts of d are split into word operations
     return d;
-#elif CUHE_SUBP_VARIANT == 3
-    // the borrow of the two-instruction 64-bit subtraction comes out as a lane mask in an SGPR pair and is handed to the
-    // compiler through inverse_ballot (written in C the borrow is rebuilt with a 64-bit compare: 6 VALU instead of 5)
-    u32 lo, hi; u64 borrow;
-    asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t"
-        "v_subb_co_u32_e64 %1, %2, %4, %6, %2"
-        : "=&v"(lo), "=&v"(hi), "=&s"(borrow)
-        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)));
-    const u64 d = ((u64)hi << 32) | lo;
-    return __builtin_amdgcn_inverse_ballot_w64(borrow) ? d - kEps : d;
-#elif CUHE_SUBP_VARIANT == 1
-    u64 d;
-    const bool borrow = __builtin_usubll_overflow(a, b, &d);   // reuse the borrow of v_sub_co/v_subb_co
-    return borrow ? d - kEps : d;      // + P
-#else
-    u64 d = a - b;
-    return (a < b) ? d - kEps : d;     // + P
-#endif
 }
-#ifndef CUHE_ADDP_VARIANT
-#define CUHE_ADDP_VARIANT 2      /* measured best (profiles/r01_dft_variants.txt) */
-#endif
+// canonical + canonical -> canonical: "the 64-bit sum carried" and "the sum is >= P" exclude each other and both call
+// for + eps, applied as ONE v_mad_u64_u32 with a 0/1 flag.  (A single-compare form exists -- t = a + b + eps (mod 2^64)
+// is the result exactly when t < a -- but needs a two-word select, and two v_cndmask reading one condition issue at
+// less than half rate on gfx950: tools/ubench_rates.hip, profiles/r02_valu_cost_model.txt.)
 __device__ __forceinline__ u64 addp(u64 a, u64 b) {
-#if CUHE_ADDP_VARIANT == 1
-    u64 nb = kP - b;                   // in (0, P]; a - nb = a + b - P
-    u64 d = a - nb;
-    u64 m = (u64)0 - (u64)(a < nb);    // all ones on borrow
-    return d - (m & kEps);             // + P on borrow
-#elif CUHE_ADDP_VARIANT == 2
     u64 s = a + b;
-    const u32 f = ((s < a) | (s >= kP)) ? 1u : 0u;     // carried, or s >= P: add eps once
-    return (u64)f * 0xffffffffu + s;                   // one v_mad_u64_u32
-#else
-    u64 s = a + b;
-    u64 t = s + kEps;                  // s - P (mod 2^64)
-    return ((s < a) | (t < s)) ? t : s;    // carried, or s >= P
-#endif
+    const u32 f = ((s < a) | (s >= kP)) ? 1u : 0u;
+    return (u64)f * 0xffffffffu + s;
 }
 __device__ __forceinline__ u64 negp(u64 a) { return a ? kP - a : 0; }
 
@@ -124,54 +63,17 @@ __device__ __forceinline__ u64 canon(u64 r) {
     return (t < r) ? t : r;
 }
 
-// lo + m*eps for a 32-bit m, canonical result: ONE correction, because "the 64-bit sum carried" and
-// "the sum is >= P" exclude each other and both call for + eps.  (m*eps + lo is one v_mad_u64_u32.)
-#ifndef CUHE_SHLMID_VARIANT
-#define CUHE_SHLMID_VARIANT 0
-#endif
-#ifndef CUHE_MADEPS_VARIANT
-#define CUHE_MADEPS_VARIANT 4      /* measured (profiles/r01_experiments_log.txt) */
-#endif
+// lo + m*eps for a 32-bit m, canonical result: ONE correction, because "the 64-bit sum carried" and "the sum is >= P"
+// exclude each other and both call for + eps.  Only the multiply-add is asm: its carry-out lands in an SGPR pair (a
+// lane mask), which inverse_ballot hands back to the compiler as a per-lane boolean; the OR with the >= P compare, the
+// select and the final add are ordinary code the compiler schedules (and pads) itself.  The mask is consumed by the
+// s_or_b64 of that OR -- an SALU read, interlocked -- never directly by a VALU instruction.
 __device__ __forceinline__ u64 mad_eps(u32 m, u64 lo) {
     if (__builtin_constant_p(m) && m == 0) return canon(lo);      // small shifts of 32-bit samples: nothing above 2^64 (canon folds too)
-#if CUHE_MADEPS_VARIANT == 4
-    // Only the multiply-add is asm: its carry-out lands in an SGPR pair (a lane mask), which inverse_ballot hands back
-    // to the compiler as a per-lane boolean.  The OR with the >= P compare, the select and the final add are then
-    // ordinary code the compiler schedules itself (no SCC / VCC clobbers around a block of instructions).  The mask is
-    // consumed by the s_or_b64 of that OR (an SALU read, interlocked), never directly by a VALU instruction, so the
-    // "VALU writes an SGPR pair -> VALU reads it" wait states that nothing would insert after an asm statement do not arise.
     u64 r, carry;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(m), "v"(0xffffffffu), "v"(lo));
     const bool f = __builtin_amdgcn_inverse_ballot_w64(carry) | (r >= kP);
     return (u64)(f ? 1u : 0u) * 0xffffffffu + r;
-#elif CUHE_MADEPS_VARIANT == 3
-    // the multiply-add's own carry-out (vcc) replaces the 64-bit compare that rebuilds it: 4 VALU + 1 SALU instead of 5 + 1
-    u64 r; u32 f; u64 tmp;
-    const u64 kPc = kP;
-    asm("v_mad_u64_u32 %0, vcc, %3, %4, %5\n\t"
-        "v_cmp_ge_u64_e64 %2, %0, %6\n\t"
-        "s_or_b64 vcc, vcc, %2\n\t"
-        "v_cndmask_b32_e64 %1, 0, 1, vcc\n\t"
-        "v_mad_u64_u32 %0, vcc, %1, %4, %0"
-        : "=&v"(r), "=&v"(f), "=&s"(tmp)
-        : "v"(m), "v"(0xffffffffu), "v"(lo), "s"(kPc)
-        : "vcc", "scc");           // s_or_b64 writes SCC: without the clobber a uniform compare-and-branch around
-                                   // the block can be fed a stale flag (seen as unwritten outputs in one kernel variant)
-    return r;
-#elif CUHE_MADEPS_VARIANT == 2
-    u64 r = (u64)m * 0xffffffffu + lo;
-    const u32 f = ((r < lo) | (r >= kP)) ? 1u : 0u;
-    return (u64)f * 0xffffffffu + r;
-#elif CUHE_MADEPS_VARIANT == 1
-    u64 r = (u64)m * 0xffffffffu + lo;
-    u64 t = r + kEps;
-    return ((r < lo) | (t < r)) ? t : r;
-#else
-    u64 t1 = ((u64)m << 32) - m;
-    u64 r = lo + t1;
-    if (r < lo) r += kEps;
-    return canon(r);
-#endif
 }
 
 // 128-bit (hi:lo) -> canonical; hi = hh:hl.  lo + hl*(phi-1) - hh
@@ -213,12 +115,8 @@ __device__ __forceinline__ u64 shlp(u64 x) {
     } else if constexpr (K == 32) {
         return mad_eps((u32)(x >> 32), (u64)(u32)x << 32);         // x0*phi + x1*(phi-1)
     } else if constexpr (K < 64) {
-#if CUHE_SHLMID_VARIANT == 1
-        return shlp<32>(shlp<K - 32>(x));
-#else
         u64 r = mad_eps((u32)(x >> (64 - K)), x << K);      // bits 0..95
         return subp(r, x >> (96 - K));                       // minus bits 96.. (2^96 = -1)
-#endif
     } else if constexpr (K == 64) {
         u32 x0 = (u32)x, x1 = (u32)(x >> 32);
         u64 t1 = ((u64)x0 << 32) - x0;             // x0 * eps

@@ -11,12 +11,9 @@
 //       twiddle w_L^(j2*k1), stored as X[k1 + N1*k2] in natural order.
 //
 // Every sub-transform of <= 64 points is shift-only (8 = 2^3 is a 64-th root of unity
-// mod P); exactly two general modular multiplications per point remain.  The DEFAULT
-// kernels are the "wave-split" forms at the end of this file (ntt_pass1w / ntt_pass2w:
-// 16 values per thread in every register stage, 64-point stages done as 16 x 4 over
-// wave-uniform quarters through LDS).  The first two kernels below (ntt_pass1: 32 values
-// per thread in two stages; ntt_pass2: a whole 64-point DFT per thread, no LDS) are the
-// earlier register-heavy forms, kept selectable for A/B measurements.
+// mod P); exactly two general modular multiplications per point remain.  Both kernels are
+// "wave-split" (ntt_pass1w / ntt_pass2w): 16 values per thread in every register stage,
+// 64-point stages done as 16 x 4 over wave-uniform quarters through LDS.
 //
 // The inverse transform reuses the same passes on index-negated input
 // (cuhe/Base.cu:454,622,799) with L^-1 folded into the outer twiddle table and
@@ -27,28 +24,6 @@
 #include "modp.cuh"
 
 namespace cuhe {
-
-template <int LG> struct NttGeom;
-template <> struct NttGeom<14> { static constexpr int R1 = 16, R2 = 16, NC = 32; };
-template <> struct NttGeom<15> { static constexpr int R1 = 16, R2 = 32, NC = 16; };
-template <> struct NttGeom<16> { static constexpr int R1 = 32, R2 = 32, NC = 8; };
-
-static constexpr int kNttThreads = 256;
-#ifndef CUHE_P2_THREADS
-#define CUHE_P2_THREADS 256
-#endif
-// pass-2 workgroup size: one thread per k1, a workgroup covers p2_threads<LG>() adjacent k1
-template <int LG> constexpr int p2_threads() { return ((1 << LG) / 64 < CUHE_P2_THREADS) ? (1 << LG) / 64 : CUHE_P2_THREADS; }
-
-template <int LG>
-struct NttLds {
-    using G = NttGeom<LG>;
-    static constexpr int RS = G::R2 + 1;                 // row stride (u64), odd: conflict-free reads
-    static constexpr int CS = G::R1 * RS + 2;            // column stride (u64), == 2 mod 16
-    static constexpr int XCH = G::NC * CS;               // exchange buffer (u64)
-    static constexpr int T1N = G::R1 * G::R2;            // inner twiddle table (u64)
-    static constexpr size_t bytes = (size_t)(XCH + T1N) * sizeof(u64);
-};
 
 enum : int { kSrcU32Ext = 0, kSrcWindow = 1, kSrcU64Neg = 2 };
 
@@ -82,87 +57,9 @@ __device__ __forceinline__ void dft_regs(u64 (&x)[N]) {
     }
 }
 
-template <int LG, int MODE>
-__global__ __launch_bounds__(kNttThreads, 2)
-void ntt_pass1(const void *__restrict__ src_, u64 *__restrict__ scratch,
-               const u64 *__restrict__ T1, long src_stride, int nbatch, WindowArgs wa) {
-    using G = NttGeom<LG>;
-    using S = NttLds<LG>;
-    constexpr int L = 1 << LG, N1 = L / 64, R1 = G::R1, R2 = G::R2, NC = G::NC;
-    constexpr int T = kNttThreads;
-    constexpr int IT1 = NC * R2 / T, IT3 = NC * R1 / T;
-    constexpr bool EXT = (MODE != kSrcU64Neg);
-    constexpr int NA = EXT ? R1 / 2 : R1;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64 *xch = lds;
-    u64 *t1 = lds + S::XCH;
-
-    int batch, tile;
-    xcd_map(64 / NC, batch, tile);
-    if (batch >= nbatch) return;
-    const int t = threadIdx.x;
-    const int col0 = tile * NC;
-
-    for (int i = t; i < S::T1N; i += T) t1[i] = T1[i];
-
-    // ---- step (i): R1-point DFTs over a, j1 = a*R2 + b ----
-#pragma unroll
-    for (int it = 0; it < IT1; ++it) {
-        const int e = t + T * it;
-        const int col = e % NC, b = e / NC;
-        u64 x[R1];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const int idx = (a * R2 + b) * 64 + col0 + col;
-            if constexpr (MODE == kSrcU32Ext) {
-                const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
-                x[a] = src[idx];
-            } else if constexpr (MODE == kSrcWindow) {
-                // cuhe/Base.cu:361-371: w-bit window `wid` of a W-word coefficient
-                const u32 *co = (const u32 *)src_ + (long)idx * wa.words;
-                const int bit = wa.w * (wa.wid0 + batch);
-                const int wi = bit >> 5;
-                u64 s = co[wi];
-                if (wi + 1 < wa.words) s |= (u64)co[wi + 1] << 32;
-                s >>= (bit & 31);
-                x[a] = s & (u64)((1u << wa.w) - 1u);
-            } else {
-                const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
-                x[a] = src[(L - idx) & (L - 1)];
-            }
-        }
-        dft_regs<R1, EXT>(x);
-        if (it == 0) __syncthreads();            // t1 table visible
-#pragma unroll
-        for (int c = 0; c < R1; ++c) {
-            u64 v = x[bitrev<R1>(c)];
-            if (c != 0) v = mulp(v, t1[c * R2 + b]);
-            xch[col * S::CS + c * S::RS + b] = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- step (iii): R2-point DFTs over b, k1 = c + R1*d ----
-    u64 *out = scratch + (long)batch * L;
-#pragma unroll
-    for (int it = 0; it < IT3; ++it) {
-        const int e = t + T * it;
-        const int c = e % R1, col = e / R1;
-        u64 y[R2];
-#pragma unroll
-        for (int b = 0; b < R2; ++b) y[b] = xch[col * S::CS + c * S::RS + b];
-        dft_regs<R2, false>(y);
-        const int j2 = col0 + col;
-#pragma unroll
-        for (int d = 0; d < R2; ++d) {
-            out[j2 * N1 + c + R1 * d] = y[bitrev<R2>(d)];        // plain store: pass 2 re-reads it from cache
-        }
-    }
-}
-
-// kOutU64Mul (wave-split pass 2 only): forward transform whose outputs are multiplied by a table row on the way out
+// kOutU64Mul: forward transform whose outputs are multiplied by a table row on the way out
 // (the pointwise product with a precomputed NTT-domain constant, fused: `pinv` carries the table, u64[prime][L])
-// kOutModPRevQ / kOutFoldFinal (wave-split pass 2 only): the two inverse transforms of the folded generic reduction
+// kOutModPRevQ / kOutFoldFinal: the two inverse transforms of the folded generic reduction
 // (cuhe_hip.hip: barrett_impl) with the elementwise step that follows each of them done in the store:
 //   RevQ      : the first Kq coefficients come out REVERSED (q[t] = C[Kq-1-t]) and zero up to Lh/2 -- the quotient, ready
 //               as input of the next forward transform;
@@ -179,59 +76,6 @@ __device__ __forceinline__ u32 fold_g(const u32 *row, int i, const FoldGeom &G, 
     u32 a = row[i];
     if (G.D == G.m && i + G.m <= 2 * G.n - 2) { a += row[i + G.m]; if (a >= p) a -= p; }
     return a;
-}
-
-template <int LG, int OUT>
-__global__ __launch_bounds__(p2_threads<LG>(), 2)
-void ntt_pass2(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
-               long dst_stride, int nbatch, int nstore,
-               const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0) {
-    constexpr int L = 1 << LG, N1 = L / 64;
-    constexpr bool INV = OUT != kOutU64;
-    int batch, tile;
-    xcd_map(N1 / p2_threads<LG>(), batch, tile);
-    if (batch >= nbatch) return;
-    const int k1 = tile * p2_threads<LG>() + threadIdx.x;
-    const u64 *in = scratch + (long)batch * L + k1;
-    const u64 *tw = T2 + k1;
-    u64 x[64];
-    // outer twiddle w_L^(j2*k1) (times L^-1 for the inverse) applied here, on the bandwidth-bound side of the
-    // pair: pass 1 is issue-bound, pass 2 has VALU slack under its loads/stores (profiles/r01_chunk_sweep.txt)
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        u64 v = __builtin_nontemporal_load(&in[j * N1]);      // slab is read exactly once
-        if (INV || j != 0) v = mulp(v, tw[j * N1]);
-        x[j] = v;
-    }
-    dft_regs<64, false>(x);
-    if constexpr (OUT == kOutU64) {
-        u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
-#pragma unroll
-        for (int k2 = 0; k2 < 64; ++k2) __builtin_nontemporal_store(x[bitrev<64>(k2)], &dst[k2 * N1]);
-    } else if constexpr (OUT == kOutModP) {
-        // cuhe/Base.cu:469-490: (x * L^-1 mod P) % p_i -> u32 (L^-1 already in T2)
-        const u32 p = primes[prime0 + batch];
-        const u64 m = pinv[prime0 + batch];
-        u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
-        const int k2full = nstore / N1, rem = nstore % N1;     // wave-uniform row limit
-#pragma unroll
-        for (int k2 = 0; k2 < 64; ++k2)
-            if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[k2 * N1] = mod_small(x[bitrev<64>(k2)], p, m);
-    } else {
-        // inverse transform of a product fused with the reduction modulo x^(L/2) + 1 (inttMod when Phi_m = x^n + 1,
-        // n = L/2): the thread owns f[i] (k2) and f[i + n] (k2 + 32); r[i] = (f[i] - f[i+n]) mod p_i.  The values are
-        // the exact integer coefficients (< P), so the signed difference is reduced once instead of both terms.
-        const u32 p = primes[prime0 + batch];
-        const u64 m = pinv[prime0 + batch];
-        u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
-#pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) {
-            const u64 a = x[bitrev<64>(k2)], b = x[bitrev<64>(k2 + 32)];
-            const bool neg = a < b;
-            const u32 r = mod_small(neg ? b - a : a - b, p, m);
-            dst[k2 * N1] = (neg && r) ? p - r : r;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -351,7 +195,9 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
                 } else if (idx < nstore) dst[idx] = 0u;
             }
         } else {
-            // fused reduction modulo x^(L/2)+1: pairs (k2, k2 + 32) = (c, c + 2), see ntt_pass2
+            // inverse transform of a product fused with the reduction modulo x^(L/2) + 1 (inttMod when Phi_m = x^n + 1,
+            // n = L/2): the thread owns f[i] (k2 = b + 16c) and f[i + n] (k2 + 32, i.e. c + 2); r[i] = (f[i] - f[i+n]) mod p_i.
+            // The values are the exact integer coefficients (< P), so the signed difference is reduced once.
             u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -373,7 +219,6 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
 //   B-A : thread (r, col, c): 16-point DFT over a' of the b = 4a' + r, times 2^(3*r*b'') (r is wave-uniform: one
 //         specialised code path per wave, compile-time shifts), -> LDS [col][c][b''][r]   (same buffer, re-used)
 //   B-B : thread (w, col, c): for b'' = 4i + w a 4-point DFT over r -> k1 = c + RA*(b'' + 16c''), stored to the slab.
-// Same arithmetic per point as ntt_pass1, half the critical path per wave, twice the resident waves.
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr int kP1wThreads = 512;
 template <int LG>

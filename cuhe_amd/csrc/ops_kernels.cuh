@@ -321,21 +321,28 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
 // Split accumulator: with a = a0 + a1 2^32, b = b0 + b1 2^32 the sum of products is
 //     S = sum a0 b0  +  2^64 sum a1 b1  +  2^32 (sum a0 b1 + sum a1 b0),
 // three independent 64-bit running sums with a carry counter each.  v_mad_u64_u32 already adds a 64-bit operand and
-// reports the carry, so one multiply-add of the inner product is four {v_mad_u64_u32 ; v_addc_co_u32} pairs = 8 VALU
+// reports the carry, so one multiply-add of the inner product is four v_mad_u64_u32 and four v_addc_co_u32 = 8 VALU
 // instructions (the 128-bit product + 160-bit add costs 15 with a hand-written carry chain, 24 in C).  The three
 // sums are recombined modulo P once per output.
 struct AccSplit { u64 s00, s11, sx; u32 c00, c11, cx; };
-__device__ __forceinline__ void acc_mad(u64 &sum, u32 &carries, u32 x, u32 y) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
-        : "+v"(sum), "+v"(carries) : "v"(x), "v"(y) : "vcc");
-}
+// The four multiply-adds first, then the four carry adds: every carry (VCC and three SGPR pairs) is read three or more
+// instructions after the VALU instruction that wrote it, which covers the two wait states gfx940/950 need between a VALU
+// write of an SGPR / VCC and a VALU read of it (nothing pads the inside of an asm string; tools/asm_hazard_check.py).
 __device__ __forceinline__ void mac_split(u64 a, u64 b, AccSplit &s) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    acc_mad(s.s00, s.c00, a0, b0);
-    acc_mad(s.s11, s.c11, a1, b1);
-    acc_mad(s.sx, s.cx, a0, b1);
-    acc_mad(s.sx, s.cx, a1, b0);
+    u64 tA, tB, tC;
+    asm("v_mad_u64_u32 %[s00], vcc, %[a0], %[b0], %[s00]\n\t"
+        "v_mad_u64_u32 %[sx], %[tA], %[a0], %[b1], %[sx]\n\t"
+        "v_mad_u64_u32 %[s11], %[tB], %[a1], %[b1], %[s11]\n\t"
+        "v_mad_u64_u32 %[sx], %[tC], %[a1], %[b0], %[sx]\n\t"
+        "v_addc_co_u32_e32 %[c00], vcc, 0, %[c00], vcc\n\t"
+        "v_addc_co_u32_e64 %[cx], %[tA], 0, %[cx], %[tA]\n\t"
+        "v_addc_co_u32_e64 %[c11], %[tB], 0, %[c11], %[tB]\n\t"
+        "v_addc_co_u32_e64 %[cx], %[tC], 0, %[cx], %[tC]"
+        : [s00] "+v"(s.s00), [s11] "+v"(s.s11), [sx] "+v"(s.sx), [c00] "+v"(s.c00), [c11] "+v"(s.c11), [cx] "+v"(s.cx),
+          [tA] "=&s"(tA), [tB] "=&s"(tB), [tC] "=&s"(tC)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1)
+        : "vcc");
 }
 // S mod P with 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32:
 //   S = (s00 + c00 2^64) + 2^64 (s11 + c11 2^64) + 2^32 (sx + cx 2^64)

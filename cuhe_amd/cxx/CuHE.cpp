@@ -513,21 +513,25 @@ void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
 	crtAddInt(out.cRep(), in.cRep(), (unsigned)param.modMsg - 1, out.logq(), out.device(), st);
 	GATE_SYNC(out.device(), st);
 }
+// The destination block is written by a copy on `st`, a stream of the SOURCE device: it must not be a block that is
+// only parked in the order of one of the destination's streams (work enqueued there may still touch it), so it comes
+// from the settled pool (cuhe_hip_malloc), never from the stream-ordered one.
+static void *peerAlloc(int dev, size_t bytes) { void *p = cuhe_hip_malloc(dev, bytes); if (!p) CSC(CUHE_EHIP); return p; }
 void moveTo(CuCtxt &tar, int dstDev, cudaStream_t st) {
 	if (dstDev == tar.device()) return;
 	const int srcDev = tar.device();
 	if (tar.domain() == 1) {
-		void *p = devAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.rRepSize());
+		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.rRepSize());
 		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.rRep(), srcDev, tar.rRepSize(), st));
 		CSC(cuhe_hip_stream_sync(srcDev, st));
 		tar.rRepFree(); tar.rRep((uint32 *)p);
 	} else if (tar.domain() == 2) {
-		void *p = devAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.cRepSize());
+		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.cRepSize());
 		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.cRep(), srcDev, tar.cRepSize(), st));
 		CSC(cuhe_hip_stream_sync(srcDev, st));
 		tar.cRepFree(); tar.cRep((uint32 *)p);
 	} else if (tar.domain() == 3) {
-		void *p = devAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.nRepSize());
+		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.nRepSize());
 		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.nRep(), srcDev, tar.nRepSize(), st));
 		CSC(cuhe_hip_stream_sync(srcDev, st));
 		tar.nRepFree(); tar.nRep((uint64 *)p);
@@ -595,9 +599,12 @@ void mulZZXBatch(ZZX *x, const ZZX *a, const ZZX *b, int count, int lvl, int dev
 #include "CuHEArray.h"
 namespace cuHE {
 
-CuIndexTable::~CuIndexTable() { if (data_) cuhe_hip_free(device_, data_); }
+// A table may still be read by a gate enqueued on any stream (asynchronous gates): wait for the device before the
+// block can be handed out again.  Tables are built once per circuit layout, so the synchronisation is off the hot path.
+static void freeIndexTable(int dev, int *p) { if (!p) return; if (streamOrdered()) CSC(cuhe_hip_device_sync(dev)); CSC(cuhe_hip_free(dev, p)); }
+CuIndexTable::~CuIndexTable() { freeIndexTable(device_, data_); }
 void CuIndexTable::set(const std::vector<int> &values, int device) {
-	if (data_) { CSC(cuhe_hip_free(device_, data_)); data_ = NULL; }
+	freeIndexTable(device_, data_); data_ = NULL;
 	device_ = device; size_ = values.size();
 	data_ = (int *)cuhe_hip_malloc(device_, (size_ ? size_ : 1) * sizeof(int));
 	if (!data_) CSC(CUHE_EHIP);
@@ -610,14 +617,16 @@ static size_t arrayCtElems(int lvl) { return (size_t)param._numCrtPrime(lvl) * p
 static void arrayMisuse(const char *msg) { printf("Error: %s\n", msg); terminate(); }
 
 void CuCtxtArray::release() {
-	if (cRep_) { devFree(device_, cRep_, 0); cRep_ = NULL; }
-	if (nRep_) { devFree(device_, nRep_, 0); nRep_ = NULL; }
+	// in the order of the stream that last used the storage (a block parked for stream s is only reissued to stream s
+	// until s has been synchronised; releasing on another stream could hand it out while kernels still touch it)
+	if (cRep_) { devFree(device_, cRep_, stream_); cRep_ = NULL; }
+	if (nRep_) { devFree(device_, nRep_, stream_); nRep_ = NULL; }
 	count_ = 0; level_ = -1; domain_ = -1; isProd_ = false;
 }
 void CuCtxtArray::create(int count, int lvl, int domain, int device, cudaStream_t st) {
 	if (count < 1 || lvl < 0 || lvl >= param.depth || (domain != 2 && domain != 3)) arrayMisuse("CuCtxtArray::create: bad count, level or domain");
 	release();
-	count_ = count; level_ = lvl; domain_ = domain; device_ = device; isProd_ = false;
+	count_ = count; level_ = lvl; domain_ = domain; device_ = device; isProd_ = false; stream_ = st;
 	// storage is sized for level 0 whatever the level: a circuit walks down the levels with arrays of the same few
 	// counts, and blocks of the same size come back from the library's block cache instead of hipMalloc / hipFree
 	if (domain == 2) cRep_ = (uint32 *)devAlloc(device, count * arrayCtWords(0) * sizeof(uint32), st);
@@ -629,12 +638,14 @@ uint64 *CuCtxtArray::nRep(int i) { return nRep_ ? nRep_ + (size_t)i * arrayCtEle
 void CuCtxtArray::put(int i, CuCtxt &src, cudaStream_t st) {
 	if (i < 0 || i >= count_ || src.level() != level_ || src.domain() != domain_ || src.device() != device_)
 		arrayMisuse("CuCtxtArray::put: index, level, domain or device mismatch");
+	touch(st);
 	if (domain_ == 2) CSC(cuhe_hip_memcpy_d2d(device_, cRep(i), src.cRep(), src.cRepSize(), st));
 	else { CSC(cuhe_hip_memcpy_d2d(device_, nRep(i), src.nRep(), src.nRepSize(), st)); isProd_ = isProd_ || src.isProd(); }
 	GATE_SYNC(device_, st);
 }
 void CuCtxtArray::get(CuCtxt &dst, int i, cudaStream_t st) {
 	if (i < 0 || i >= count_) arrayMisuse("CuCtxtArray::get: index out of range");
+	touch(st);
 	dst.reset();
 	dst.setLevelForOutput(level_, domain_, device_, st);
 	if (domain_ == 2) CSC(cuhe_hip_memcpy_d2d(device_, dst.cRep(), cRep(i), dst.cRepSize(), st));
@@ -644,6 +655,7 @@ void CuCtxtArray::get(CuCtxt &dst, int i, cudaStream_t st) {
 void CuCtxtArray::x2n(cudaStream_t st) {
 	if (domain_ == 3) return;
 	if (domain_ != 2) arrayMisuse("CuCtxtArray::x2n: empty array");
+	touch(st);
 	{
 		GateScope chain;
 		nRep_ = (uint64 *)devAlloc(device_, count_ * arrayCtElems(0) * sizeof(uint64), st);
@@ -656,6 +668,7 @@ void CuCtxtArray::x2n(cudaStream_t st) {
 void CuCtxtArray::x2c(cudaStream_t st) {
 	if (domain_ == 2) return;
 	if (domain_ != 3) arrayMisuse("CuCtxtArray::x2c: empty array");
+	touch(st);
 	{
 		GateScope chain;
 		cRep_ = (uint32 *)devAlloc(device_, count_ * arrayCtWords(0) * sizeof(uint32), st);
@@ -670,6 +683,7 @@ void CuCtxtArray::relin(cudaStream_t st) {
 	{
 		GateScope chain;
 		x2c(st);
+		touch(st);
 		CSC(cuhe_hip_relin_batch(cRep_, cRep_, level_, count_, device_, st));
 	}
 	GATE_SYNC(device_, st);
@@ -679,6 +693,7 @@ void CuCtxtArray::modSwitch(cudaStream_t st) {
 	{
 		GateScope chain;
 		x2c(st);
+		touch(st);
 		uint32 *next = (uint32 *)devAlloc(device_, count_ * arrayCtWords(0) * sizeof(uint32), st);
 		CSC(cuhe_hip_crt_mod_switch_batch(next, cRep_, level_, count_, device_, st));
 		devFree(device_, cRep_, st);
@@ -700,6 +715,7 @@ void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStrea
 		dst.create(total, lvl, dom, dev, st);
 		int at = 0;
 		for (CuCtxtArray *p : parts) {
+			p->touch(st);
 			if (dom == 2) CSC(cuhe_hip_memcpy_d2d(dev, dst.cRep(at), p->cRep_, p->count() * arrayCtWords(lvl) * sizeof(uint32), st));
 			else CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(at), p->nRep_, p->count() * arrayCtElems(lvl) * sizeof(uint64), st));
 			at += p->count();
@@ -714,6 +730,7 @@ void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuInde
 	{
 		GateScope chain;
 		out.create((int)a.size(), in.level(), 3, in.device(), st);
+		in.touch(st);
 		CSC(cuhe_hip_ntt_mul_pairs(U64P(out.nRep_), U64P(in.nRep_), a.data(), b.data(), (int)a.size(), param._numCrtPrime(in.level()), in.device(), st));
 		out.isProd_ = true;
 	}
@@ -728,6 +745,7 @@ void cXor(CuCtxtArray &out, CuCtxtArray &in0, CuCtxtArray *in1, const CuIndexTab
 	{
 		GateScope chain;
 		out.create(nout, in0.level(), 2, in0.device(), st);
+		in0.touch(st); if (in1) in1->touch(st);
 		CSC(cuhe_hip_crt_combine(out.cRep_, in0.cRep_, in0.count(), in1 ? in1->cRep_ : NULL, offsets.data(), list.data(), addOne.data(), nout,
 		                         in0.level(), in0.device(), st));
 	}

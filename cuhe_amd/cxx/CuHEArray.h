@@ -14,7 +14,7 @@ namespace cuHE {
 // a table of ciphertext indices in device memory (operand pairs of cAnd, term lists of cXor)
 class CuIndexTable {
 public:
-	CuIndexTable() : data_(NULL), size_(0), device_(0) {}
+	CuIndexTable() : data_(NULL), size_(0), device_(0) {}   // (tables are uploaded synchronously on stream 0 and only read afterwards)
 	~CuIndexTable();
 	void set(const std::vector<int> &values, int device = 0);
 	const int *data() const { return data_; }
@@ -27,7 +27,7 @@ private:
 
 class CuCtxtArray {
 public:
-	CuCtxtArray() : count_(0), level_(-1), domain_(-1), device_(0), isProd_(false), cRep_(NULL), nRep_(NULL) {}
+	CuCtxtArray() : count_(0), level_(-1), domain_(-1), device_(0), isProd_(false), cRep_(NULL), nRep_(NULL), stream_(0) {}
 	~CuCtxtArray() { release(); }
 	// `count` ciphertexts of level `lvl` in `domain` (2 = CRT, 3 = NTT), contents undefined
 	void create(int count, int lvl, int domain, int device = 0, cudaStream_t st = 0);
@@ -57,6 +57,8 @@ private:
 	bool isProd_;
 	uint32 *cRep_;
 	uint64 *nRep_;
+	cudaStream_t stream_;             // the stream that last produced or consumed the storage: blocks are released in its order
+	void touch(cudaStream_t st) { stream_ = st; }
 };
 
 // dst = a copy of src; dst = the ciphertexts of all parts in order (parts of one level, domain and device)

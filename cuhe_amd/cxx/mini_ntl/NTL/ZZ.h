@@ -4,6 +4,9 @@
 // its headers are found first (see cuhe_amd/cxx/Makefile) and this directory is
 // not on the include path.  Only what CuHE.h / the tests need is provided.
 #pragma once
+#include <sys/random.h>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -224,10 +227,25 @@ inline std::ostream &operator<<(std::ostream &os, const ZZ &a) {
     std::reverse(s.begin(), s.end());
     return os << s;
 }
-// deterministic xorshift stream (stand-in for NTL's PRG in tests)
-inline uint64_t &mini_seed() { static uint64_t s = 0x9E3779B97F4A7C15ULL; return s; }
-inline void SetSeed(const ZZ &s) { mini_seed() = (uint64_t)to_long(s) * 2654435761ULL + 1; }
-inline uint64_t mini_next() { uint64_t &s = mini_seed(); s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+// Random source of this fallback.  NOT a cryptographic PRG: until SetSeed is called every word comes from the
+// operating system (getrandom), so a client built against mini_ntl by accident does not draw predictable keys; after
+// SetSeed(s) -- which the tests call for reproducible runs -- it is a 64-bit xorshift stream determined by s alone.
+// Deployments use the real NTL (Makefile: NTL_PREFIX); INTEGRATION.md says so.
+inline uint64_t &mini_seed() { static uint64_t s = 0; return s; }
+inline bool &mini_seeded() { static bool b = false; return b; }
+inline void SetSeed(const ZZ &s) { mini_seed() = (uint64_t)to_long(s) * 2654435761ULL + 1; mini_seeded() = true; }
+inline uint64_t mini_next() {
+    if (!mini_seeded()) {
+        uint64_t v = 0; size_t got = 0;
+        while (got < sizeof v) {
+            const ssize_t r = getrandom((unsigned char *)&v + got, sizeof v - got, 0);
+            if (r <= 0) { std::fprintf(stderr, "mini_ntl: getrandom failed\n"); std::abort(); }
+            got += (size_t)r;
+        }
+        return v;
+    }
+    uint64_t &s = mini_seed(); s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s;
+}
 inline ZZ RandomBnd(const ZZ &n) {
     ZZ r; r.m.assign(n.m.size() + 1, 0);
     for (auto &x : r.m) x = (uint32_t)mini_next();

@@ -116,6 +116,8 @@ int cuhe_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, s
 int cuhe_hip_stream_create(int dev, void **stream_out);
 int cuhe_hip_stream_destroy(int dev, void *stream);
 int cuhe_hip_stream_sync(int dev, void *stream);
+/* waits for all work on the device (every stream); blocks freed in stream order become reusable by any stream */
+int cuhe_hip_device_sync(int dev);
 
 /* ---- operation drivers (cuhe/Operations.h:60-108), same argument order */
 int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *stream);            /* Operations.cu:245 */
@@ -216,9 +218,6 @@ int cuhe_hip_set_ntt_chunk(int chunk);
 /* 1 (default): pass 2 of chunk c runs concurrently with pass 1 of chunk c+1 on two internal streams
  * (joined back into `stream` before the call returns control of it); 0: strictly serial launches */
 int cuhe_hip_set_ntt_overlap(int on);
-/* pass-2 kernel form: 1 (default) = wave-split 16 x 4 through LDS, 0 = one thread per 64-point DFT (tuning / A-B tests) */
-int cuhe_hip_set_pass2_form(int form);
-int cuhe_hip_set_pass1_form(int form);    /* 1 (default) = wave-split RA x 16 x 4, 0 = 32 values per thread */
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,

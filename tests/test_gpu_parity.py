@@ -479,35 +479,6 @@ def test_prince_full_size_properties(gu):
         g.close()
 
 
-@pytest.mark.parametrize("p1,p2", [(0, 0), (0, 1), (1, 0)])
-def test_alternative_kernel_forms(gu, p1, p2):
-    """the register-heavy forms of both passes (ntt_pass1 / ntt_pass2) stay selectable for A/B runs: forward (all three
-    lengths) and inverse results must not depend on the form."""
-    import oracle_lib as O
-    lib, ck = gu.lib, gu.ck
-    ck(lib.cuhe_hip_set_pass1_form(p1)); ck(lib.cuhe_hip_set_pass2_form(p2))
-    try:
-        for length in (16384, 32768, 65536):
-            x = np.stack([O.splitmix_u32_below(length // 2, 0xFFFFFFFF, 700 + b) for b in range(3)])
-            dx, dX = gu.to_dev(x), gu.empty_u64(3, length)
-            ck(lib.cuhe_hip_ntt_prepare(length, 0))
-            ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), dx.data_ptr(), length, 3, length // 2, 0, None))
-            X = gu.host_u64(dX)
-            for b in range(3):
-                assert np.array_equal(X[b], O.ntt_ext(x[b], length)), (length, b)
-        g = gu.GpuCtx(3, 2, 16, 50, 25, 16384)           # x^8192 + 1: fused inverse epilogue too
-        o = O.Ctx(3, 2, 16, 50, 25, 16384)
-        try:
-            a, b = _rand_crt(o, o.np_(0), 1), _rand_crt(o, o.np_(0), 2)
-            Xp = o.ntt_mul(o.ntt(a), o.ntt(b))
-            assert np.array_equal(g.intt_mod(Xp, 0), o.intt_mod(Xp))
-            assert np.array_equal(g.intt_double_deg(Xp, 0), o.intt_hold(Xp))
-        finally:
-            g.close(); o.close()
-    finally:
-        ck(lib.cuhe_hip_set_pass1_form(1)); ck(lib.cuhe_hip_set_pass2_form(1))
-
-
 def test_evalkey_cache_roundtrip(gu):
     """binary evaluation-key cache (include/cuhe_hip.h: cuhe_hip_relin_export / _import): an exported image, re-imported
     into a FRESH context of the same parameters, relinearises exactly like the context that computed the keys and
@@ -541,6 +512,10 @@ def test_evalkey_cache_roundtrip(gu):
         bad = img.copy(); bad[96 + 12345] ^= 1
         assert gu.lib.cuhe_hip_relin_import(bad.ctypes.data_as(ctypes.c_void_p), size) != 0           # damaged payload
         assert gu.lib.cuhe_hip_relin_import(img.ctypes.data_as(ctypes.c_void_p), size - 8) != 0       # truncated
+        bad = img.copy(); w = bad[96:].view(np.uint64); w[[10, 11]] = w[[11, 10]]                      # two payload words swapped
+        assert not np.array_equal(bad, img) and gu.lib.cuhe_hip_relin_import(bad.ctypes.data_as(ctypes.c_void_p), size) != 0
+        bad = img.copy(); w = bad[96:].view(np.uint64); w[5] ^= np.uint64(1 << 40); w[9] ^= np.uint64(1 << 40)   # paired bit flips
+        assert gu.lib.cuhe_hip_relin_import(bad.ctypes.data_as(ctypes.c_void_p), size) != 0
         bad = img.copy(); bad[0] = ord("X")
         assert gu.lib.cuhe_hip_relin_import(bad.ctypes.data_as(ctypes.c_void_p), size) != 0           # bad magic
         gu.ck(gu.lib.cuhe_hip_relin_import(img.ctypes.data_as(ctypes.c_void_p), size))
