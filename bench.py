@@ -45,10 +45,15 @@ def main():
     ap.add_argument("--relin-batch", type=int, default=24, help="ciphertexts per call of the batched multiply+relinearise leg")
     ap.add_argument("--relin-threads", type=int, default=4, help="host threads of the concurrent multiply+relinearise leg (4 ciphertexts per call each)")
     ap.add_argument("--mul-batch", type=int, default=16, help="operand pairs per call of the batched full-multiply leg")
+    ap.add_argument("--cyclic", action="store_true", help="ciphertext legs: keep the reference's cyclic 2n-point representation on x^n+1 rings (A/B against the negacyclic default)")
     ap.add_argument("--no-mulrelin", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--ring", choices=["2^15", "2^16"], default="2^15",
+                    help="ciphertext mul+relin leg: x^32768+1 (the reference's largest ring, 64K-point cyclic or 32K-point negacyclic "
+                         "transforms) or x^65536+1 (BASELINE config 4 read literally: 64K-point negacyclic transforms, 23-bit primes)")
     args = ap.parse_args()
+    args.relin_params = (25, 2, 16, 576, 24, 65536) if args.ring == "2^15" else (25, 2, 16, 552, 23, 131072)
 
     import numpy as np
     import torch
@@ -212,7 +217,7 @@ def main():
         mulrelin = mulfull = None
         if not args.no_mulrelin and world == 1:
             mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args)
-            mulfull = bench_mul_full(lib, ck, torch, np, dev, with_cpu=not args.no_cpu, batch=args.mul_batch)
+            mulfull = bench_mul_full(lib, ck, torch, np, dev, with_cpu=not args.no_cpu, batch=args.mul_batch, cyclic=args.cyclic)
 
         out = {
             "metric": "64K-point fwd NTT/s (u32[32768] -> u64[65536] over P=2^64-2^32+1)",
@@ -287,16 +292,18 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
             "collective": "1 all-gather of %d B per rank per multiply (RCCL)" % (sh.count * q.crtLen * 4)}
 
 
-def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16):
+def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16, cyclic=False):
     """BASELINE config 3: N = 2^15 (64K-point transforms), 32 CRT primes, full multiply of two raw polynomials
     CRT -> NTT -> pointwise -> INTT (+ reduction mod x^n+1) -> ICRT, device resident (mulZZX without the ZZX<->raw staging)."""
     from cuhe_amd import capi
     d, p, w, mn, cut, m = 9, 2, 16, 576, 24, 65536
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    ck(lib.cuhe_hip_set_negacyclic(0 if cyclic else -1))
     ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
     ck(lib.cuhe_hip_init(None, 0))
     q = capi.get_params()
-    npn, L, W, logq = q.numCrtPrime, q.nttLen, lib.cuhe_hip_words_coeff(0), lib.cuhe_hip_log_coeff(0)
+    npn, L, W, logq = q.numCrtPrime, lib.cuhe_hip_ct_len(), lib.cuhe_hip_words_coeff(0), lib.cuhe_hip_log_coeff(0)
+    rep = "negacyclic %d-point" % L if lib.cuhe_hip_ct_negacyclic() else "cyclic %d-point" % L
     gen = torch.Generator(device=dev); gen.manual_seed(9)
     ra = torch.randint(-(1 << 31), (1 << 31) - 1, (q.rawLen, W), dtype=torch.int32, device=dev, generator=gen)
     rb = torch.randint(-(1 << 31), (1 << 31) - 1, (q.rawLen, W), dtype=torch.int32, device=dev, generator=gen)
@@ -307,10 +314,10 @@ def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16):
     def one():
         ck(lib.cuhe_hip_crt(ca.data_ptr(), ra.data_ptr(), logq, 0, None))
         ck(lib.cuhe_hip_crt(cb.data_ptr(), rb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_intt_mod(ca.data_ptr(), na.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_intt(ca.data_ptr(), na.data_ptr(), logq, 1, 0, None))
         ck(lib.cuhe_hip_icrt(out.data_ptr(), ca.data_ptr(), logq, 0, None))
 
     for _ in range(3):
@@ -343,9 +350,9 @@ def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16):
         batched = {"value": round(1.0 / bdt, 1), "unit": "full multiplies/s (raw -> raw)", "ms_per_multiply": round(bdt * 1e3, 4), "batch": B}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
-    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_negacyclic(-1)
     res = {"value": round(1.0 / dt, 1), "unit": "full multiplies/s (raw -> raw)", "ms": round(dt * 1e3, 4),
-           "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "nttLen": L, "coeff_words": W},
+           "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "transform": rep, "coeff_words": W},
            "transforms_per_multiply": 3 * npn, "batched": batched}
     if with_cpu:
         # the same multiply on ONE host core through the oracle (checker + reported CPU baseline, never the product path)
@@ -365,13 +372,15 @@ def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16):
 def bench_mulrelin(lib, ck, torch, np, dev, args):
     """DHS ciphertext multiply + relinearise per second on 64K-point transforms (BASELINE config 4 shape:
     48 CRT primes < 2^24, w = 16).  NTT-domain operands -> reduced CRT-domain result, keys resident in HBM."""
-    d, p, w, mn, cut, m = 25, 2, 16, 576, 24, 65536
+    d, p, w, mn, cut, m = args.relin_params
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    ck(lib.cuhe_hip_set_negacyclic(0 if args.cyclic else -1))
     ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
     ck(lib.cuhe_hip_init(None, 0))
     from cuhe_amd import capi
     q = capi.get_params()
-    npn, L, K, W = q.numCrtPrime, q.nttLen, q.numEvalKey, lib.cuhe_hip_words_coeff(0)
+    npn, L, K, W = q.numCrtPrime, lib.cuhe_hip_ct_len(), q.numEvalKey, lib.cuhe_hip_words_coeff(0)
+    rep = "negacyclic %d-point" % L if lib.cuhe_hip_ct_negacyclic() else "cyclic %d-point" % L
     rng = np.random.default_rng(7)
     ek = rng.integers(0, 1 << 32, (K, q.rawLen, W), dtype=np.uint32)
     ek[:, :, W - 1] &= 0x7FFF                        # keep below 2^(32W-17): any value works, crt reduces
@@ -380,20 +389,20 @@ def bench_mulrelin(lib, ck, torch, np, dev, args):
     init_s = time.perf_counter() - t0
     logq = lib.cuhe_hip_log_coeff(0)
     gen = torch.Generator(device=dev); gen.manual_seed(5)
-    a = torch.randint(0, 1 << 24, (npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
-    b = torch.randint(0, 1 << 24, (npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    a = torch.randint(0, 1 << (q.logCrtPrime - 1), (npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    b = torch.randint(0, 1 << (q.logCrtPrime - 1), (npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
     na = torch.empty((npn, L), dtype=torch.int64, device=dev); nb = torch.empty_like(na); nc = torch.empty_like(na)
     cr = torch.empty((npn, q.crtLen), dtype=torch.int32, device=dev)
     raw = torch.zeros((q.rawLen, W), dtype=torch.int32, device=dev)
-    ck(lib.cuhe_hip_ntt(na.data_ptr(), a.data_ptr(), logq, 0, None))
-    ck(lib.cuhe_hip_ntt(nb.data_ptr(), b.data_ptr(), logq, 0, None))
+    ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), a.data_ptr(), logq, 0, None))
+    ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), b.data_ptr(), logq, 0, None))
 
     def one():
-        ck(lib.cuhe_hip_ntt_mul(nc.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))      # cAnd
-        ck(lib.cuhe_hip_intt_mod(cr.data_ptr(), nc.data_ptr(), logq, 0, None))                     # relin: x2r
+        ck(lib.cuhe_hip_ct_mul(nc.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))       # cAnd
+        ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), nc.data_ptr(), logq, 1, 0, None))                   # relin: x2r
         ck(lib.cuhe_hip_icrt(raw.data_ptr(), cr.data_ptr(), logq, 0, None))
         ck(lib.cuhe_hip_relinearization(nc.data_ptr(), raw.data_ptr(), 0, 0, None))
-        ck(lib.cuhe_hip_intt_mod(cr.data_ptr(), nc.data_ptr(), logq, 0, None))                     # n2c
+        ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), nc.data_ptr(), logq, 1, 0, None))                   # n2c
 
     for _ in range(3):
         one()
@@ -461,9 +470,9 @@ def bench_mulrelin(lib, ck, torch, np, dev, args):
                       "note": "T host threads, one stream each, batched calls of 4 ciphertexts"}
     except Exception as ex:
         concurrent = {"error": repr(ex)[:300]}
-    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_negacyclic(-1)
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s", "ms": round(dt * 1e3, 3),
-            "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "numEvalKey": K, "nttLen": L},
+            "params": {"setParameters": [d, p, w, mn, cut, m], "ring_degree": q.modLen, "numCrtPrime": npn, "numEvalKey": K, "transform": rep},
             "algorithmic_bytes": key_bytes, "achieved_GBs": round(key_bytes / dt / 1e9, 1),
             "frac_hbm": round(key_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "key_upload_s": round(init_s, 2),
             "batched": batched, "concurrent": concurrent}

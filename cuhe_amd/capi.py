@@ -83,6 +83,15 @@ SIGNATURES = {
     "cuhe_hip_ntt_add_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_barrett": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_barrett_hold": (i32, [vp, i32, i32, vp]),
+    "cuhe_hip_set_negacyclic": (i32, [i32]),
+    "cuhe_hip_ct_negacyclic": (i32, []),
+    "cuhe_hip_ct_len": (i32, []),
+    "cuhe_hip_ct_ntt": (i32, [vp, vp, i32, i32, vp]),
+    "cuhe_hip_ct_intt": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_ct_mul": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_ct_mul_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_ct_add": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_ct_add_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_ntt_one": (i32, [vp, vp, i32, vp]),
     "cuhe_hip_nttw_one": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_intt_one": (i32, [vp, vp, i32, i32, vp]),

@@ -48,6 +48,7 @@ int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------ state
 struct NttTab {
     u64 *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of pass 1; T2 / T2inv: outer twiddles (x L^-1)
+    u64 *tw = nullptr, *twinv = nullptr;                    // negacyclic twist psi^j and psi^-j, psi^2 = w_L (ensure_twist)
     int chunk = 0;                             // transforms per launch pair (slab size / transform size)
 };
 // Mutable scratch of ONE host thread on one device.  The reference keeps a single set per device and is therefore
@@ -110,6 +111,8 @@ struct Global {
     std::vector<BigU> coeffModulus;
     std::vector<int32_t> modulus;
     int reduce_kind = 0;                 // 0 generic, 1 x^n+1, 2 prime m
+    int nc_mode = -1;                    // -1: negacyclic ciphertext domain wherever it applies (default), 0: never (tests)
+    bool nc = false;                     // ciphertext-domain transforms are NEGACYCLIC of length modLen (decided by init)
     bool force_generic = false;
     bool no_fold = false;          // tests: take the five-transform form of the generic reduction
     bool allocator_on = false;
@@ -310,6 +313,23 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     return CUHE_OK;
 }
 
+// twist tables of the negacyclic transform of length `len` (psi^j, psi^-j; psi^2 = w_len)
+int ensure_twist(int dev, int len) {
+    CHK(ensure_ntt(dev, len, 1));
+    std::lock_guard<std::mutex> lk(G_.mu);
+    NttTab &tab = G_.dev[dev].ntt[lg_index(len)];
+    if (tab.tw) return CUHE_OK;
+    const u64 psi = host::root_2len(len);
+    if (!psi) return fail(CUHE_EINVAL, "no primitive %d-th root of unity found", 2 * len);
+    const u64 ipsi = host::powP(psi, host::P - 2);
+    std::vector<u64> tw(len), twi(len);
+    u64 a = 1, b = 1;
+    for (int j = 0; j < len; ++j) { tw[j] = a; twi[j] = b; a = host::mulP(a, psi); b = host::mulP(b, ipsi); }
+    CHK(upload(&tab.tw, tw));
+    CHK(upload(&tab.twinv, twi));
+    return CUHE_OK;
+}
+
 // hipFuncSetAttribute once per (kernel instantiation, device); host threads may race to be first
 struct AttrOnce {
     std::mutex mu; bool done[64] = {false};
@@ -331,7 +351,8 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stri
     auto kern = ntt_pass1w<LG, MODE>;
     CHK(once.set(kern, (int)Gw::bytes));
     const int grid = ((nb + 7) / 8) * 8 * (64 / Gw::NC);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa);
+    if (MODE == kSrcU32Twist && !tab.tw) return fail(CUHE_EINVAL, "negacyclic twist table missing");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa, (const u64 *)tab.tw);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -340,14 +361,15 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stri
 struct Epilogue { int kind = 0; const u32 *aux = nullptr; long aux_stride = 0; FoldGeom fg{0, 0, 0, 0, 0}; };
 template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
-                 const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0, const Epilogue *ep = nullptr) {
+                 const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0, const Epilogue *ep = nullptr, const u64 *xtab = nullptr) {
     constexpr int N1 = (1 << LG) / 64;
+    if ((OUT == kOutU64Mul || OUT == kOutModPNc) && !xtab) return fail(CUHE_EINVAL, "pass 2: table missing");
     const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
     const Epilogue none;
     const Epilogue &e = ep ? *ep : none;
     hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
                        out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
-                       e.aux, e.aux_stride, e.fg);
+                       e.aux, e.aux_stride, e.fg, xtab);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -358,6 +380,7 @@ int icrt_lds_attr(size_t lds) {                 // k_icrt needs the large-LDS at
 }
 
 constexpr int kFoldXn1 = -1;     // nstore sentinel: inverse transform fused with the reduction mod x^(L/2)+1
+constexpr int kNcInverse = -2;   // nstore sentinel: inverse NEGACYCLIC transform (untwist, centred lift, mod p), all L outputs
 
 struct EvTimer {                 // optional per-pass hipEvent timing (bench)
     std::vector<hipEvent_t> ev;
@@ -395,6 +418,9 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         if (mode == kSrcU32Ext) {
             const u32 *s = (const u32 *)src + (long)b0 * src_stride;
             CHK((launch_pass1<LG, kSrcU32Ext>(s, slab, tab, src_stride, nb, wa, q1)));
+        } else if (mode == kSrcU32Twist) {
+            const u32 *s = (const u32 *)src + (long)b0 * src_stride;
+            CHK((launch_pass1<LG, kSrcU32Twist>(s, slab, tab, src_stride, nb, wa, q1)));
         } else if (mode == kSrcWindow) {
             WindowArgs w2 = wa; w2.wid0 += b0;
             CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, 0, nb, w2, q1)));
@@ -411,11 +437,12 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 if (e.aux) e.aux += (long)b0 * e.aux_stride;
                 if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod, &e)));
                 else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod, &e)));
-            } else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, np_mod)));
+            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, np_mod, nullptr, tab.twinv)));
+            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, np_mod)));
             else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, mul_tab, prime0 + b0, q2, np_mod)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, np_mod, nullptr, mul_tab)));
             else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
@@ -465,7 +492,7 @@ PrimeTab prime_tab_at(const DevCtx &D, int prime0) {
 
 // reduction modulo the polynomial modulus of rows belonging to primes [prime0, prime0+np)
 // np_mod > 0: `np` rows = several ciphertexts of the same np_mod primes (prime0 must be 0)
-int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStream_t st, int np_mod = 0) {
+int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStream_t st, int np_mod) {
     const Params &q = G_.prm;
     DevCtx &D = G_.dev[dev];
     const int n = q.modLen, L = q.nttLen, cl = q.crtLen;
@@ -535,6 +562,43 @@ int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStrea
     return CUHE_OK;
 }
 
+// ------------------------------------------------------------------ ciphertext-domain ("ct") transforms
+// The NTT representation ciphertext operations work in.  On general rings it is the reference's: cyclic transforms of
+// nttLen = 2 modLen2 points of the zero-padded residues, products reduced modulo Phi_m afterwards (Operations.cu:394-504).
+// When the polynomial modulus is x^n + 1 with n a transform length (16384 / 32768 / 65536) and the primes obey
+// 2 n p^2 < P, it is the NEGACYCLIC transform of n points: half the points per polynomial, half the bytes per
+// evaluation key, and products are already reduced modulo x^n + 1.  Results in the CRT / raw domain are identical.
+inline int ct_len() { return G_.nc ? G_.prm.modLen : G_.prm.nttLen; }
+int need_cyclic() {
+    if (G_.prm.ncOnly()) return fail(CUHE_EINVAL, "ring degree %d has only the negacyclic representation (cuhe_hip_ct_*): the cyclic transforms of the reference stop at 65536 points", G_.prm.modLen);
+    return CUHE_OK;
+}
+// CRT rows u32[rows][crtLen] -> ct rows u64[rows][ct_len]; mul_tab: rows the outputs are multiplied by on the way out
+int ct_forward(u64 *X, const u32 *x, int rows, int dev, hipStream_t st, const u64 *mul_tab = nullptr, int np_mod = 0) {
+    const Params &q = G_.prm;
+    if (G_.nc) return run_ntt(q.modLen, kSrcU32Twist, X, x, rows, q.crtLen, q.modLen, q.modLen, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, mul_tab, np_mod);
+    return run_ntt(q.nttLen, kSrcU32Ext, X, x, rows, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, mul_tab, np_mod);
+}
+// Phi_m = x^n + 1 with n = L/2 on the cyclic representation: INTT, mod p_i and the reduction in one pass-2 epilogue
+bool fused_xn1() {
+    return !G_.force_generic && G_.reduce_kind == 1 && G_.prm.modLen * 2 == G_.prm.nttLen && G_.prm.crtLen == G_.prm.modLen;
+}
+// ct rows -> CRT rows u32[rows][crtLen]; row r is reduced modulo prime prime0 + r (row r mod np_mod when np_mod > 0, prime0
+// = 0 then); is_prod: the rows are products of two reduced polynomials (cyclic representation: reduce modulo Phi_m)
+int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st) {
+    const Params &q = G_.prm;
+    const int n = q.modLen, L = q.nttLen, cl = q.crtLen;
+    const WindowArgs wa{0, 0, 0};
+    if (G_.nc) return run_ntt(n, kSrcU64Neg, dst, X, rows, n, cl, kNcInverse, prime0, wa, dev, st, nullptr, nullptr, np_mod);
+    if (!is_prod) return run_ntt(L, kSrcU64Neg, dst, X, rows, L, cl, cl, prime0, wa, dev, st, nullptr, nullptr, np_mod);
+    if (fused_xn1()) return run_ntt(L, kSrcU64Neg, dst, X, rows, L, cl, kFoldXn1, prime0, wa, dev, st, nullptr, nullptr, np_mod);
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, st, &Wp));
+    CHK(ws_barrett(*Wp, rows));
+    CHK(run_ntt(L, kSrcU64Neg, Wp->hold, X, rows, L, L, L, prime0, wa, dev, st, nullptr, nullptr, np_mod));
+    return barrett_impl(dst, Wp->hold, prime0, rows, dev, st, np_mod);
+}
+
 int init_device(int dev) {
     CHK(set_dev(dev));
     DevCtx &D = G_.dev[dev];
@@ -576,6 +640,12 @@ int init_device(int dev) {
     }
     // ---- transforms + scratch (initNtt: cuhe/Operations.cu:173-184)
     CHK(ensure_ntt(dev, L, pnum));
+    if (G_.nc) CHK(ensure_twist(dev, n));
+    if (q.ncOnly()) {                    // no cyclic representation, hence no Barrett tables (the ring has x^n + 1 only)
+        HIPCHK(hipDeviceSynchronize());
+        D.ready = true;
+        return CUHE_OK;
+    }
     // ---- Barrett (initBarrett: cuhe/Operations.cu:196-238)
     HIPCHK(hipMalloc((void **)&D.u_ntt, (size_t)pnum * L * sizeof(u64)));
     HIPCHK(hipMalloc((void **)&D.m_ntt, (size_t)pnum * L * sizeof(u64)));
@@ -667,7 +737,7 @@ int cuhe_hip_set_parameters(int d, int p, int w, int min, int cut, int m) {
         return fail(CUHE_EINVAL, "setParameters(%d,%d,%d,%d,%d,%d): invalid", d, p, w, min, cut, m);
     G_.prm.set(d, p, w, min, cut, m);
     if (lg_index(G_.prm.nttLen) < 0)
-        return fail(CUHE_EINVAL, "ring degree %d needs nttLen %d (supported: 16384/32768/65536)", G_.prm.modLen, G_.prm.nttLen);
+        return fail(CUHE_EINVAL, "ring degree %d needs nttLen %d (supported: 16384/32768/65536; degree 65536 only as m = 131072, x^65536 + 1)", G_.prm.modLen, G_.prm.nttLen);
     if (G_.prm.numCrtPrime > 103 * 4) return fail(CUHE_EINVAL, "too many CRT primes (%d)", G_.prm.numCrtPrime);
     G_.params_set = true;
     return CUHE_OK;
@@ -732,6 +802,20 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
         G_.reduce_kind = xn1 ? 1 : (ones ? 2 : 0);
     }
     G_.primes = host::gen_crt_primes(q);                           // cuhe/Operations.cu:37-80
+    // negacyclic ciphertext domain: modulus x^n + 1, n a transform length, and the centred lift must be unambiguous:
+    // a product coefficient is a signed sum of n terms below p^2 (2 n p^2 < P), a key-switch sum one of k n terms below 2^w p
+    {
+        const int n = q.modLen;
+        host::u128 pmax = 0;
+        for (uint32_t p : G_.primes) pmax = std::max<host::u128>(pmax, p);
+        const bool shape = G_.reduce_kind == 1 && lg_index(n) >= 0 && q.crtLen == n;
+        const bool bound = 2 * (host::u128)n * (pmax - 1) * (pmax - 1) < host::P &&
+                           (!q.logRelin || 2 * (host::u128)q.numEvalKey * n * (((host::u128)1 << q.logRelin) - 1) * (pmax - 1) < host::P);
+        G_.nc = G_.nc_mode != 0 && shape && bound;
+        if (q.ncOnly() && !G_.nc)
+            return fail(CUHE_EINVAL, "ring degree %d needs the negacyclic representation: modulus x^n + 1, primes with 2 n p^2 < P%s", n,
+                        G_.nc_mode == 0 ? " (and cuhe_hip_set_negacyclic(0) is in effect)" : "");
+    }
     G_.coeffModulus.assign(q.depth, BigU(1));                      // cuhe/Operations.cu:81-90
     for (int i = 0; i < q.depth; ++i)
         for (int j = 0; j < q.numCrtPrime - i; ++j) G_.coeffModulus[i].mul_small(G_.primes[j]);
@@ -757,7 +841,7 @@ int cuhe_hip_shutdown(void) {
         if (hipSetDevice(phys_dev(d)) != hipSuccess) { (void)hipGetLastError(); continue; }
         (void)hipDeviceSynchronize();
         DevCtx &D = G_.dev[d];
-        for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); t = NttTab(); }
+        for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek};
         for (Workspace *w : D.spaces) free_workspace(w);
@@ -1012,12 +1096,14 @@ int cuhe_hip_crt_mod_switch(uint32_t *dst, const uint32_t *src, int logq, int de
 
 int cuhe_hip_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
     return run_ntt(q.nttLen, kSrcU32Ext, X, x, np, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
 }
 int cuhe_hip_nttw(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
     if (!q.logRelin) return fail(CUHE_EINVAL, "logRelin = 0");
@@ -1026,12 +1112,14 @@ int cuhe_hip_nttw(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
 }
 int cuhe_hip_intt(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
     return run_ntt(q.nttLen, kSrcU64Neg, x, X, np, q.nttLen, q.crtLen, q.crtLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
 }
 int cuhe_hip_intt_hold(const uint64_t *X, int logq, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
     Workspace *Wp = nullptr;
@@ -1042,14 +1130,16 @@ int cuhe_hip_intt_hold(const uint64_t *X, int logq, int dev, void *st) {
 }
 int cuhe_hip_intt_double_deg(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
     return run_ntt(q.nttLen, kSrcU64Neg, x, X, np, q.nttLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
 }
 int cuhe_hip_barrett(uint32_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
-    return barrett_impl(dst, src, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st));
+    return barrett_impl(dst, src, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st), 0);
 }
 int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *st) {
     CHK(need_init(dev));
@@ -1058,10 +1148,8 @@ int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *st) {
     CHK(ws_barrett(*Wp));
     return cuhe_hip_barrett(dst, Wp->hold, lvl, dev, st);
 }
-static bool fused_xn1() {
-    return !G_.force_generic && G_.reduce_kind == 1 && G_.prm.modLen * 2 == G_.prm.nttLen && G_.prm.crtLen == G_.prm.modLen;
-}
 int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *st) {
+    CHK(need_cyclic());
     if (fused_xn1()) {          // Phi_m = x^n + 1 with n = L/2: INTT, mod p_i and the reduction in one pass-2 epilogue
         CHK(need_init(dev));
         int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
@@ -1074,7 +1162,7 @@ int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *s
     if (lvl < 0) return fail(CUHE_EINVAL, "inttMod below level 0");
     Workspace *Wp = nullptr;
     CHK(workspace(dev, S(st), &Wp));
-    return barrett_impl(x, Wp->hold, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st));
+    return barrett_impl(x, Wp->hold, 0, G_.prm.numCrtPrimeAt(lvl), dev, S(st), 0);
 }
 uint32_t *cuhe_hip_intt_result(int dev) {
     if (!G_.inited || dev < 0 || dev >= (int)G_.dev.size() || set_dev(dev) != CUHE_OK) return nullptr;
@@ -1083,10 +1171,10 @@ uint32_t *cuhe_hip_intt_result(int dev) {
     return Wp->hold;
 }
 
-static int binop(bool mul, bool nx1, uint64_t *z, const uint64_t *x, const uint64_t *y, int logq, int dev, void *st) {
+static int binop(bool mul, bool nx1, uint64_t *z, const uint64_t *x, const uint64_t *y, int logq, int dev, void *st, bool ct = false) {
     CHK(need_init(dev));
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
-    const int L = G_.prm.nttLen;
+    const int L = ct ? ct_len() : G_.prm.nttLen;
     if (!nx1) {
         const long pairs = (long)np * L / 2;
         const int grid = (int)std::min<long>((pairs + 255) / 256, 8192);
@@ -1105,19 +1193,47 @@ int cuhe_hip_ntt_mul_nx1(uint64_t *z, const uint64_t *x, const uint64_t *s, int 
 int cuhe_hip_ntt_add(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *st) { return binop(false, false, z, y, x, logq, dev, st); }
 int cuhe_hip_ntt_add_nx1(uint64_t *z, const uint64_t *x, const uint64_t *s, int logq, int dev, void *st) { return binop(false, true, z, x, s, logq, dev, st); }
 
+// ---------------------------------------------------------------- ciphertext-domain (ct) drivers: what CuCtxt runs on
+int cuhe_hip_set_negacyclic(int mode) {
+    if (G_.inited) return fail(CUHE_EINVAL, "set_negacyclic must precede init");
+    if (mode != 0 && mode != -1) return fail(CUHE_EINVAL, "negacyclic mode %d (-1 = where it applies, 0 = never)", mode);
+    G_.nc_mode = mode;
+    return CUHE_OK;
+}
+int cuhe_hip_ct_negacyclic(void) { return G_.inited && G_.nc ? 1 : 0; }
+int cuhe_hip_ct_len(void) { return G_.params_set ? (G_.inited ? ct_len() : G_.prm.nttLen) : 0; }
+int cuhe_hip_ct_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    return ct_forward((u64 *)X, x, np, dev, S(st));
+}
+int cuhe_hip_ct_intt(uint32_t *x, const uint64_t *X, int logq, int is_prod, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (is_prod && lvl < 0) return fail(CUHE_EINVAL, "product below level 0");
+    return ct_inverse(x, (const u64 *)X, np, 0, 0, is_prod != 0, dev, S(st));
+}
+int cuhe_hip_ct_mul(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *st) { return binop(true, false, z, y, x, logq, dev, st, true); }
+int cuhe_hip_ct_mul_nx1(uint64_t *z, const uint64_t *x, const uint64_t *s, int logq, int dev, void *st) { return binop(true, true, z, x, s, logq, dev, st, true); }
+int cuhe_hip_ct_add(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *st) { return binop(false, false, z, y, x, logq, dev, st, true); }
+int cuhe_hip_ct_add_nx1(uint64_t *z, const uint64_t *x, const uint64_t *s, int logq, int dev, void *st) { return binop(false, true, z, x, s, logq, dev, st, true); }
+
 int cuhe_hip_ntt_one(uint64_t *X, const uint32_t *x, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     const Params &q = G_.prm;
     return run_ntt(q.nttLen, kSrcU32Ext, X, x, 1, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
 }
 int cuhe_hip_nttw_one(uint64_t *X, const uint32_t *x, int coeffwords, int relinIdx, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     const Params &q = G_.prm;
     return run_ntt(q.nttLen, kSrcWindow, X, x, 1, 0, q.nttLen, q.nttLen, 0, WindowArgs{coeffwords, q.logRelin, relinIdx},
                    dev, S(st));
 }
 int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void *st) {
     CHK(need_init(dev));
+    CHK(need_cyclic());
     const Params &q = G_.prm;
     if (crtidx < 0 || crtidx >= q.numCrtPrime) return fail(CUHE_EINVAL, "crtidx %d", crtidx);
     return run_ntt(q.nttLen, kSrcU64Neg, x, X, 1, q.nttLen, q.nttLen, q.nttLen, crtidx, WindowArgs{0, 0, 0}, dev, S(st));
@@ -1127,7 +1243,7 @@ int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void 
 int cuhe_hip_init_relin(const uint32_t *ek_host) {
     if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
     const Params &q = G_.prm;
-    const int K = q.numEvalKey, np = q.numCrtPrime, L = q.nttLen, W0 = q.wordsCoeff(0);
+    const int K = q.numEvalKey, np = q.numCrtPrime, L = ct_len(), W0 = q.wordsCoeff(0);     // keys live in the ct domain
     if (K <= 0) return fail(CUHE_EINVAL, "numEvalKey = 0");
     const size_t rawBytes = (size_t)q.rawLen * W0 * 4;
     for (int dev = 0; dev < G_.ndev; ++dev) {
@@ -1143,7 +1259,7 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
             HIPCHK(hipMemcpy(raw, ek_host + (size_t)j * q.rawLen * W0, rawBytes, hipMemcpyHostToDevice));
             HIPCHK(hipMemsetAsync(crt, 0, (size_t)np * q.crtLen * 4, 0));
             CHK(cuhe_hip_crt(crt, raw, q.logCoeff(0), dev, nullptr));
-            CHK(cuhe_hip_ntt((uint64_t *)ntt, crt, q.logCoeff(0), dev, nullptr));
+            CHK(ct_forward(ntt, crt, np, dev, nullptr));
             // ek[prime i][key j][L]
             HIPCHK(hipMemcpy2DAsync(D.ek + (size_t)j * L, (size_t)K * L * 8, ntt, (size_t)L * 8, (size_t)L * 8, np,
                                     hipMemcpyDeviceToDevice, 0));
@@ -1198,10 +1314,10 @@ static EkHeader ek_header_now() {
     memcpy(h.magic, kEkMagic, 8); h.version = 2;
     const int set[6] = {q.depth, q.modMsg, q.logRelin, q.logCoeffMin, q.logCoeffCut, q.mSize};
     memcpy(h.set, set, sizeof set);
-    h.np = q.numCrtPrime; h.k = q.numEvalKey; h.L = q.nttLen;
+    h.np = q.numCrtPrime; h.k = q.numEvalKey; h.L = ct_len(); h.key_rep = G_.nc ? 1 : 0;
     h.primes_fnv = fnv1a(G_.primes.data(), G_.primes.size() * sizeof(uint32_t));
     h.modulus_fnv = fnv1a(G_.modulus.data(), G_.modulus.size() * sizeof(int32_t));
-    h.payload_bytes = (uint64_t)q.numCrtPrime * q.numEvalKey * q.nttLen * sizeof(u64);
+    h.payload_bytes = (uint64_t)q.numCrtPrime * q.numEvalKey * ct_len() * sizeof(u64);
     return h;
 }
 size_t cuhe_hip_relin_cache_size(void) {
@@ -1249,7 +1365,7 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
     const Params &q = G_.prm;
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
-    const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = q.nttLen;
+    const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = ct_len();
     if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d) at level %d", prime0, prime0 + count, lvl);
     DevCtx &D = G_.dev[dev];
     Workspace *Wp = nullptr;
@@ -1260,7 +1376,7 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     hipLaunchKernelGGL(k_extract_windows, dim3((q.crtLen + kWinCoef - 1) / kWinCoef), dim3(kWinCoef * kWinGroups),
                        (size_t)W * kWinCoef * 4, S(st), Wp->win, src, W, q.logRelin, k, q.crtLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
-    CHK(run_ntt(L, kSrcU32Ext, Wp->relin, Wp->win, k, q.crtLen, L, L, 0, WindowArgs{0, 0, 0}, dev, S(st)));
+    CHK(ct_forward(Wp->relin, Wp->win, k, dev, S(st)));
     constexpr int PB = 4;
     hipLaunchKernelGGL((k_relin_mac<PB, 1>), dim3((L / 512) * ((count + PB - 1) / PB), 1, 1), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
                        D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
@@ -1288,7 +1404,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
     hipStream_t st = S(st_);
     DevCtx &D = G_.dev[dev];
-    const int np = q.numCrtPrimeAt(lvl), k = q.numEvalKeyAt(lvl), W = q.wordsCoeff(lvl), L = q.nttLen, cl = q.crtLen;
+    const int np = q.numCrtPrimeAt(lvl), k = q.numEvalKeyAt(lvl), W = q.wordsCoeff(lvl), L = ct_len(), cl = q.crtLen;
     const int rows = batch * np;
     Workspace *Wp = nullptr;
     CHK(workspace(dev, st, &Wp));
@@ -1304,14 +1420,8 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
         Ws.n_bt = batch;
     }
     CHK(ws_relin(Ws, batch));
-    const bool fused = fused_xn1();
-    if (!fused) CHK(ws_barrett(Ws, rows));
-    // reduction of `rows` NTT-domain product rows to CRT rows (n2c with isProd, CuHE.cu:398-408)
-    auto reduce_rows = [&](u32 *out, const u64 *in) -> int {
-        if (fused) return run_ntt(L, kSrcU64Neg, out, in, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np);
-        CHK(run_ntt(L, kSrcU64Neg, Ws.hold, in, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
-        return barrett_impl(out, Ws.hold, 0, rows, dev, st, np);
-    };
+    // reduction of `rows` ct-domain product rows to CRT rows (n2c with isProd, CuHE.cu:398-408)
+    auto reduce_rows = [&](u32 *out, const u64 *in) -> int { return ct_inverse(out, in, rows, 0, np, true, dev, st); };
     const u32 *crt_rows = crt_in;
     if (!crt_in) {
         // 1. pointwise products
@@ -1336,7 +1446,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     hipLaunchKernelGGL(k_extract_windows, dim3((cl + kWinCoef - 1) / kWinCoef, batch), dim3(kWinCoef * kWinGroups), (size_t)W * kWinCoef * 4, st,
                        Ws.win, Ws.bt_raw, W, q.logRelin, k, cl, cl, (long)q.rawLen * W, (long)k * cl);
     HIPCHK(hipGetLastError());
-    CHK(run_ntt(L, kSrcU32Ext, Ws.relin, Ws.win, batch * k, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));
+    CHK(ct_forward(Ws.relin, Ws.win, batch * k, dev, st));
     // 4. key-switch inner products: a key value fetched once serves four ciphertexts
     // window tiles of 4 ciphertexts resident in LDS, every key value fetched once per 4 ciphertexts (k_relin_mac_lds);
     // PB (primes per thread and pass) is the one of 2, 3, 4 that wastes the fewest of the 8 x PB prime slots per pass.
@@ -1389,10 +1499,10 @@ static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b,
     const int groups = (batch + GB - 1) / GB, lanes = std::min(g_relin_lanes, groups);
     const Params &q = G_.prm;
     if (lanes <= 1 || !G_.inited || lvl < 0 || lvl >= q.depth ||
-        (!g_relin_lanes_any_size && (size_t)q.numEvalKeyAt(lvl) * q.numCrtPrimeAt(lvl) * q.nttLen * sizeof(u64) < ((size_t)1 << 30)))
+        (!g_relin_lanes_any_size && (size_t)q.numEvalKeyAt(lvl) * q.numCrtPrimeAt(lvl) * ct_len() * sizeof(u64) < ((size_t)1 << 30)))
         return relin_batch_run(dst, a, b, crt_in, lvl, batch, dev, st_);
     CHK(need_init(dev));
-    const size_t np = q.numCrtPrimeAt(lvl), L = q.nttLen, cl = q.crtLen;
+    const size_t np = q.numCrtPrimeAt(lvl), L = ct_len(), cl = q.crtLen;
     hipStream_t st = S(st_);
     Workspace *W0 = nullptr, *LW[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     CHK(workspace(dev, st, &W0));
@@ -1445,13 +1555,8 @@ int cuhe_hip_intt_mod_batch(uint32_t *dst, const uint64_t *src, int lvl, int bat
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
     hipStream_t st = S(st_);
-    const int np = q.numCrtPrimeAt(lvl), L = q.nttLen, cl = q.crtLen, rows = batch * np;
-    if (fused_xn1()) return run_ntt(L, kSrcU64Neg, dst, src, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np);
-    Workspace *Wp = nullptr;
-    CHK(workspace(dev, st, &Wp));
-    CHK(ws_barrett(*Wp, rows));
-    CHK(run_ntt(L, kSrcU64Neg, Wp->hold, src, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
-    return barrett_impl(dst, Wp->hold, 0, rows, dev, st, np);
+    const int np = q.numCrtPrimeAt(lvl);
+    return ct_inverse(dst, (const u64 *)src, batch * np, 0, np, true, dev, st);
 }
 // modSwitch of `batch` ciphertexts of level lvl: src u32[batch][np][crtLen] -> dst u32[batch][np-1][crtLen] (packed)
 int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *st) {
@@ -1472,7 +1577,7 @@ int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, i
 int cuhe_hip_ntt_mul_pairs(uint64_t *dst, const uint64_t *src, const int32_t *idx_a, const int32_t *idx_b, int npairs, int np_rows, int dev, void *st) {
     CHK(need_init(dev));
     if (npairs < 1 || np_rows < 1) return fail(CUHE_EINVAL, "npairs %d rows %d", npairs, np_rows);
-    const long ct_pairs = (long)np_rows * G_.prm.nttLen / 2;
+    const long ct_pairs = (long)np_rows * ct_len() / 2;
     const int gx = (int)std::min<long>((ct_pairs + 255) / 256, 1024);
     hipLaunchKernelGGL(k_ntt_mul_pairs, dim3(gx, npairs), dim3(256), 0, S(st), (u64 *)dst, (const u64 *)src, idx_a, idx_b, ct_pairs);
     HIPCHK(hipGetLastError());
@@ -1506,7 +1611,7 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
     hipStream_t st = S(st_);
     DevCtx &D = G_.dev[dev];
-    const int np = q.numCrtPrimeAt(lvl), W = q.wordsCoeff(lvl), L = q.nttLen, cl = q.crtLen;
+    const int np = q.numCrtPrimeAt(lvl), W = q.wordsCoeff(lvl), L = ct_len(), cl = q.crtLen;
     if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
     const int rows = batch * np;
     Workspace *Wp = nullptr;
@@ -1521,8 +1626,6 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
         CHK(ws_grow(&Ws.mr_crt, &y, (size_t)2 * batch * q.numCrtPrime * cl));
         Ws.n_mr = batch;
     }
-    const bool fused = fused_xn1();
-    if (!fused) CHK(ws_barrett(Ws, rows));
     u32 *ca = Ws.mr_crt, *cb = Ws.mr_crt + (size_t)rows * cl;
     u64 *na = Ws.mr_ntt;
     if (q.modLen < cl) HIPCHK(hipMemsetAsync(Ws.mr_crt, 0, (size_t)2 * rows * cl * sizeof(u32), st));
@@ -1534,13 +1637,9 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     // transforms of the a operands, then those of the b operands with the pointwise product riding on their output
     // (kOutU64Mul with the a transforms as the table: row r of b times row r of a) -- no separate product pass
     u64 *nb = na + (size_t)rows * L;
-    CHK(run_ntt(L, kSrcU32Ext, nb, cb, rows, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st));
-    CHK(run_ntt(L, kSrcU32Ext, na, ca, rows, cl, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nb));
-    if (fused) CHK(run_ntt(L, kSrcU64Neg, ca, na, rows, L, cl, kFoldXn1, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
-    else {
-        CHK(run_ntt(L, kSrcU64Neg, Ws.hold, na, rows, L, L, L, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, nullptr, np));
-        CHK(barrett_impl(ca, Ws.hold, 0, rows, dev, st, np));
-    }
+    CHK(ct_forward(nb, cb, rows, dev, st));
+    CHK(ct_forward(na, ca, rows, dev, st, nb));
+    CHK(ct_inverse(ca, na, rows, 0, np, true, dev, st));
     if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(dst, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
     const IcrtLevel &I = D.icrt[lvl];
     IcrtTab it{I.M, I.mi, I.bi, I.rp};
@@ -1558,12 +1657,11 @@ int cuhe_hip_relin_range(uint64_t *dst, const uint32_t *raw, int lvl, int prime0
 }
 int cuhe_hip_ntt_rows(uint64_t *X, const uint32_t *x, int count, int dev, void *st) {
     CHK(need_init(dev));
-    const Params &q = G_.prm;
-    return run_ntt(q.nttLen, kSrcU32Ext, X, x, count, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, S(st));
+    return ct_forward((u64 *)X, x, count, dev, S(st));
 }
 int cuhe_hip_ntt_mul_rows(uint64_t *z, const uint64_t *y, const uint64_t *x, int count, int dev, void *st) {
     CHK(need_init(dev));
-    const long pairs = (long)count * G_.prm.nttLen / 2;
+    const long pairs = (long)count * ct_len() / 2;
     const int grid = (int)std::min<long>((pairs + 255) / 256, 8192);
     hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, S(st), (u64 *)z, (const u64 *)y, (const u64 *)x, pairs);
     HIPCHK(hipGetLastError());
@@ -1574,14 +1672,7 @@ int cuhe_hip_intt_mod_range(uint32_t *x, const uint64_t *X, int lvl, int prime0,
     const Params &q = G_.prm;
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     if (prime0 < 0 || count < 1 || prime0 + count > q.numCrtPrimeAt(lvl)) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
-    DevCtx &D = G_.dev[dev];
-    if (fused_xn1())
-        return run_ntt(q.nttLen, kSrcU64Neg, x, X, count, q.nttLen, q.crtLen, kFoldXn1, prime0, WindowArgs{0, 0, 0}, dev, S(st));
-    Workspace *Wp = nullptr;
-    CHK(workspace(dev, S(st), &Wp));
-    CHK(ws_barrett(*Wp));
-    CHK(run_ntt(q.nttLen, kSrcU64Neg, Wp->hold, X, count, q.nttLen, q.nttLen, q.nttLen, prime0, WindowArgs{0, 0, 0}, dev, S(st)));
-    return barrett_impl(x, Wp->hold, prime0, count, dev, S(st));
+    return ct_inverse(x, (const u64 *)X, count, prime0, 0, true, dev, S(st));
 }
 int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0, int count, int dev, void *st) {
     CHK(need_init(dev));

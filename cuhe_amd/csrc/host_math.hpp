@@ -22,6 +22,31 @@ inline uint64_t powP(uint64_t x, uint64_t e) {
     return r;
 }
 
+// psi with psi^2 = w_len = G^(65536/len): a primitive 2*len-th root of unity, the twist of the negacyclic transform of
+// length len <= 65536.  For len < 65536 it is a power of G.  For len = 65536 it is a square root of G, a primitive
+// 2^17-th root (2^32 divides P - 1): with z a generator of the 2-Sylow subgroup of Z_P^* (order
+// 2^32) G = z^e for an e divisible by 2^16, found bit by bit (Pohlig-Hellman), and psi = z^(e/2).  Returns 0 on failure.
+inline uint64_t root_2len(int len) {
+    if (len < 65536) return powP(G, (uint64_t)(32768 / len));
+    uint64_t z = 0;
+    for (uint64_t base : {7ULL, 3ULL, 5ULL, 11ULL, 13ULL}) {
+        z = powP(base, (P - 1) >> 32);
+        if (powP(z, 1ULL << 31) != 1) break;          // order exactly 2^32
+        z = 0;
+    }
+    if (!z) return 0;
+    const uint64_t zinv = powP(z, P - 2);
+    uint64_t e = 0;
+    for (int i = 0; i < 32; ++i) {
+        uint64_t t = mulP(G, powP(zinv, e));          // order divides 2^(32-i)
+        t = powP(t, 1ULL << (31 - i));
+        if (t != 1) e |= 1ULL << i;
+    }
+    if (e & 1) return 0;
+    const uint64_t psi = powP(z, e >> 1);
+    return mulP(psi, psi) == G ? psi : 0;
+}
+
 inline int numbits(uint64_t x) { int n = 0; while (x) { ++n; x >>= 1; } return n; }
 inline uint64_t isqrt(uint64_t x) {
     uint64_t r = 0, bit = 1ULL << 62;
@@ -114,11 +139,19 @@ struct Params {                                   // cuhe/Parameters.h:34-62
         wordsMsg = (logMsg + 31) / 32;
         numEvalKey = w ? (logCoeffMax + w - 1) / w : 0;
         logCrtPrime = numbits(isqrt(P / (uint64_t)modLen));
+        if (ncOnly()) {
+            // ring degree 2^16 (m = 2^17): beyond the reference, whose transforms stop at 65536 points = degree 2^15
+            // (cuhe/Parameters.cu:63-68, Base.cu:59-62).  Only the negacyclic representation exists: transforms of
+            // modLen points, and the primes obey the centred-lift bound 2 n p^2 < P, i.e. at most 23 bits.
+            nttLen = modLen2;
+            logCrtPrime = numbits(isqrt(P / (2 * (uint64_t)modLen))) - 1;
+        }
         numCrtPrime = (min + logCrtPrime - 1) / logCrtPrime;
         logCrtPrime = 0;
         while (logCrtPrime * numCrtPrime < min) ++logCrtPrime;
         numCrtPrime += d - 1;
     }
+    bool ncOnly() const { return mSize == 131072; }
     int numCrtPrimeAt(int lvl) const { return lvl == -1 ? 1 : numCrtPrime - lvl; }        // :107-116
     int logCoeff(int lvl) const {                                                          // :117-128
         if (lvl == -1) return logMsg;

@@ -25,7 +25,11 @@
 
 namespace cuhe {
 
-enum : int { kSrcU32Ext = 0, kSrcWindow = 1, kSrcU64Neg = 2 };
+// kSrcU32Twist: NEGACYCLIC forward transform of a full-length u32 row: x[j] * psi^j on load (psi a primitive 2L-th root of
+// unity, psi^2 = w_L; table `tw`), then the plain length-L cyclic transform: X[k] = sum_j x[j] psi^(j(2k+1)).  Products of
+// such transforms are products modulo x^L + 1 -- no zero padding, no reduction step (cuhe/Operations.cu:460-501 vanishes).
+enum : int { kSrcU32Ext = 0, kSrcWindow = 1, kSrcU64Neg = 2, kSrcU32Twist = 3 };
+__host__ __device__ constexpr bool src_is_ext(int mode) { return mode == kSrcU32Ext || mode == kSrcWindow; }
 
 // blockIdx -> (batch, tile) with every tile of one transform on one XCD
 // (block b runs on XCD b % 8: MI355X_MICROARCH "Workgroup dispatch"; speed only).
@@ -65,8 +69,11 @@ __device__ __forceinline__ void dft_regs(u64 (&x)[N]) {
 //               as input of the next forward transform;
 //   FoldFinal : r[i] = (g mod (x^Lh - 1))[i] - (q Phi mod (x^Lh - 1))[i] for i < n, zero up to the row length, with g the
 //               fold of the product row f (`aux`) modulo x^m - 1.
-enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2, kOutU64Mul = 3, kOutModPRevQ = 4, kOutFoldFinal = 5 };
-__host__ __device__ constexpr bool out_is_inverse(int out) { return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPRevQ || out == kOutFoldFinal; }
+// kOutModPNc: inverse NEGACYCLIC transform: the outputs are multiplied by psi^-j (table `xtab`; L^-1 sits in the outer
+//   twiddles as for every inverse), lifted to the centred representative (the integer coefficient of a product modulo
+//   x^L + 1 lies in (-P/2, P/2) when 2 L p^2 < P) and reduced modulo p_i.
+enum : int { kOutU64 = 0, kOutModP = 1, kOutModPFoldXn1 = 2, kOutU64Mul = 3, kOutModPRevQ = 4, kOutFoldFinal = 5, kOutModPNc = 6 };
+__host__ __device__ constexpr bool out_is_inverse(int out) { return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPRevQ || out == kOutFoldFinal || out == kOutModPNc; }
 
 // ---- folded form of the generic reduction.  f = product of two reduced polynomials (degree <= 2n-2, row stride nlen,
 // residues < p).  g = f mod (x^m - 1) when m < 2n-1 (Phi_m divides x^m - 1), else g = f; D = length of g;
@@ -112,7 +119,8 @@ __global__ __launch_bounds__(256, 4)
 void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
                 long dst_stride, int nbatch, int nstore,
                 const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
-                const u32 *__restrict__ aux, long aux_stride, FoldGeom fg) {
+                const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab) {
+    // xtab: kOutU64Mul -- the table rows u64[row][L] the outputs are multiplied by; kOutModPNc -- psi^-j, u64[L]
     // np_mod > 0: the rows are several ciphertexts' worth of the same np_mod primes (batched operations); row r of the
     // whole call belongs to prime r mod np_mod and prime0 carries the row offset of this launch
     constexpr int L = 1 << LG, N1 = L / 64;
@@ -160,7 +168,7 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
             for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(y[bitrev<4>(c)], &dst[(long)(b + 16 * c) * N1]);
         } else if constexpr (OUT == kOutU64Mul) {
             u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
-            const u64 *tab = pinv + (long)pidx * L + k1;
+            const u64 *tab = xtab + (long)pidx * L + k1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const long o = (long)(b + 16 * c) * N1;
@@ -172,6 +180,17 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
             for (int c = 0; c < 4; ++c) {
                 const int k2 = b + 16 * c;
                 if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[(long)k2 * N1] = mod_small(y[bitrev<4>(c)], p, m);
+            }
+        } else if constexpr (OUT == kOutModPNc) {
+            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
+            const u64 *ti = xtab + k1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long o = (long)(b + 16 * c) * N1;
+                const u64 v = mulp(y[bitrev<4>(c)], ti[o]);
+                const bool neg = v > (kP >> 1);                       // centred lift: v - P < 0
+                const u32 rr = mod_small(neg ? kP - v : v, p, m);
+                dst[o] = (neg && rr) ? p - rr : rr;
             }
         } else if constexpr (OUT == kOutModPRevQ) {
             u32 *dst = (u32 *)dst_ + (long)batch * dst_stride;
@@ -242,11 +261,11 @@ struct StepBWrite {
 template <int LG, int MODE>
 __global__ __launch_bounds__(kP1wThreads, 2)
 void ntt_pass1w(const void *__restrict__ src_, u64 *__restrict__ scratch,
-                const u64 *__restrict__ T1, long src_stride, int nbatch, WindowArgs wa) {
+                const u64 *__restrict__ T1, long src_stride, int nbatch, WindowArgs wa, const u64 *__restrict__ tw) {
     using G = P1wGeom<LG>;
     constexpr int L = 1 << LG, N1 = G::N1, RA = G::RA, NC = G::NC, T = kP1wThreads;
     constexpr int IA = NC * 64 / T;                       // stage-A items per thread (1 / 2 / 4), RA values each
-    constexpr bool EXT = (MODE != kSrcU64Neg);
+    constexpr bool EXT = src_is_ext(MODE);
     constexpr int NA = EXT ? RA / 2 : RA;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     u64 *xch = lds;
@@ -280,6 +299,9 @@ void ntt_pass1w(const void *__restrict__ src_, u64 *__restrict__ scratch,
                 if (wi + 1 < wa.words) sv |= (u64)co[wi + 1] << 32;
                 sv >>= (bit & 31);
                 x[a] = sv & (u64)((1u << wa.w) - 1u);
+            } else if constexpr (MODE == kSrcU32Twist) {
+                const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
+                x[a] = mulp_u32(tw[idx], src[idx]);
             } else {
                 const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
                 x[a] = src[(L - idx) & (L - 1)];

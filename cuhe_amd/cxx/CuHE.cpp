@@ -348,7 +348,9 @@ void CuPolynomial::c2r(cudaStream_t st) {
 void CuPolynomial::c2n(cudaStream_t st) {
 	if (domain_ != 2) { printf("Error: Not in domain CRT!\n"); terminate(); }
 	nRepAlloc(st);
-	ntt(nRep_, cRep_, logq_, device_, st);
+	// the ciphertext-domain transform: cyclic (the reference's ntt()) on general rings, negacyclic of modLen points
+	// when the modulus is x^n + 1 (include/cuhe_hip.h, cuhe_hip_ct_*); every NTT-domain gate below works on either
+	CSC(cuhe_hip_ct_ntt(U64P(nRep_), cRep_, logq_, device_, st));
 	GATE_SYNC(device_, st);
 	cRepFree();
 	domain_ = 3;
@@ -356,8 +358,7 @@ void CuPolynomial::c2n(cudaStream_t st) {
 void CuPolynomial::n2c(cudaStream_t st) {
 	if (domain_ != 3) { printf("Error: Not in domain NTT!\n"); terminate(); }
 	cRepAlloc(st);
-	if (isProd_) inttMod(cRep_, nRep_, logq_, device_, st);
-	else intt(cRep_, nRep_, logq_, device_, st);
+	CSC(cuhe_hip_ct_intt(cRep_, U64P(nRep_), logq_, isProd_ ? 1 : 0, device_, st));    // inttMod for products, intt otherwise
 	GATE_SYNC(device_, st);
 	isProd_ = false;
 	nRepFree();
@@ -406,7 +407,7 @@ void CuCtxt::setLevel(int lvl, int device, ZZX val) {
 }
 int CuCtxt::level() { return level_; }
 size_t CuCtxt::cRepSize() { return (size_t)param._numCrtPrime(level_) * param.crtLen * sizeof(uint32); }
-size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * param.nttLen * sizeof(uint64); }
+size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * cuhe_hip_ct_len() * sizeof(uint64); }   // ct rows: nttLen, or modLen on x^n + 1 rings
 void CuCtxt::modSwitch(cudaStream_t st) {
 	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
 	{ GateScope chain; x2c(st); stream_ = st; crtModSwitch(cRep_, cRep_, logq_, device_, st); }
@@ -437,7 +438,7 @@ void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
 }
 void CuPtxt::setLogq(int logq, int device, ZZX val) { logq_ = logq; domain_ = 0; device_ = device; zRep_ = std::move(val); }
 size_t CuPtxt::cRepSize() { return (size_t)param.crtLen * sizeof(uint32); }
-size_t CuPtxt::nRepSize() { return (size_t)param.nttLen * sizeof(uint64); }
+size_t CuPtxt::nRepSize() { return (size_t)cuhe_hip_ct_len() * sizeof(uint64); }
 
 // ------------------------------------------------------------------ gates
 void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
@@ -462,7 +463,7 @@ void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
 	prepareOut(out, in0, 3, st);
 	in0.stream(st); in1.stream(st); out.stream(st);
-	nttMul(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
+	CSC(cuhe_hip_ct_mul(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
 	out.isProd(true);
 	GATE_SYNC(out.device(), st);
 }
@@ -471,7 +472,7 @@ void cAnd(CuCtxt &out, CuCtxt &inc, CuPtxt &inp, cudaStream_t st) {
 	if (inc.domain() != 3 || inp.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
 	prepareOut(out, inc, 3, st);
 	inc.stream(st); inp.stream(st); out.stream(st);
-	nttMulNX1(out.nRep(), inc.nRep(), inp.nRep(), out.logq(), out.device(), st);
+	CSC(cuhe_hip_ct_mul_nx1(U64P(out.nRep()), U64P(inc.nRep()), U64P(inp.nRep()), out.logq(), out.device(), st));
 	out.isProd(true);
 	GATE_SYNC(out.device(), st);
 }
@@ -485,7 +486,7 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	} else if (in0.domain() == 3 && in1.domain() == 3) {
 		const bool prod = in0.isProd() || in1.isProd();
 		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
-		nttAdd(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
+		CSC(cuhe_hip_ct_add(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
 	GATE_SYNC(out.device(), st);
 }
@@ -498,7 +499,7 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuPtxt &in1, cudaStream_t st) {
 	} else if (in0.domain() == 3 && in1.domain() == 3) {
 		const bool prod = in0.isProd() || in1.isProd();
 		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
-		nttAddNX1(out.nRep(), in0.nRep(), in1.nRep(), out.logq(), out.device(), st);
+		CSC(cuhe_hip_ct_add_nx1(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
 	GATE_SYNC(out.device(), st);
 }
@@ -613,7 +614,7 @@ void CuIndexTable::set(const std::vector<int> &values, int device) {
 }
 
 static size_t arrayCtWords(int lvl) { return (size_t)param._numCrtPrime(lvl) * param.crtLen; }     // u32 per CRT ciphertext
-static size_t arrayCtElems(int lvl) { return (size_t)param._numCrtPrime(lvl) * param.nttLen; }     // u64 per NTT ciphertext
+static size_t arrayCtElems(int lvl) { return (size_t)param._numCrtPrime(lvl) * cuhe_hip_ct_len(); } // u64 per NTT-domain ciphertext (ct rows)
 static void arrayMisuse(const char *msg) { printf("Error: %s\n", msg); terminate(); }
 
 void CuCtxtArray::release() {
@@ -673,7 +674,7 @@ void CuCtxtArray::x2c(cudaStream_t st) {
 		GateScope chain;
 		cRep_ = (uint32 *)devAlloc(device_, count_ * arrayCtWords(0) * sizeof(uint32), st);
 		if (isProd_) CSC(cuhe_hip_intt_mod_batch(cRep_, U64P(nRep_), level_, count_, device_, st));
-		else for (int i = 0; i < count_; ++i) CSC(cuhe_hip_intt(cRep(i), U64P(nRep(i)), param._logCoeff(level_), device_, st));
+		else for (int i = 0; i < count_; ++i) CSC(cuhe_hip_ct_intt(cRep(i), U64P(nRep(i)), param._logCoeff(level_), 0, device_, st));
 		devFree(device_, nRep_, st); nRep_ = NULL;
 	}
 	domain_ = 2; isProd_ = false;

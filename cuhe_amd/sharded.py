@@ -81,6 +81,7 @@ class HipBackend:
         self.capi, self.lib, self.ck = capi, capi.lib, capi.check
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.prm = capi.get_params()
+        self.ctlen = self.lib.cuhe_hip_ct_len()          # row length of NTT-domain (ct) rows: nttLen, or modLen on x^n + 1 rings
 
     def num_primes(self, lvl):
         return self.lib.cuhe_hip_num_crt_prime(lvl)
@@ -101,11 +102,11 @@ class HipBackend:
         return raw
 
     def relin_range(self, raw, lvl, first, count):
-        out = torch.empty((count, self.prm.nttLen), dtype=torch.int64, device=self.dev)
+        out = torch.empty((count, self.ctlen), dtype=torch.int64, device=self.dev)
         self.ck(self.lib.cuhe_hip_relin_range(out.data_ptr(), raw.data_ptr(), lvl, first, count, 0, None))
         return out
 
     def ntt_rows(self, crt_rows):
-        out = torch.empty((crt_rows.shape[0], self.prm.nttLen), dtype=torch.int64, device=self.dev)
+        out = torch.empty((crt_rows.shape[0], self.ctlen), dtype=torch.int64, device=self.dev)
         self.ck(self.lib.cuhe_hip_ntt_rows(out.data_ptr(), crt_rows.data_ptr(), crt_rows.shape[0], 0, None))
         return out

@@ -142,6 +142,29 @@ int cuhe_hip_ntt_add_nx1(uint64_t *z, const uint64_t *x, const uint64_t *scalar,
 int cuhe_hip_barrett(uint32_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
 int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *stream);
 
+/* ---- ciphertext-domain ("ct") transforms: the NTT representation CuCtxt / CuPtxt keep their polynomials in
+ * (cuhe/CuHE.cu:383-408 c2n / n2c, :101-215 gates, :570-581 relin).  On general rings it IS the reference's: cyclic
+ * transforms of nttLen points of the zero-padded residues, products reduced modulo Phi_m afterwards
+ * (cuhe/Operations.cu:394-504) -- the functions above.  When the polynomial modulus is x^n + 1 with n a transform
+ * length (16384 / 32768 / 65536) and every CRT prime obeys 2 n p^2 < P (and 2 k n 2^w p < P for the key switch), it
+ * is the NEGACYCLIC transform of n points, X[k] = sum_j x[j] psi^(j (2k+1)) with psi a primitive 2n-th root of unity
+ * (psi = g for n = 32768): half the points per polynomial, half the bytes per evaluation key, and a product of
+ * transforms is already the product modulo x^n + 1 -- the reduction of cuhe/Operations.cu:460-501 disappears.  CRT- and
+ * raw-domain results are bit-identical either way.  Ring degree 65536 (m = 131072, beyond the reference's 65536-point
+ * limit, cuhe/Base.cu:59-62) exists in this representation only: there the cyclic functions above fail with CUHE_EINVAL
+ * and setParameters picks primes of at most 23 bits.
+ * Row length of a ct-domain polynomial: cuhe_hip_ct_len() (= modLen or nttLen).  ct arrays are u64[rows][ct_len]. */
+int cuhe_hip_set_negacyclic(int mode);   /* before init: -1 = negacyclic wherever it applies (default), 0 = never */
+int cuhe_hip_ct_negacyclic(void);        /* 1 if the initialised context uses the negacyclic representation */
+int cuhe_hip_ct_len(void);
+int cuhe_hip_ct_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *stream);                /* c2n, CuHE.cu:383 */
+/* n2c, CuHE.cu:394-408: is_prod != 0 -> the rows are products (inttMod: reduction modulo the polynomial modulus) */
+int cuhe_hip_ct_intt(uint32_t *x, const uint64_t *X, int logq, int is_prod, int dev, void *stream);
+int cuhe_hip_ct_mul(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *stream);       /* cAnd */
+int cuhe_hip_ct_mul_nx1(uint64_t *z, const uint64_t *x, const uint64_t *scalar, int logq, int dev, void *stream);
+int cuhe_hip_ct_add(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *stream);       /* cXor in the NTT domain */
+int cuhe_hip_ct_add_nx1(uint64_t *z, const uint64_t *x, const uint64_t *scalar, int logq, int dev, void *stream);
+
 /* single-polynomial forms _ntt / _nttw / _intt (cuhe/Operations.h:78-81) */
 int cuhe_hip_ntt_one(uint64_t *X, const uint32_t *x, int dev, void *stream);
 int cuhe_hip_nttw_one(uint64_t *X, const uint32_t *x, int coeffwords, int relinIdx, int dev, void *stream);
@@ -151,10 +174,11 @@ int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void 
 /* initRelinearization: evalkey = numEvalKey polynomials in raw layout at level 0,
  * HOST memory u32[numEvalKey][rawLen][W0]; keys are converted once and stay in HBM. */
 int cuhe_hip_init_relin(const uint32_t *evalkey_raw_host);
-/* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst ntt u64[np][nttLen] */
+/* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst in the ct domain u64[np][ct_len]
+ * (the keys are kept in the ct domain only; the reference's sole consumer of dst is n2c, CuHE.cu:570-581) */
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
 /* `batch` independent (cAnd ; CuCtxt::relin) chains of one level in one call (CuHE.cu:101,570-581 issue them one
-   ciphertext at a time): a, b = NTT-domain operands u64[batch][np][nttLen], dst = reduced CRT-domain results
+   ciphertext at a time): a, b = ct-domain operands u64[batch][np][ct_len], dst = reduced CRT-domain results
    u32[batch][np][crtLen], np = primes of `lvl`.  Bit-identical to the single-ciphertext sequence
    ntt_mul, intt_mod, icrt, relinearization, intt_mod; every stage runs over batch*np rows and the key-switch inner
    product reads each key value once per four ciphertexts. */
@@ -173,9 +197,9 @@ int cuhe_hip_set_relin_lanes(int n);
    single sequence crt, crt, ntt, ntt, ntt_mul, intt_mod, icrt */
 int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a_raw, const uint32_t *b_raw, int lvl, int batch, int dev, void *stream);
 /* ---- gates on ARRAYS of ciphertexts of one level (no counterpart: the reference's gates, CuHE.cu:101-215,545-568,
-   take one ciphertext per call).  Arrays are u32[count][np][crtLen] (CRT domain) or u64[count][np][nttLen] (NTT domain);
+   take one ciphertext per call).  Arrays are u32[count][np][crtLen] (CRT domain) or u64[count][np][ct_len] (ct domain);
    index arrays live in device memory.  Each call is bit-identical to the per-ciphertext gates it stands for. */
-/* n2c of products: INTT + reduction modulo the polynomial modulus for `batch` ciphertexts */
+/* n2c of products: inverse transform + reduction modulo the polynomial modulus for `batch` ciphertexts */
 int cuhe_hip_intt_mod_batch(uint32_t *dst_crt, const uint64_t *src_ntt, int lvl, int batch, int dev, void *stream);
 /* modSwitch: src at level lvl (np rows each) -> dst at level lvl+1, packed u32[batch][np-1][crtLen] */
 int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *stream);
@@ -193,7 +217,7 @@ int cuhe_hip_relin_export(void *dst_host, size_t capacity, int dev);
 int cuhe_hip_relin_import(const void *src_host, size_t bytes);
 
 /* ---- CRT-prime-sharded variants (new): one rank owns primes [prime0, prime0+count) of level
- * `lvl`; row pointers address the shard's own rows (row 0 = prime0).  Per-prime stages need no communication;
+ * `lvl`; row pointers address the shard's own rows (row 0 = prime0), NTT-domain rows are ct rows (ct_len).  Per-prime stages need no communication;
  * the only exchange of a sharded multiply+relinearise is the all-gather of CRT rows before cuhe_hip_icrt. */
 int cuhe_hip_ntt_rows(uint64_t *X, const uint32_t *x, int count, int dev, void *stream);
 int cuhe_hip_ntt_mul_rows(uint64_t *z, const uint64_t *y, const uint64_t *x, int count, int dev, void *stream);

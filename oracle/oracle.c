@@ -160,6 +160,13 @@ int orc_set_param(orc_params *q, int d, int p, int w, int min, int cut, int m) {
     q->wordsMsg = (q->logMsg + 31) / 32;
     q->numEvalKey = w ? (q->logCoeffMax + w - 1) / w : 0;
     q->logCrtPrime = numbits_u64(isqrt_u64(ORC_P / (uint64_t)q->modLen));
+    if (m == 131072) {
+        /* NOT in the reference (its transforms stop at 65536 points, i.e. ring degree 2^15: Parameters.cu:63-68,
+         * Base.cu:59-62): x^65536 + 1 through 64K-point negacyclic transforms.  nttLen is the transform length and the
+         * primes obey the centred-lift bound 2 n p^2 < P: at most 23 bits. */
+        q->nttLen = q->modLen2;
+        q->logCrtPrime = numbits_u64(isqrt_u64(ORC_P / (2 * (uint64_t)q->modLen))) - 1;
+    }
     q->numCrtPrime = (min + q->logCrtPrime - 1) / q->logCrtPrime;
     q->logCrtPrime = 0;
     while (q->logCrtPrime * q->numCrtPrime < min) q->logCrtPrime++;
@@ -717,6 +724,75 @@ void orc_mul_relin_crt(const orc_ctx *c, uint32_t *dst, const uint32_t *a, const
 }
 
 /* ------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------ */
+/* products modulo x^n + 1 (m = 2n a power of two)                           */
+/* The reference reduces the zero-padded cyclic product with its NTT Barrett */
+/* chain (cuhe/Operations.cu:460-501); for Phi_m = x^n + 1 that remainder is */
+/* the negacyclic convolution restated here, first by definition, then with  */
+/* the twisted length-n transform the MI355X backend uses on such rings.     */
+/* ------------------------------------------------------------------------ */
+void orc_negacyclic_mul_modp_naive(uint32_t *dst, const uint32_t *a, const uint32_t *b, int n, uint32_t p) {
+    /* c[i] = sum_{j<=i} a[j] b[i-j] - sum_{j>i} a[j] b[n+i-j]  (mod p), residues below p < 2^32 */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        uint64_t pos = 0, neg = 0;
+        for (int j = 0; j <= i; j++) pos = (pos + (uint64_t)a[j] * b[i - j] % p) % p;
+        for (int j = i + 1; j < n; j++) neg = (neg + (uint64_t)a[j] * b[n + i - j] % p) % p;
+        dst[i] = (uint32_t)((pos + p - neg) % p);
+    }
+}
+/* psi = 7^((P-1)/2n): 7 generates Z_P^* (P - 1 = 2^32 * 3 * 5 * 17 * 257 * 65537), so psi is a primitive 2n-th root of
+ * unity for every power of two 2n <= 2^32.  Which primitive root is used does not matter for the product. */
+static uint64_t nc_psi(int n) {
+    uint64_t psi = orc_pow_modP(7, (ORC_P - 1) / (2 * (uint64_t)n));
+    if (orc_pow_modP(psi, (uint64_t)n) != ORC_P - 1) { fprintf(stderr, "oracle: 7 is not a generator?\n"); abort(); }
+    return psi;
+}
+void orc_nc_ntt(uint64_t *dst, const uint32_t *src, int n) {     /* X[k] = sum_j x[j] psi^(j(2k+1)) */
+    const uint64_t psi = nc_psi(n);
+    uint64_t t = 1;
+    for (int j = 0; j < n; j++) { dst[j] = orc_mul_modP(src[j], t); t = orc_mul_modP(t, psi); }
+    fft_inplace(dst, n, orc_mul_modP(psi, psi));
+}
+int orc_nc_intt_modp(uint32_t *dst, const uint64_t *src, int n, uint32_t p) {
+    /* exact integer coefficient = centred representative modulo P (|c| < P/2 required), then mod p */
+    const uint64_t psi = nc_psi(n), ipsi = orc_pow_modP(psi, ORC_P - 2);
+    const uint64_t w = orc_mul_modP(psi, psi), iw = orc_pow_modP(w, ORC_P - 2), ninv = orc_pow_modP((uint64_t)n, ORC_P - 2);
+    uint64_t *t = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    memcpy(t, src, sizeof(uint64_t) * n);
+    fft_inplace(t, n, iw);
+    uint64_t tw = ninv;
+    for (int j = 0; j < n; j++) {
+        const uint64_t v = orc_mul_modP(t[j], tw);
+        tw = orc_mul_modP(tw, ipsi);
+        if (v > ORC_P / 2) { const uint32_t r = (uint32_t)((ORC_P - v) % p); dst[j] = r ? p - r : 0; }
+        else dst[j] = (uint32_t)(v % p);
+    }
+    free(t);
+    return 0;
+}
+int orc_negacyclic_mul_modp(uint32_t *dst, const uint32_t *a, const uint32_t *b, int n, uint32_t p) {
+    if ((u128)2 * n * (p - 1) * (p - 1) >= ORC_P) return -1;        /* the centred lift would be ambiguous */
+    uint64_t *A = (uint64_t *)malloc(sizeof(uint64_t) * n), *B = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    orc_nc_ntt(A, a, n); orc_nc_ntt(B, b, n);
+    for (int i = 0; i < n; i++) A[i] = orc_mul_modP(A[i], B[i]);
+    orc_nc_intt_modp(dst, A, n, p);
+    free(A); free(B);
+    return 0;
+}
+/* key-switch inner product modulo x^n + 1 for ONE prime: dst = sum_j win[j] * key[j] mod (x^n + 1) mod p, accumulated in the
+ * transform domain like cuhe/Relinearization.cu:76-88 (windows below 2^w, key residues below p; 2 k n 2^w p < P required) */
+int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, int k, int n, uint32_t p) {
+    uint64_t *acc = (uint64_t *)calloc(n, sizeof(uint64_t)), *A = (uint64_t *)malloc(sizeof(uint64_t) * n), *B = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    for (int j = 0; j < k; j++) {
+        orc_nc_ntt(A, win + (size_t)j * n, n); orc_nc_ntt(B, key + (size_t)j * n, n);
+        for (int i = 0; i < n; i++) acc[i] = orc_add_modP(acc[i], orc_mul_modP(A[i], B[i]));
+    }
+    orc_nc_intt_modp(dst, acc, n, p);
+    free(acc); free(A); free(B);
+    return 0;
+}
+
 uint64_t orc_splitmix64(uint64_t *s) {
     uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

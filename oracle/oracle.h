@@ -134,6 +134,17 @@ void orc_mul_raw(const orc_ctx *c, uint32_t *out, const uint32_t *a, const uint3
 void orc_mul_relin_crt(const orc_ctx *c, uint32_t *dst, const uint32_t *a, const uint32_t *b,
                        int lvl, const uint64_t *ek);
 
+/* ---- products modulo x^n + 1 (rings with m = 2n a power of two): the remainder the reference's Barrett chain
+ * (cuhe/Operations.cu:460-501) produces for Phi_m = x^n + 1, restated as the negacyclic convolution -- by definition
+ * (O(n^2)) and through the twisted length-n transform (X[k] = sum_j x[j] psi^(j(2k+1)), psi a primitive 2n-th root of
+ * unity, centred lift on the way back).  The fast forms return -1 when 2 n (p-1)^2 >= P. */
+void orc_negacyclic_mul_modp_naive(uint32_t *dst, const uint32_t *a, const uint32_t *b, int n, uint32_t p);
+int orc_negacyclic_mul_modp(uint32_t *dst, const uint32_t *a, const uint32_t *b, int n, uint32_t p);
+void orc_nc_ntt(uint64_t *dst, const uint32_t *src, int n);
+int orc_nc_intt_modp(uint32_t *dst, const uint64_t *src, int n, uint32_t p);
+/* sum_j win[j] * key[j] mod (x^n + 1) mod p over k window / key rows of n coefficients (cuhe/Relinearization.cu:76-88) */
+int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, int k, int n, uint32_t p);
+
 /* seeded generator shared by tests / bench: splitmix64 */
 uint64_t orc_splitmix64(uint64_t *state);
 void orc_fill_u32_below(uint32_t *dst, size_t n, uint32_t bound, uint64_t seed);

@@ -338,6 +338,9 @@ PARAM_SETS = {
     "pow2_16384": (3, 2, 16, 50, 25, 16384),      # Phi = x^8192 + 1
     "c3_65536": (9, 2, 16, 576, 24, 65536),       # BASELINE config 3 shape: n = 2^15, L = 65536, 32 primes < 2^24
     "c4_65536": (25, 2, 16, 576, 24, 65536),      # BASELINE config 4 shape: 64K-point transforms, 48 primes < 2^24
+    # BASELINE config 1 exactly: N = 2^13 with ONE CRT prime (p = 2097143), on x^8192 + 1 and on Phi_8191
+    "c1_pow2_1prime": (1, 2, 16, 21, 21, 16384),
+    "c1_prime_m_1prime": (1, 2, 16, 21, 21, 8191),
 }
 
 
@@ -465,6 +468,16 @@ def lv_iter(l):
 
 def main():
     sets = {}
+    if "--config1" in sys.argv:                      # only the fixtures added for BASELINE config 1 (+ the parameter table)
+        sets["params.json"] = fx_params()
+        for nm in ("c1_pow2_1prime", "c1_prime_m_1prime"):
+            print("pipeline", nm, "...", flush=True)
+            sets["pipeline_%s.json" % nm] = fx_pipeline(nm, [0], False, False)
+        for fn, obj in sets.items():
+            with open(os.path.join(HERE, fn), "w") as f:
+                json.dump(obj, f, indent=1)
+            print("wrote", fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
+        return
     print("field ...", flush=True)
     sets["field.json"] = fx_field()
     print("ntt ...", flush=True)
@@ -477,6 +490,9 @@ def main():
     sets["pipeline_pow2_16384.json"] = fx_pipeline("pow2_16384", [0, 2], False, False)
     print("pipeline dhs_simple ...", flush=True)
     sets["pipeline_dhs_simple.json"] = fx_pipeline("dhs_simple", [0, 4], False, False)
+    for nm in ("c1_pow2_1prime", "c1_prime_m_1prime"):
+        print("pipeline", nm, "...", flush=True)
+        sets["pipeline_%s.json" % nm] = fx_pipeline(nm, [0], False, False)
     for fn, obj in sets.items():
         with open(os.path.join(HERE, fn), "w") as f:
             json.dump(obj, f, indent=1)

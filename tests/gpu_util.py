@@ -42,9 +42,11 @@ def host_u64(t):
 class GpuCtx:
     """(re)initialises the library-global context for one parameter set."""
 
-    def __init__(self, d, p, w, mn, cut, m, modulus=None):
+    def __init__(self, d, p, w, mn, cut, m, modulus=None, negacyclic=True):
+        """negacyclic=False: keep the reference's cyclic representation even where the negacyclic one applies."""
         lib.cuhe_hip_shutdown()
         lib.cuhe_hip_reset_parameters()
+        ck(lib.cuhe_hip_set_negacyclic(-1 if negacyclic else 0))
         ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))
         if modulus is None:
             ck(lib.cuhe_hip_init(None, 0))
@@ -55,10 +57,33 @@ class GpuCtx:
         pr = np.zeros(self.prm.numCrtPrime, dtype=np.uint32)
         ck(lib.cuhe_hip_get_crt_primes(pr.ctypes.data_as(C.c_void_p), pr.size))
         self.primes = pr
+        self.nc = bool(lib.cuhe_hip_ct_negacyclic())        # ciphertext-domain rows are negacyclic transforms of modLen points
+        self.ctlen = lib.cuhe_hip_ct_len()
 
     def close(self):
         lib.cuhe_hip_shutdown()
         lib.cuhe_hip_reset_parameters()
+        lib.cuhe_hip_set_negacyclic(-1)
+
+    # --- ciphertext-domain transforms (what CuCtxt uses): rows of ctlen
+    def ct_ntt(self, crt, lvl):
+        d_in = to_dev(crt)
+        d_out = empty_u64(self.np_(lvl), self.ctlen)
+        ck(lib.cuhe_hip_ct_ntt(d_out.data_ptr(), d_in.data_ptr(), self.logq(lvl), 0, None))
+        return host_u64(d_out)
+
+    def ct_intt(self, X, lvl, prod):
+        d_in = to_dev(X)
+        d_out = empty_u32(self.np_(lvl), self.prm.crtLen)
+        ck(lib.cuhe_hip_ct_intt(d_out.data_ptr(), d_in.data_ptr(), self.logq(lvl), 1 if prod else 0, 0, None))
+        return host_u32(d_out)
+
+    def ct_mul(self, x, y, lvl): return self._bin64("cuhe_hip_ct_mul", x, y, lvl)
+    def ct_add(self, x, y, lvl): return self._bin64("cuhe_hip_ct_add", x, y, lvl)
+
+    def relin_crt(self, raw, lvl):
+        """CuCtxt::relin on a raw ciphertext: key switch, then n2c of the sums -> u32[np][crtLen]"""
+        return self.ct_intt(self.relin(raw, lvl), lvl, True)
 
     def np_(self, lvl): return lib.cuhe_hip_num_crt_prime(lvl)
     def words(self, lvl): return lib.cuhe_hip_words_coeff(lvl)
@@ -168,25 +193,34 @@ class GpuCtx:
         ck(lib.cuhe_hip_init_relin(ek_raw.ctypes.data_as(C.c_void_p)))
 
     def relin(self, raw, lvl):
+        """ct-domain rows u64[np][ctlen] (== the reference's NTT-domain rows on the cyclic representation)"""
         d_in = to_dev(raw)
-        d_out = empty_u64(self.np_(lvl), self.prm.nttLen)
+        d_out = empty_u64(self.np_(lvl), self.ctlen)
         ck(lib.cuhe_hip_relinearization(d_out.data_ptr(), d_in.data_ptr(), lvl, 0, None))
         return host_u64(d_out)
 
-    def mul_raw(self, a_raw, b_raw, lvl):
-        """mulZZX at the raw level (cuhe/CuHE.cu:259-268) with device-resident intermediates."""
+    def mul_raw(self, a_raw, b_raw, lvl, cyclic_api=False):
+        """mulZZX at the raw level (cuhe/CuHE.cu:259-268) with device-resident intermediates: through the ciphertext-
+        domain entry points CuCtxt uses, or (cyclic_api) through the reference-contract ntt / nttMul / inttMod."""
         logq = self.logq(lvl)
         np_, q = self.np_(lvl), self.prm
         da, db = to_dev(a_raw), to_dev(b_raw)
         ca, cb = empty_u32(np_, q.crtLen), empty_u32(np_, q.crtLen)
-        na, nb = empty_u64(np_, q.nttLen), empty_u64(np_, q.nttLen)
+        rl = q.nttLen if cyclic_api else self.ctlen
+        na, nb = empty_u64(np_, rl), empty_u64(np_, rl)
         out = empty_u32(q.rawLen, self.words(lvl))
         ck(lib.cuhe_hip_crt(ca.data_ptr(), da.data_ptr(), logq, 0, None))
         ck(lib.cuhe_hip_crt(cb.data_ptr(), db.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_intt_mod(ca.data_ptr(), na.data_ptr(), logq, 0, None))
+        if cyclic_api:
+            ck(lib.cuhe_hip_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ntt_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_intt_mod(ca.data_ptr(), na.data_ptr(), logq, 0, None))
+        else:
+            ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ct_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ct_intt(ca.data_ptr(), na.data_ptr(), logq, 1, 0, None))
         ck(lib.cuhe_hip_icrt(out.data_ptr(), ca.data_ptr(), logq, 0, None))
         return host_u32(out)
 
@@ -195,14 +229,14 @@ class GpuCtx:
         logq = self.logq(lvl)
         np_, q = self.np_(lvl), self.prm
         ca, cb = to_dev(a_crt), to_dev(b_crt)
-        na, nb = empty_u64(np_, q.nttLen), empty_u64(np_, q.nttLen)
+        na, nb = empty_u64(np_, self.ctlen), empty_u64(np_, self.ctlen)
         cr = empty_u32(np_, q.crtLen)
         raw = empty_u32(q.rawLen, self.words(lvl))
-        ck(lib.cuhe_hip_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_ntt_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_intt_mod(cr.data_ptr(), na.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), ca.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), cb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), na.data_ptr(), logq, 1, 0, None))
         ck(lib.cuhe_hip_icrt(raw.data_ptr(), cr.data_ptr(), logq, 0, None))
         ck(lib.cuhe_hip_relinearization(na.data_ptr(), raw.data_ptr(), lvl, 0, None))
-        ck(lib.cuhe_hip_intt_mod(cr.data_ptr(), na.data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), na.data_ptr(), logq, 1, 0, None))
         return host_u32(cr)

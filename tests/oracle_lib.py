@@ -81,6 +81,9 @@ def lib():
         }
         for f, a in sig.items():
             getattr(L, f).restype = None; getattr(L, f).argtypes = a
+        L.orc_negacyclic_mul_modp_naive.restype = None; L.orc_negacyclic_mul_modp_naive.argtypes = [vp, vp, vp, i32, u32]
+        L.orc_negacyclic_mul_modp.restype = i32; L.orc_negacyclic_mul_modp.argtypes = [vp, vp, vp, i32, u32]
+        L.orc_nc_relin_modp.restype = i32; L.orc_nc_relin_modp.argtypes = [vp, vp, vp, i32, i32, u32]
         L.orc_fill_u32_below.restype = None; L.orc_fill_u32_below.argtypes = [vp, C.c_size_t, u32, u64]
         _LIB = L
     return _LIB
@@ -124,6 +127,27 @@ def intt_modp(X, length, p):
     X = np.ascontiguousarray(X, dtype=np.uint64)
     out = np.empty(length, dtype=np.uint32)
     lib().orc_intt_modp(_p(out), _p(X), length, p)
+    return out
+
+
+def negacyclic_mul_modp(a, b, p, naive=False):
+    """(a * b mod x^n + 1) mod p for residue rows a, b (u32[n], entries below p): by definition (naive) or through the
+    twisted length-n transform (needs 2 n p^2 < P)"""
+    a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
+    out = np.empty(a.size, dtype=np.uint32)
+    if naive:
+        lib().orc_negacyclic_mul_modp_naive(_p(out), _p(a), _p(b), a.size, p)
+    else:
+        assert lib().orc_negacyclic_mul_modp(_p(out), _p(a), _p(b), a.size, p) == 0, "2 n p^2 >= P"
+    return out
+
+
+def nc_relin_modp(win, key, p):
+    """sum_j win[j] * key[j] mod (x^n + 1) mod p; win, key: u32[k][n]"""
+    win = np.ascontiguousarray(win, dtype=np.uint32); key = np.ascontiguousarray(key, dtype=np.uint32)
+    k, n = win.shape
+    out = np.empty(n, dtype=np.uint32)
+    assert lib().orc_nc_relin_modp(_p(out), _p(win), _p(key), k, n, p) == 0
     return out
 
 

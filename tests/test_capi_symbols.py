@@ -42,7 +42,7 @@ def test_version_and_error_string(capi):
     assert b"setParameters" in capi.lib.cuhe_hip_last_error()
 
 
-@pytest.mark.parametrize("name", ["dhs_simple", "prince", "toy1155", "pow2_16384", "c3_65536", "c4_65536"])
+@pytest.mark.parametrize("name", ["dhs_simple", "prince", "toy1155", "pow2_16384", "c3_65536", "c4_65536", "c1_pow2_1prime", "c1_prime_m_1prime"])
 def test_parameter_derivation(capi, golden, name):
     g = golden("params.json")[name]
     capi.lib.cuhe_hip_reset_parameters()
@@ -62,8 +62,20 @@ def test_parameter_derivation(capi, golden, name):
 
 
 def test_unsupported_ring_is_rejected(capi):
-    # phi(m) > 32768 would need a 128K-point transform (cuhe/Base.cu:59-62 supports 16K/32K/64K only)
-    assert capi.lib.cuhe_hip_set_parameters(2, 2, 16, 50, 25, 131072) != 0
+    # phi(m) > 32768 would need a 128K-point cyclic transform (cuhe/Base.cu:59-62 supports 16K/32K/64K only) ...
+    assert capi.lib.cuhe_hip_set_parameters(2, 2, 16, 50, 25, 262144) != 0
+    assert capi.lib.cuhe_hip_set_parameters(2, 2, 16, 50, 25, 3 * 65536) != 0
+    capi.lib.cuhe_hip_reset_parameters()
+
+
+def test_degree_65536_ring_parameters(capi):
+    # ... except x^65536 + 1 (m = 131072), which exists in the negacyclic representation: 64K-point transforms of the
+    # full-length residues, primes capped at 23 bits so that 2 n p^2 < P (include/cuhe_hip.h, cuhe_hip_ct_*)
+    capi.check(capi.lib.cuhe_hip_set_parameters(25, 2, 16, 552, 23, 131072))
+    q = capi.get_params()
+    assert (q.modLen, q.crtLen, q.rawLen, q.nttLen) == (65536, 65536, 65536, 65536)
+    assert q.logCrtPrime == 23 and q.numCrtPrime == 48 and q.numEvalKey == 69
+    assert capi.lib.cuhe_hip_ct_len() == 65536
     capi.lib.cuhe_hip_reset_parameters()
 
 

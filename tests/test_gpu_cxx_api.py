@@ -24,7 +24,8 @@ def test_cxx_api_program():
     assert "ALL PASSED" in r.stdout
 
 
-@pytest.mark.parametrize("params", [(3, 2, 8, 40, 20, 1155), (5, 2, 1, 61, 20, 8191)], ids=["toy1155", "dhs_simple"])
+@pytest.mark.parametrize("params", [(3, 2, 8, 40, 20, 1155), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
+                         ids=["toy1155", "dhs_simple", "pow2_32768-negacyclic"])
 def test_dhs_scheme_flow(params):
     """keygen / encrypt / XOR / NOT / AND + relin + modSwitch (two levels) / decrypt through CuHE.h -- the checks of
     examples/DHS/simple_DHS.cu:49-170, with the reference example's own parameter set as the second case"""

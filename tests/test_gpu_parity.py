@@ -115,6 +115,7 @@ PSETS = {
     "dhs_simple": (5, 2, 1, 61, 20, 8191),       # prime m: fold reduction
     "pow2_16384": (3, 2, 16, 50, 25, 16384),     # x^n + 1
     "prince_small": (3, 2, 16, 25, 25, 21845),   # Prince ring (n=16384, L=32768), 3 levels
+    "pow2_32768": (3, 2, 16, 48, 24, 32768),     # x^16384 + 1 with 24-bit primes: the NEGACYCLIC ciphertext domain applies
 }
 
 
@@ -243,7 +244,9 @@ def test_mul_pipeline_vs_oracle(ctxpair):
 
 @pytest.mark.parametrize("name,fixture", [("toy1155", "pipeline_toy1155.json"),
                                           ("pow2_16384", "pipeline_pow2_16384.json"),
-                                          ("dhs_simple", "pipeline_dhs_simple.json")])
+                                          ("dhs_simple", "pipeline_dhs_simple.json"),
+                                          ("c1_pow2_1prime", "pipeline_c1_pow2_1prime.json"),         # BASELINE config 1: N = 2^13,
+                                          ("c1_prime_m_1prime", "pipeline_c1_prime_m_1prime.json")])  # exactly ONE CRT prime
 def test_mul_pipeline_vs_golden(gu, golden, name, fixture):
     """(a*b mod Phi_m) mod q against the pure-Python big-int fixtures (examples/DHS/DHS.cu:219-221)."""
     import oracle_lib as O
@@ -270,7 +273,7 @@ def test_mul_pipeline_vs_golden(gu, golden, name, fixture):
             for lvl_s, rec in gold["relin"]["levels"].items():
                 lvl = int(lvl_s)
                 ct, _ = O.random_raw(q.rawLen, q.modLen, g.words(lvl), g.coeff_modulus(lvl), rec["seed_ct"])
-                res = g.intt_mod(g.relin(ct, lvl), lvl)
+                res = g.relin_crt(ct, lvl)
                 assert sha(res) == rec["crt_sha256"]
     finally:
         g.close()
@@ -298,17 +301,19 @@ def test_relin_vs_oracle(gu):
         g.close(); o.close()
 
 
-def test_config3_full_size_properties(gu):
-    """BASELINE config 3: N = 2^15 (L = 65536), 32 CRT primes, full ciphertext multiply.
+@pytest.mark.parametrize("nc", [True, False], ids=["negacyclic", "cyclic"])
+def test_config3_full_size_properties(gu, nc):
+    """BASELINE config 3: N = 2^15 (L = 65536), 32 CRT primes, full ciphertext multiply, in the negacyclic ciphertext
+    domain (32K-point transforms, the default on this ring) and in the reference's cyclic one (64K-point transforms).
     Size-independent properties: (1) CRT->ICRT and NTT->INTT round trips, (2) x * 1 = x,
     (3) x * x^k = negacyclic shift, (4) bilinearity (a+b)*c = a*c + b*c mod q, plus the oracle on
     one prime row."""
     import oracle_lib as O
     args = (9, 2, 16, 576, 24, 65536)
-    g = gu.GpuCtx(*args)
+    g = gu.GpuCtx(*args, negacyclic=nc)
     try:
         q = g.prm
-        assert q.nttLen == 65536 and q.numCrtPrime == 32 and q.modLen == 32768
+        assert q.nttLen == 65536 and q.numCrtPrime == 32 and q.modLen == 32768 and g.nc == nc
         lvl = 0
         W, M, n = g.words(lvl), g.coeff_modulus(lvl), q.modLen
         a, av = O.random_raw(q.rawLen, n, W, M, 1)
@@ -319,6 +324,10 @@ def test_config3_full_size_properties(gu):
         X = g.ntt(ca, lvl)
         assert np.array_equal(g.intt(X, lvl), ca)
         assert np.array_equal(X[5], O.ntt_ext(ca[5], q.nttLen))
+        cb = g.crt(b, lvl)
+        pr = g.ct_intt(g.ct_mul(g.ct_ntt(ca, lvl), g.ct_ntt(cb, lvl), lvl), lvl, True)      # dense product rows vs the oracle
+        for i in (0, 13, 31):
+            assert np.array_equal(pr[i], O.negacyclic_mul_modp(ca[i], cb[i], int(g.primes[i]))), i
         one = O.ints_to_raw([1], q.rawLen, W)
         assert np.array_equal(g.mul_raw(a, one, lvl), a)
         k = 12345
@@ -338,7 +347,7 @@ def test_config3_full_size_properties(gu):
         g.close()
 
 
-@pytest.mark.parametrize("name", ["toy1155", "prince_small"])
+@pytest.mark.parametrize("name", ["toy1155", "prince_small", "pow2_32768"])
 def test_prime_range_entry_points(gu, name):
     """CRT-prime-sharded entry points (cuhe_hip_*_range / *_rows): two shards computed one after the other on one
     GPU and reassembled must equal the unsharded oracle result (the collective itself is covered by
@@ -365,7 +374,7 @@ def test_prime_range_entry_points(gu, name):
             crt_full = o.crt(raw, lvl)
             world = 2
             na = hb.ntt_rows(gu.to_dev(a)); nb = hb.ntt_rows(gu.to_dev(b))
-            assert np.array_equal(gu.host_u64(na), o.ntt(a))
+            if not g.nc: assert np.array_equal(gu.host_u64(na), o.ntt(a))
             # stage 1 per shard, then emulate the all-gather by concatenation
             crt_rows = []
             for r in range(world):
@@ -595,11 +604,11 @@ def test_reentrant_host_threads(gu):
         gu.ck(gu.lib.cuhe_hip_set_relin_lanes(-3))
         stacks = []
         for t in range(T):
-            na = gu.empty_u64(B2 * npr, q.nttLen); nb = gu.empty_u64(B2 * npr, q.nttLen)
+            na = gu.empty_u64(B2 * npr, g.ctlen); nb = gu.empty_u64(B2 * npr, g.ctlen)
             for i in range(B2):
                 d = bufs[t][i % REPS]
-                gu.ck(gu.lib.cuhe_hip_ntt(na[i * npr:].data_ptr(), d["ca"].data_ptr(), logq, 0, None))
-                gu.ck(gu.lib.cuhe_hip_ntt(nb[i * npr:].data_ptr(), d["cb"].data_ptr(), logq, 0, None))
+                gu.ck(gu.lib.cuhe_hip_ct_ntt(na[i * npr:].data_ptr(), d["ca"].data_ptr(), logq, 0, None))
+                gu.ck(gu.lib.cuhe_hip_ct_ntt(nb[i * npr:].data_ptr(), d["cb"].data_ptr(), logq, 0, None))
             stacks.append((na, nb, gu.empty_u32(B2 * npr, q.crtLen)))
         torch.cuda.synchronize()
         barrier2 = threading.Barrier(T)
@@ -656,7 +665,7 @@ def test_config4_relin_structured_keys_vs_python(gu):
         for lvl in (0, 5):
             ql, npr = g.coeff_modulus(lvl), g.np_(lvl)
             ct, cv = O.random_raw(q.rawLen, n, g.words(lvl), ql, 0xC400 + lvl)
-            got = g.intt_mod(g.relin(ct, lvl), lvl)                  # u32[npr][crtLen]
+            got = g.relin_crt(ct, lvl)                               # u32[npr][crtLen]
             # exact: (c * s mod x^n + 1) mod q_lvl, then its residues
             acc = [0] * n
             for e, v in terms:
@@ -675,9 +684,9 @@ def test_config4_relin_structured_keys_vs_python(gu):
 
 
 @pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 25, 25, 21845),
-                                  (5, 2, 1, 61, 20, 8191), (6, 2, 1, 61, 20, 8191)],
+                                  (5, 2, 1, 61, 20, 8191), (6, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
                          ids=["toy1155-generic", "pow2_16384-fused", "prince_ring-generic", "dhs_simple-141keys-lds144K",
-                              "w1-161keys-register-kernel"])
+                              "w1-161keys-register-kernel", "pow2_32768-negacyclic"])
 def test_mul_relin_batch_equals_single(gu, args):
     """cuhe_hip_mul_relin_batch (B independent cAnd + relin chains in one call: batch*np rows per stage, key values
     shared by four ciphertexts in the inner product) is bit-identical to B single-ciphertext sequences, which the other
@@ -703,10 +712,10 @@ def test_mul_relin_batch_equals_single(gu, args):
             single = [g.mul_relin_crt(a[i], b[i], lvl) for i in range(B)]
             if B == 1:
                 assert np.array_equal(single[0], o.mul_relin_crt(a[0], b[0], lvl, ek))      # the anchor itself, once
-            na = gu.empty_u64(B * npr, q.nttLen); nb = gu.empty_u64(B * npr, q.nttLen)
+            na = gu.empty_u64(B * npr, g.ctlen); nb = gu.empty_u64(B * npr, g.ctlen)
             for i in range(B):
-                gu.ck(gu.lib.cuhe_hip_ntt(na[i * npr:].data_ptr(), gu.to_dev(a[i]).data_ptr(), o.logq(lvl), 0, None))
-                gu.ck(gu.lib.cuhe_hip_ntt(nb[i * npr:].data_ptr(), gu.to_dev(b[i]).data_ptr(), o.logq(lvl), 0, None))
+                gu.ck(gu.lib.cuhe_hip_ct_ntt(na[i * npr:].data_ptr(), gu.to_dev(a[i]).data_ptr(), o.logq(lvl), 0, None))
+                gu.ck(gu.lib.cuhe_hip_ct_ntt(nb[i * npr:].data_ptr(), gu.to_dev(b[i]).data_ptr(), o.logq(lvl), 0, None))
             out = gu.empty_u32(B * npr, q.crtLen)
             gu.ck(gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, B, 0, None))
             got = gu.host_u32(out).reshape(B, npr, q.crtLen)
@@ -714,7 +723,7 @@ def test_mul_relin_batch_equals_single(gu, args):
                 assert np.array_equal(got[i], single[i]), (lvl, B, i)
             # cuhe_hip_relin_batch: relinearise the B results once more (CRT-domain input, in place) against the
             # single-ciphertext sequence icrt, relinearization, intt_mod
-            again = [g.intt_mod(g.relin(g.icrt(single[i], lvl), lvl), lvl) for i in range(B)]
+            again = [g.relin_crt(g.icrt(single[i], lvl), lvl) for i in range(B)]
             gu.ck(gu.lib.cuhe_hip_relin_batch(out.data_ptr(), out.data_ptr(), lvl, B, 0, None))
             got2 = gu.host_u32(out).reshape(B, npr, q.crtLen)
             for i in range(B):
@@ -727,8 +736,8 @@ def test_mul_relin_batch_equals_single(gu, args):
         g.close(); o.close()
 
 
-@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (5, 2, 1, 61, 20, 8191)],
-                         ids=["toy1155-generic", "pow2_16384-fused", "dhs_simple-prime_m"])
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "dhs_simple-prime_m", "pow2_32768-negacyclic"])
 def test_mul_raw_batch_equals_single(gu, args):
     """cuhe_hip_mul_raw_batch (B full multiplications raw -> raw per call) against the oracle's mulZZX-at-the-raw-level
     for every ciphertext of the batch, on the three reduction kinds, at two levels, with odd batch sizes."""
@@ -751,7 +760,8 @@ def test_mul_raw_batch_equals_single(gu, args):
         g.close(); o.close()
 
 
-@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384)], ids=["toy1155-generic", "pow2_16384-fused"])
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 48, 24, 32768)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "pow2_32768-negacyclic"])
 def test_array_gates_equal_single_gates(gu, args):
     """gates on arrays of ciphertexts (cuhe_hip_ntt_mul_pairs, intt_mod_batch, crt_mod_switch_batch, crt_combine) against the
     per-ciphertext entry points they stand for (ntt_mul, intt_mod, crt_mod_switch, crt_add / crt_add_int), which the
@@ -766,12 +776,12 @@ def test_array_gates_equal_single_gates(gu, args):
         cts = [_rand_crt(o, npr, 7000 + i) for i in range(B)]
         arr = gu.to_dev(np.concatenate(cts))                              # u32[B*np][crtLen]
         # forward transforms of the whole array, then products over index pairs
-        ntt = gu.empty_u64(B * npr, q.nttLen)
+        ntt = gu.empty_u64(B * npr, g.ctlen)
         gu.ck(gu.lib.cuhe_hip_ntt_rows(ntt.data_ptr(), arr.data_ptr(), B * npr, 0, None))
         pairs = [(0, 1), (2, 2), (4, 0), (3, 1)]
         ia = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=gu.DEV)
         ib = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=gu.DEV)
-        prod = gu.empty_u64(len(pairs) * npr, q.nttLen)
+        prod = gu.empty_u64(len(pairs) * npr, g.ctlen)
         gu.ck(gu.lib.cuhe_hip_ntt_mul_pairs(prod.data_ptr(), ntt.data_ptr(), ia.data_ptr(), ib.data_ptr(), len(pairs), npr, 0, None))
         red = gu.empty_u32(len(pairs) * npr, q.crtLen)
         gu.ck(gu.lib.cuhe_hip_intt_mod_batch(red.data_ptr(), prod.data_ptr(), lvl, len(pairs), 0, None))
@@ -822,3 +832,135 @@ def test_config2_roundtrip_8_primes(gu):
         assert np.array_equal(g.intt(X, 0), a)
     finally:
         g.close(); o.close()
+
+
+def test_negacyclic_equals_cyclic_representation(gu):
+    """x^16384 + 1 with 24-bit primes: the negacyclic ciphertext domain (transforms of modLen points, no reduction step,
+    keys of half the size) against the reference's cyclic representation forced on the same ring and against the oracle's
+    reference-shaped path: full multiply, multiply + relinearise, relinearisation alone, a round trip and an addition in
+    the ct domain, at the first and the last level."""
+    import oracle_lib as O
+    args = PSETS["pow2_32768"]
+    o = O.Ctx(*args)
+    res = {}
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE700 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        for nc in (True, False):
+            g = gu.GpuCtx(*args, negacyclic=nc)
+            try:
+                assert g.nc == nc and g.ctlen == (q.modLen if nc else q.nttLen)
+                g.init_relin(ek_raw)
+                for lvl in (0, q.depth - 1):
+                    npr, W, M = o.np_(lvl), o.words(lvl), o.coeff_modulus(lvl)
+                    a, _ = O.random_raw(q.rawLen, q.modLen, W, M, 0xA700 + lvl)
+                    b, _ = O.random_raw(q.rawLen, q.modLen, W, M, 0xB700 + lvl)
+                    ca, cb = _rand_crt(o, npr, 71 + lvl), _rand_crt(o, npr, 72 + lvl, full=True)      # full: every residue p - 1
+                    out = dict(mul=g.mul_raw(a, b, lvl), mulfull=g.mul_relin_crt(cb, cb, lvl), mr=g.mul_relin_crt(ca, cb, lvl),
+                               relin=g.relin_crt(a, lvl), rt=g.ct_intt(g.ct_ntt(ca, lvl), lvl, False),
+                               add=g.ct_intt(g.ct_add(g.ct_ntt(ca, lvl), g.ct_ntt(cb, lvl), lvl), lvl, False))
+                    if nc:
+                        assert np.array_equal(out["mul"], o.mul_raw(a, b, lvl))
+                        assert np.array_equal(out["mr"], o.mul_relin_crt(ca, cb, lvl, ek))
+                        assert np.array_equal(out["mulfull"], o.mul_relin_crt(cb, cb, lvl, ek))
+                        assert np.array_equal(out["relin"], o.intt_mod(o.relin(a, lvl, ek)))
+                        assert np.array_equal(out["rt"], ca) and np.array_equal(out["add"], o.crt_add(ca, cb))
+                        assert np.array_equal(g.mul_raw(a, b, lvl, cyclic_api=True), out["mul"])         # the reference-contract entry points still work
+                        res[lvl] = out
+                    else:
+                        for k, v in out.items():
+                            assert np.array_equal(v, res[lvl][k]), (k, lvl)
+            finally:
+                g.close()
+    finally:
+        o.close()
+
+
+def test_degree_65536_ring(gu):
+    """x^65536 + 1 (m = 131072, BASELINE config 4 read literally: N = 2^16, 48 CRT primes): beyond the reference's
+    65536-point limit, reachable only through 64K-point NEGACYCLIC transforms (primes of 23 bits: 2 n p^2 < P).
+    Dense random products against the oracle's negacyclic restatement on every prime; the full multiply and the
+    relinearisation against exact Python integers (sparse second operand / structured keys, as in
+    test_config4_relin_structured_keys_vs_python); the batched call against the single sequence; the cyclic entry points
+    must refuse."""
+    import oracle_lib as O
+    g = gu.GpuCtx(25, 2, 16, 552, 23, 131072)
+    try:
+        q = g.prm
+        assert g.nc and g.ctlen == 65536
+        assert (q.modLen, q.crtLen, q.nttLen, q.numCrtPrime, q.numEvalKey, q.logCrtPrime) == (65536, 65536, 65536, 48, 69, 23)
+        n, w, K = q.modLen, q.logRelin, q.numEvalKey
+        primes = g.crt_primes()
+        assert 2 * n * (max(primes) - 1) ** 2 < O.P
+        lib, ck = gu.lib, gu.ck
+        # ---- dense products per prime vs the oracle (level 0: 48 primes)
+        lvl = 0
+        npr, W, M = g.np_(lvl), g.words(lvl), g.coeff_modulus(lvl)
+        a, av = O.random_raw(q.rawLen, n, W, M, 0x6501)
+        b, bv = O.random_raw(q.rawLen, n, W, M, 0x6502)
+        ca, cb = g.crt(a, lvl), g.crt(b, lvl)
+        for i in (0, 7, 47):                                             # the CRT rows themselves, on a stride, vs Python
+            assert [int(v) for v in ca[i, ::4099]] == [x % primes[i] for x in av[::4099]]
+        prod = g.ct_intt(g.ct_mul(g.ct_ntt(ca, lvl), g.ct_ntt(cb, lvl), lvl), lvl, True)
+        for i in range(npr):
+            assert np.array_equal(prod[i], O.negacyclic_mul_modp(ca[i], cb[i], primes[i])), i
+        full = np.stack([np.full(n, p - 1, dtype=np.uint32) for p in primes[:npr]])          # largest magnitudes
+        pf = g.ct_intt(g.ct_mul(g.ct_ntt(full, lvl), g.ct_ntt(full, lvl), lvl), lvl, True)
+        for i in (0, 23, 47):
+            assert np.array_equal(pf[i], O.negacyclic_mul_modp(full[i], full[i], primes[i])), i
+        # ---- full multiply raw -> raw vs exact integers: b sparse
+        terms = [(0, 3), (1, M - 1), (40000, 0x1234567890ABCDEF % M), (n - 1, M // 3)]
+        bs = [0] * n
+        for e, v in terms: bs[e] = v
+        got = O.raw_to_ints(g.mul_raw(a, O.ints_to_raw(bs, q.rawLen, W), lvl), n)
+        acc = [0] * n
+        for e, v in terms:
+            for i in range(n):
+                k = i + e
+                if k < n: acc[k] += av[i] * v
+                else: acc[k - n] -= av[i] * v
+        assert got == [x % M for x in acc]
+        # ---- relinearisation with structured keys ek_j = s * 2^(w j) mod q0, s sparse: the key-switch sum is c * s
+        q0 = g.coeff_modulus(0)
+        rng = np.random.default_rng(65)
+        sterms = [(int(e), int.from_bytes(rng.bytes(150), "little") % q0) for e in (0, 5, 33333, n - 1)]
+        W0 = g.words(0)
+        ek_raw = np.zeros((K, q.rawLen, W0), dtype=np.uint32)
+        for j in range(K):
+            for e, v in sterms:
+                ek_raw[j, e] = np.frombuffer(((v << (w * j)) % q0).to_bytes(4 * W0, "little"), dtype=np.uint32)
+        g.init_relin(ek_raw)
+        for lvl in (0, 7):
+            ql, npr = g.coeff_modulus(lvl), g.np_(lvl)
+            ct, cv = O.random_raw(q.rawLen, n, g.words(lvl), ql, 0x6510 + lvl)
+            got = g.relin_crt(ct, lvl)
+            acc = [0] * n
+            for e, v in sterms:
+                for i in range(n):
+                    k = i + e
+                    if k < n: acc[k] += cv[i] * v
+                    else: acc[k - n] -= cv[i] * v
+            for t in (0, npr // 2, npr - 1):
+                assert [int(x) for x in got[t]] == [(r % ql) % primes[t] for r in acc], (lvl, t)
+        # ---- batched multiply + relinearise equals the single sequence
+        lvl, B = 1, 3
+        npr = g.np_(lvl)
+        xs = [g.crt(O.random_raw(q.rawLen, n, g.words(lvl), g.coeff_modulus(lvl), 0x6520 + i)[0], lvl) for i in range(2 * B)]
+        single = [g.mul_relin_crt(xs[2 * i], xs[2 * i + 1], lvl) for i in range(B)]
+        na, nb = gu.empty_u64(B * npr, n), gu.empty_u64(B * npr, n)
+        for i in range(B):
+            ck(lib.cuhe_hip_ct_ntt(na[i * npr:].data_ptr(), gu.to_dev(xs[2 * i]).data_ptr(), g.logq(lvl), 0, None))
+            ck(lib.cuhe_hip_ct_ntt(nb[i * npr:].data_ptr(), gu.to_dev(xs[2 * i + 1]).data_ptr(), g.logq(lvl), 0, None))
+        out = gu.empty_u32(B * npr, q.crtLen)
+        ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, B, 0, None))
+        got = gu.host_u32(out).reshape(B, npr, q.crtLen)
+        for i in range(B):
+            assert np.array_equal(got[i], single[i]), i
+        # ---- the reference's cyclic transforms do not exist on this ring
+        assert lib.cuhe_hip_ntt(na.data_ptr(), gu.to_dev(xs[0]).data_ptr(), g.logq(lvl), 0, None) != 0
+        assert b"negacyclic" in lib.cuhe_hip_last_error()
+        assert lib.cuhe_hip_intt_mod(out.data_ptr(), na.data_ptr(), g.logq(lvl), 0, None) != 0
+    finally:
+        g.close()

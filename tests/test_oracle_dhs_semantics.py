@@ -93,54 +93,76 @@ def _inverse_mod_prime(f, phi, p):
     return [v * g % p for v in t[:n]]
 
 
-def test_oracle_stages_carry_a_homomorphic_and_to_the_right_plaintext():
-    d, pm, w, mn, cut, m = 3, 2, 8, 40, 20, 1155
-    o = O.Ctx(d, pm, w, mn, cut, m)
-    try:
+class Scheme:
+    """a DHS / LTV key pair, evaluation keys, encryption and decryption with Python integers only (nothing from oracle/
+    except the parameter set and the CRT primes the context reports): examples/DHS/DHS.cu keygen / encrypt / decrypt"""
+
+    def __init__(self, o, seed):
         q = o.prm
-        n, K = q.modLen, q.numEvalKey
-        phi = _cyclotomic(m)
-        assert len(phi) == n + 1 and phi[-1] == 1
-        q0, q1 = o.coeff_modulus(0), o.coeff_modulus(1)
-        # the CRT primes of level 0: q0 is their product, level 1 drops the last one
-        primes, rest, last = [], q0, q0 // q1
-        cand = 1 << 21
-        while rest > 1:
-            cand -= 1
-            if rest % cand == 0:
-                primes.append(cand); rest //= cand
-        assert last in primes and len(primes) == q.numCrtPrime
-        rnd = random.Random(20260926)
-        tern = lambda: [rnd.choice((-1, 0, 1)) for _ in range(n)]
+        self.o, self.n, self.K, self.w = o, q.modLen, q.numEvalKey, q.logRelin
+        n = self.n
+        self.phi = _cyclotomic(q.mSize)
+        assert len(self.phi) == n + 1 and self.phi[-1] == 1
+        self.qs = [o.coeff_modulus(l) for l in range(q.depth)]
+        q0 = self.qs[0]
+        primes = [int(p) for p in o.primes]
+        prod = 1
+        for p in primes: prod *= p
+        assert prod == q0 and len(primes) == q.numCrtPrime
+        self.rnd = rnd = random.Random(seed)
+        tern = self.tern = lambda: [rnd.choice((-1, 0, 1)) for _ in range(n)]
         while True:                                             # f = 2 f' + 1 invertible modulo every prime
             f = [2 * v for v in tern()]; f[0] += 1
-            invs = [_inverse_mod_prime(f, phi, p) for p in primes]
+            invs = [_inverse_mod_prime(f, self.phi, p) for p in primes]
             if all(v is not None for v in invs):
                 break
+        self.f = f
         finv = [0] * n
         for p, row in zip(primes, invs):
             mi = q0 // p
             lift = mi * pow(mi % p, p - 2, p)
             for k in range(n):
                 finv[k] = (finv[k] + lift * row[k]) % q0
-        assert _polymul_mod([v % q0 for v in f], finv, phi, q0) == [1] + [0] * (n - 1)
-        pk = [2 * v % q0 for v in _polymul_mod([v % q0 for v in tern()], finv, phi, q0)]
-        enc = lambda msg, mod: [(a + 2 * e + b) % mod for a, e, b in zip(_polymul_mod(pk, [v % mod for v in tern()], phi, mod), tern(), msg)]
-        ek = [[(a + (fk << (w * j))) % q0 for a, fk in zip(enc([0] * n, q0), f)] for j in range(K)]
-        ek_raw = np.stack([O.ints_to_raw(e, q.rawLen, o.words(0)) for e in ek])
-        keys = o.init_relin(ek_raw)
-        m1 = [rnd.randrange(2) for _ in range(n)]; m2 = [rnd.randrange(2) for _ in range(n)]
-        c1, c2 = enc(m1, q0), enc(m2, q0)
-        a = o.crt(O.ints_to_raw(c1, q.rawLen, o.words(0)), 0)
-        b = o.crt(O.ints_to_raw(c2, q.rawLen, o.words(0)), 0)
-        prod = o.mul_relin_crt(a, b, 0, keys)                    # cAnd ; relin   (CRT rows, level 0)
+        assert _polymul_mod([v % q0 for v in f], finv, self.phi, q0) == [1] + [0] * (n - 1)
+        self.pk = [2 * v % q0 for v in _polymul_mod([v % q0 for v in tern()], finv, self.phi, q0)]
+        ek = [[(a + (fk << (self.w * j))) % q0 for a, fk in zip(self.enc([0] * n, 0), f)] for j in range(self.K)]
+        self.ek_raw = np.stack([O.ints_to_raw(e, q.rawLen, o.words(0)) for e in ek])
+        self.keys = o.init_relin(self.ek_raw)
+
+    def enc(self, msg, lvl):
+        """coefficients of the ciphertext of the message polynomial `msg` at level lvl"""
+        mod = self.qs[lvl]
+        hs = _polymul_mod([v % mod for v in self.pk], [v % mod for v in self.tern()], self.phi, mod)
+        return [(a + 2 * e + b) % mod for a, e, b in zip(hs, self.tern(), msg)]
+
+    def enc_crt(self, msg, lvl):
+        q = self.o.prm
+        return self.o.crt(O.ints_to_raw(self.enc(msg, lvl), q.rawLen, self.o.words(lvl)), lvl)
+
+    def dec_crt(self, crt_rows, lvl):
+        """(message polynomial mod 2, largest |noise| coefficient) of CRT rows of a level-lvl ciphertext that went through
+        `mults` multiplications: c * f^(degree) -- here always degree 1 after relinearisation"""
+        mod = self.qs[lvl]
+        c = O.raw_to_ints(self.o.icrt(crt_rows, lvl), self.n)
+        dec = _polymul_mod(c, [v % mod for v in self.f], self.phi, mod)
+        cen = [v - mod if v > (mod - 1) // 2 else v for v in dec]
+        return [v % 2 for v in cen], max(abs(v) for v in cen)
+
+
+def test_oracle_stages_carry_a_homomorphic_and_to_the_right_plaintext():
+    d, pm, w, mn, cut, m = 3, 2, 8, 40, 20, 1155
+    o = O.Ctx(d, pm, w, mn, cut, m)
+    try:
+        S = Scheme(o, 20260926)
+        n, q1 = S.n, S.qs[1]
+        m1 = [S.rnd.randrange(2) for _ in range(n)]; m2 = [S.rnd.randrange(2) for _ in range(n)]
+        a, b = S.enc_crt(m1, 0), S.enc_crt(m2, 0)
+        prod = o.mul_relin_crt(a, b, 0, S.keys)                  # cAnd ; relin   (CRT rows, level 0)
         low = o.modswitch(prod)                                  # modSwitch      (level 1)
-        c = O.raw_to_ints(o.icrt(low, 1), n)
-        dec = _polymul_mod(c, [v % q1 for v in f], phi, q1)
-        got = [(v - q1 if v > (q1 - 1) // 2 else v) % 2 for v in dec]
-        want = [v % 2 for v in _polymul_mod(m1, m2, phi, 1 << 40)]
+        got, noise = S.dec_crt(low, 1)
+        want = [v % 2 for v in _polymul_mod(m1, m2, S.phi, 1 << 40)]
         assert got == want
         # and the noise is where the scheme says it is: far below q1 / 2
-        assert max(abs(v - q1 if v > q1 // 2 else v) for v in dec) < q1 >> 12
+        assert noise < q1 >> 12
     finally:
         o.close()

@@ -56,7 +56,7 @@ def test_ntt_fast_equals_definition_16k():
     assert np.array_equal(O.ntt_naive(x, 16384), O.ntt_ext(x, 16384))
 
 
-@pytest.mark.parametrize("name", ["dhs_simple", "prince", "toy1155", "pow2_16384", "c3_65536", "c4_65536"])
+@pytest.mark.parametrize("name", ["dhs_simple", "prince", "toy1155", "pow2_16384", "c3_65536", "c4_65536", "c1_pow2_1prime", "c1_prime_m_1prime"])
 def test_params_and_primes(golden, name):
     g = golden("params.json")[name]
     q = O.set_param(*g["args"])
@@ -148,6 +148,15 @@ def test_pipeline_toy(golden):
 
 def test_pipeline_pow2(golden):
     _pipeline(golden, "pow2_16384", "pipeline_pow2_16384.json")
+
+
+@pytest.mark.parametrize("name", ["c1_pow2_1prime", "c1_prime_m_1prime"])
+def test_pipeline_config1_single_prime(golden, name):
+    """BASELINE config 1 exactly: N = 2^13, ONE CRT prime (p = 2097143), host only: the polynomial product on
+    x^8192 + 1 and on Phi_8191 against the pure-Python fixture (examples/DHS/DHS.cu:219-221 meaning)"""
+    g = golden("params.json")[name]
+    assert g["primes"] == [2097143] and g["params"]["numCrtPrime"] == 1 and g["params"]["modLen2"] == 8192
+    _pipeline(golden, name, "pipeline_%s.json" % name)
 
 
 def test_pipeline_dhs(golden):
