@@ -4,8 +4,9 @@
 Metric (BASELINE.json): 64K-point forward NTT/s per node (u32[32768] zero-padded
 input -> u64[65536] natural-order output over P = 2^64-2^32+1: the contract of
 the reference's ntt_{1,2,3}_64k kernels that doc/Perf_NTT.txt times), with the
-HBM roofline fraction of that transform and, as a second figure in the same
-JSON line, DHS ciphertext mul+relin/s.
+HBM roofline fraction of that transform and, as further figures in the same
+JSON line, DHS ciphertext mul+relin/s (BASELINE config 4), the full multiply
+(config 3) and the homomorphic PRINCE block (config 5).
 
 A "step" = one pass of the hot path over one batch of `--batch` independent
 64K-point transforms, inputs already resident in HBM.  One process per GPU
@@ -14,11 +15,15 @@ transforms are independent, so the path shards with no data-path collective).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --perf-table profiles/rNN_perf_ntt_table.txt      # the table of doc/Perf_NTT.txt on this GPU
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,12 +33,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+RING_PARAMS = {"2^15": (25, 2, 16, 576, 24, 65536),       # x^32768 + 1: 48 primes < 2^24, 72 keys (the reference's largest ring)
+               "2^16": (25, 2, 16, 552, 23, 131072)}      # x^65536 + 1: BASELINE config 4 read literally, 48 primes < 2^23, 69 keys
+
+
+def kernel_sha16():
+    """identifies the transform kernels a committed PMC figure was measured on"""
+    h = hashlib.sha256()
+    for f in ("modp.cuh", "ntt_kernels.cuh"):
+        h.update(open(os.path.join(ROOT, "cuhe_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    # default: ~1 s of GPU time in the timed region (300 steps x ~3.3 ms), so that samplers outside the process see it
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     # 8192 transforms (4 GiB of output) per step: a step lasts ~4 ms, so that even a 5-step timed region is long enough
     # for the clocks to settle (the chip needs tens of ms of load; with 1024 per step a 10-step run reads 20 % low)
@@ -49,11 +65,15 @@ def main():
     ap.add_argument("--no-mulrelin", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--ring", choices=["2^15", "2^16"], default="2^15",
+    ap.add_argument("--ring", choices=list(RING_PARAMS), default="2^15",
                     help="ciphertext mul+relin leg: x^32768+1 (the reference's largest ring, 64K-point cyclic or 32K-point negacyclic "
-                         "transforms) or x^65536+1 (BASELINE config 4 read literally: 64K-point negacyclic transforms, 23-bit primes)")
+                         "transforms) or x^65536+1 (BASELINE config 4 read literally: 64K-point negacyclic transforms, 23-bit primes); "
+                         "the other ring is reported beside it unless --one-ring")
+    ap.add_argument("--one-ring", action="store_true")
+    ap.add_argument("--no-prince", action="store_true")
+    ap.add_argument("--perf-table", default="", help="write the bundle-size table of doc/Perf_NTT.txt (tests/test_ntt.cu:140-151) to this file and exit")
     args = ap.parse_args()
-    args.relin_params = (25, 2, 16, 576, 24, 65536) if args.ring == "2^15" else (25, 2, 16, 552, 23, 131072)
+    args.relin_params = RING_PARAMS[args.ring]
 
     import numpy as np
     import torch
@@ -62,7 +82,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("CUHE_BENCH_SINGLE_DEVICE") == "1":
+    single_dev = os.environ.get("CUHE_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
         local_rank = 0                      # test hook: every rank on device 0 (use with --dist-backend gloo)
     if world > 1:
         if args.dist_backend == "nccl":
@@ -81,6 +102,10 @@ def main():
     if args.chunk:
         ck(lib.cuhe_hip_set_ntt_chunk(args.chunk))
     ck(lib.cuhe_hip_set_ntt_overlap(args.overlap))
+
+    if args.perf_table:
+        perf_table(lib, ck, torch, dev, args.perf_table)
+        return
 
     L, B = args.length, args.batch
     # synthetic input: uniform 32-bit words, generated on the device
@@ -116,7 +141,7 @@ def main():
     sharded = None
     if world > 1 and not args.no_mulrelin:
         try:
-            sharded = bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world)
+            sharded = bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args)
         except Exception as ex:                      # never lose the headline line to the secondary figure
             sharded = {"error": repr(ex)[:300]}
         ck(lib.cuhe_hip_ntt_prepare(L, 0))
@@ -128,7 +153,7 @@ def main():
         barrier()
         mr, err = None, None
         try:
-            mr = bench_mulrelin(lib, ck, torch, np, dev, args)
+            mr = bench_mulrelin(lib, ck, torch, np, dev, args, args.relin_params)
             vals = [mr["value"], (mr["batched"] or {}).get("value", 0.0), (mr["concurrent"] or {}).get("value", 0.0), 1.0]
         except Exception as ex:                      # every rank still joins the reduction below
             err, vals = repr(ex)[:300], [0.0, 0.0, 0.0, 0.0]
@@ -137,6 +162,17 @@ def main():
         replicated = {"unit": "mul+relin/s, all GPUs (independent ciphertexts per GPU, keys replicated)", "one_at_a_time": round(float(v[0]), 1),
                       "batched": round(float(v[1]), 1), "concurrent": round(float(v[2]), 1), "ranks_reporting": int(v[3]), "rank0": mr if err is None else {"error": err}}
         ck(lib.cuhe_hip_ntt_prepare(L, 0))
+
+    # ---- homomorphic PRINCE (BASELINE config 5) across the N GPUs of this node: rank 0 runs the in-process multi-device
+    # driver (one host thread per GPU, examples/Prince/Prince.cu:194-200) while the other ranks wait
+    prince = None
+    if not args.no_prince:
+        if world > 1:
+            barrier()
+        if rank == 0:
+            prince = bench_prince(world, single_dev)
+        if world > 1:
+            barrier()
 
     out = None
     if rank == 0:
@@ -152,34 +188,36 @@ def main():
         # bracket the pipelined region on the launch stream; the serial per-pass durations are reported beside it.
         pair_s = mst.value * 1e-3
         achieved = n_tr * alg_bytes / pair_s / 1e9
-        # traffic: corrected FETCH_SIZE + WRITE_SIZE per launch pair from the committed rocprofv3 PMC passes of this
-        # same command (profiles/traffic_r*.json); PMC collection cannot run inside the timed process.
-        traffic = None
         per_launch = min(B, args.chunk if args.chunk else (256 << 20) // (L * 8))     # transforms per launch pair (library default: 256 MiB slab)
+        # PMC-derived figures (HBM-side bytes, VALU lane-instructions per transform) cannot be collected inside the timed
+        # process: they come from the committed rocprofv3 passes of this same command (profiles/traffic_r*.json), and only
+        # if that file was measured on the kernels that are running now (hash of the kernel sources); otherwise null.
+        traffic, lane_instr, pmc_note = None, None, "no profiles/traffic_r*.json for this transform length"
         try:
-            import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
             if tf and L == 65536:
-                traffic = json.load(open(tf[-1]))["bytes_per_transform"] * per_launch
-        except Exception:
-            traffic = None
+                rec = json.load(open(tf[-1]))
+                if rec.get("kernel_sha16") == kernel_sha16():
+                    traffic = rec["bytes_per_transform"] * per_launch
+                    lane_instr = rec.get("valu_lane_instructions_per_transform")
+                    pmc_note = "HBM-side bytes per launch pair (%d transforms) from %s; algorithmic = %d" % (per_launch, os.path.basename(tf[-1]), per_launch * alg_bytes)
+                else:
+                    pmc_note = "%s was measured on other kernel sources (%s, now %s): re-run tools/profile_final.sh" % (os.path.basename(tf[-1]), rec.get("kernel_sha16"), kernel_sha16())
+        except Exception as ex:
+            pmc_note = "traffic file unreadable: %r" % (ex,)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_note": "HBM-side bytes per launch pair (%d transforms) from profiles/traffic_r*.json; algorithmic = %d" % (per_launch, per_launch * alg_bytes),
-                    "kernel": "ntt_pass1w<16,0> + ntt_pass2w<16,0> (wave-split forms; one transform = one launch pair)",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": pmc_note,
+                    "kernel": "ntt_pass1w<16,0> + ntt_pass2w<16,0> (one transform = one launch pair)", "kernel_sha16": kernel_sha16(),
                     "algorithmic_bytes_per_transform": alg_bytes,
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),
                     "pass1_ms_per_batch": round(ms1.value / iters, 4), "pass2_ms_per_batch": round(ms2.value / iters, 4)}
-        if L == 65536:
-            # the limiter that actually binds: the pair executes 10.33 M VALU lane-instructions per
-            # transform (SQ_INSTS_VALU x 64, profiles/r01_final5_ntt64k_pmc.txt); every instruction of the mix issues at
-            # ~60 lanes/clk/CU (profiles/r01_ubench_valu.txt), i.e. 256 CU x 64 lanes x clock lane-instructions/s
-            lane_instr = 10.33e6
+        if lane_instr:
+            # the limiter that actually binds: integer VALU issue under the chip's power limit.  Dense
+            # streams of these instructions saturate near 36.5 T lane-instructions/s (profiles/r02_valu_cost_model.txt)
             got = n_tr * lane_instr / pair_s / 1e12
             roofline["valu_ceiling"] = {"lane_instructions_per_transform": lane_instr, "achieved_T_per_s": round(got, 2),
-                                        "peak_T_per_s_at_2.4GHz": 39.3, "frac_of_2.4GHz_peak": round(got / 39.3, 3),
-                                        "note": "under this instruction mix the chip settles near 1.8 GHz "
-                                                "(profiles/r01_effective_clock.txt): ~29 T/s sustained"}
+                                        "dense_stream_ceiling_T_per_s": 36.5, "frac_of_dense_stream_ceiling": round(got / 36.5, 3),
+                                        "note": "ceiling = pure v_lshl_add_u64 / v_mad_u64_u32 / v_cmp_u64 streams at 4 waves per SIMD (power-limited clock)"}
 
         # measured device-to-device copy ceiling of this box: 1 GiB read + 1 GiB written per copy
         ca = torch.empty(1 << 28, dtype=torch.int32, device=dev); cb = torch.empty_like(ca)
@@ -214,9 +252,15 @@ def main():
                    "sample": "%d 64K-point forward transforms, oracle radix-2 NTT (u128 %% P), OpenMP over transforms, %.1f s"
                              % (sample, cdt)}
 
-        mulrelin = mulfull = None
+        mulrelin = mulrelin2 = mulfull = None
         if not args.no_mulrelin and world == 1:
-            mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args)
+            mulrelin = bench_mulrelin(lib, ck, torch, np, dev, args, args.relin_params)
+            if not args.one_ring and not args.cyclic:
+                other = [k for k in RING_PARAMS if k != args.ring][0]
+                try:
+                    mulrelin2 = bench_mulrelin(lib, ck, torch, np, dev, args, RING_PARAMS[other])
+                except Exception as ex:
+                    mulrelin2 = {"error": repr(ex)[:300]}
             mulfull = bench_mul_full(lib, ck, torch, np, dev, with_cpu=not args.no_cpu, batch=args.mul_batch, cyclic=args.cyclic)
 
         out = {
@@ -233,7 +277,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
                                          "source": "doc/Perf_NTT.txt:14 (bundle 512)"},
-            "mul_relin": mulrelin, "mul_relin_sharded": sharded, "mul_relin_replicated": replicated, "mul_full": mulfull,
+            "mul_relin": mulrelin, "mul_relin_other_ring": mulrelin2, "mul_relin_sharded": sharded, "mul_relin_replicated": replicated,
+            "mul_full": mulfull, "prince": prince,
         }
     if world > 1:
         dist.barrier()
@@ -242,12 +287,73 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
-    """primes of ONE ciphertext sharded over the ranks, a single RCCL all-gather (CRT rows before ICRT)
-    per multiply+relinearise; value = multiplies per second of the whole job (max time over ranks)."""
+def perf_table(lib, ck, torch, dev, path):
+    """doc/Perf_NTT.txt on this GPU: ms per single forward transform when `bundle` transforms share a launch pair, bundle
+    1 ... 512, lengths 16K / 32K / 64K, 1024 transforms per measurement on consecutive slabs (tests/test_ntt.cu:67-100,140-151)."""
+    cnt = 1024
+    ref = {1: (0.0486284, 0.051598, 0.064822), 512: (0.00407564, 0.00804859, 0.0226647)}     # doc/Perf_NTT.txt:5,14
+    rows = []
+    lens = (16384, 32768, 65536)
+    for L in lens:
+        ck(lib.cuhe_hip_ntt_prepare(L, 0))
+    src = {L: torch.randint(-(1 << 31), (1 << 31) - 1, (cnt, L // 2), dtype=torch.int32, device=dev) for L in lens}
+    dst = {L: torch.empty((cnt, L), dtype=torch.int64, device=dev) for L in lens}
+    for bundle in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
+        row = [bundle]
+        for L in lens:
+            s, d = src[L], dst[L]
+
+            def run():
+                for b0 in range(0, cnt, bundle):
+                    ck(lib.cuhe_hip_ntt_fwd_batched(d[b0:].data_ptr(), s[b0:].data_ptr(), L, bundle, L // 2, 0, None))
+            run(); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter(); run(); torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / cnt * 1e3)
+            row.append(best)
+        rows.append(row)
+    with open(path, "w") as f:
+        f.write("# forward NTT (u32 half-length input -> u64 output), ms per single transform with `Num` transforms per launch pair;\n")
+        f.write("# 1024 transforms per measurement on consecutive slabs, host launch loop + device time, best of 3 (bench.py --perf-table);\n")
+        f.write("# the shape of the reference's doc/Perf_NTT.txt (tests/test_ntt.cu:140-151; its hardware is not stated):\n")
+        f.write("#   reference bundle 1:   16K %.7f  32K %.7f  64K %.7f\n#   reference bundle 512: 16K %.7f  32K %.7f  64K %.7f\n" % (ref[1] + ref[512]))
+        f.write("%-6s %-14s %-14s %-14s\n" % ("Num", "16K", "32K", "64K"))
+        for r in rows:
+            f.write("%-6d %-14.7f %-14.7f %-14.7f\n" % tuple(r))
+    print(open(path).read())
+
+
+def bench_prince(world, single_dev):
+    """BASELINE config 5: wall clock of one homomorphic PRINCE block (examples/Prince/Prince.cu:83-87 times princeEncrypt)
+    and its known answer (Prince.cu:96), gates on arrays of ciphertexts, S-boxes of a layer spread over `world` GPUs by
+    the in-process multi-device driver (tests/cxx/test_prince_arrays_cxx.cpp)."""
+    try:
+        exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_arrays_cxx")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cuhe_amd", "cxx"), "-s", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        cmd = [exe, "--no-round-checks", "--async", "--json", "--devices", str(world)] + (["--virtual"] if single_dev and world > 1 else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
+        rec = json.loads(line[-1])
+        return {"value": rec["prince_seconds"], "unit": "s per PRINCE block (64 ciphertext bits, 1920 cAnd, 1152 relin, 24 levels)", "n_gpus": rec["devices"],
+                "virtual_devices": rec["virtual"], "known_answer": rec["kat"], "known_answer_ok": rec["kat_ok"],
+                "params": "CuDHS(25,2,16,25,25,21845): n=16384, 32K-point transforms, 25 -> 1 primes, 40 keys",
+                "mode": "CuCtxtArray gates, asynchronous, one host thread per GPU (Prince.cu:194-200)"}
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
+
+
+def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
+    """primes of ONE ciphertext sharded over the ranks, one all-gather (CRT rows before ICRT) per
+    multiply+relinearise; value = multiplies per second of the whole job (max time over ranks).  The whole chain, RCCL
+    all-gather included, is one C-ABI call per multiply (cuhe_hip_mul_relin_sharded) enqueued on the compute stream;
+    if the in-library communicator cannot be made (e.g. every rank on one device in the gloo smoke test) the exchange
+    falls back to torch.distributed around the same stage functions (cuhe_amd/sharded.py)."""
     from cuhe_amd import capi
     from cuhe_amd.sharded import HipBackend, ShardedMulRelin
-    d, p, w, mn, cut, m = 25, 2, 16, 576, 24, 65536
+    d, p, w, mn, cut, m = args.relin_params
     # local set-up first; the ranks then agree (one all-reduce) that everybody is ready before the first data-path
     # collective, so that a local failure (e.g. out of memory) cannot leave the others hanging in the all-gather
     ready, err = 1, None
@@ -263,9 +369,10 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
         hb = HipBackend()
         sh = ShardedMulRelin(hb, 0, rank, world)
         gen = torch.Generator(device=dev); gen.manual_seed(5)
-        a = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
-        b = torch.randint(0, 1 << 24, (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+        a = torch.randint(0, 1 << (q.logCrtPrime - 1), (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+        b = torch.randint(0, 1 << (q.logCrtPrime - 1), (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
         na = hb.ntt_rows(sh.own(a).contiguous()); nb = hb.ntt_rows(sh.own(b).contiguous())
+        outc = torch.zeros((sh.count, q.crtLen), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
     except Exception as ex:
         ready, err = 0, repr(ex)[:200]
@@ -274,22 +381,53 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world):
     if int(flag.item()) == 0:
         lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
         return {"error": "set-up failed on at least one rank" + (": " + err if err else "")}
+    # in-library communicator: rank 0 makes the id, torch.distributed carries the 128 bytes
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    ok = 1
+    if rank == 0:
+        uid = (C.c_uint8 * 128)()
+        if lib.cuhe_hip_comm_unique_id(uid) == 0:
+            idt = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+        else:
+            ok = 0
+    dist.broadcast(idt, 0)
+    if ok:
+        uid = (C.c_uint8 * 128)(*[int(v) for v in idt.cpu().tolist()])
+        ok = 1 if lib.cuhe_hip_comm_init(world, rank, uid) == 0 else 0
+    comm_err = None if ok else lib.cuhe_hip_last_error().decode()[:200]
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    in_library = int(flag.item()) == 1
+    if not in_library:
+        lib.cuhe_hip_comm_destroy()
+
+    def one():
+        if in_library:
+            ck(lib.cuhe_hip_mul_relin_sharded(outc.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, 0, None))
+            return outc
+        return sh.mul_relin(na, nb)
+    first = one().clone()
+    if in_library:                                     # same rows through the torch.distributed exchange: must agree
+        assert torch.equal(first, sh.mul_relin(na, nb)), "in-library all-gather differs from the torch.distributed path"
     for _ in range(3):
-        sh.mul_relin(na, nb)
+        one()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
-        sh.mul_relin(na, nb)
+        one()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    lib.cuhe_hip_comm_destroy()
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s (one ciphertext, primes sharded)", "ms": round(dt * 1e3, 3),
-            "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "nttLen": q.nttLen,
-            "collective": "1 all-gather of %d B per rank per multiply (RCCL)" % (sh.count * q.crtLen * 4)}
+            "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "ring_degree": q.modLen,
+            "exchange": "RCCL group of broadcasts inside cuhe_hip_mul_relin_sharded, on the compute stream" if in_library
+                        else "torch.distributed all-gather around the C-ABI stages (in-library communicator unavailable: %s)" % comm_err,
+            "collective": "1 all-gather of %d B per rank per multiply" % (sh.count * q.crtLen * 4)}
 
 
 def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16, cyclic=False):
@@ -355,24 +493,40 @@ def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16, cyclic=Fals
            "params": {"setParameters": [d, p, w, mn, cut, m], "numCrtPrime": npn, "transform": rep, "coeff_words": W},
            "transforms_per_multiply": 3 * npn, "batched": batched}
     if with_cpu:
-        # the same multiply on ONE host core through the oracle (checker + reported CPU baseline, never the product path)
+        # the same multiply on the host through the oracle with OpenMP over the CRT primes on all cores (checker + reported
+        # CPU baseline, never the product path), and -- when the box has libgmp -- the way the reference's host library does
+        # it: ONE big-integer multiplication of Kronecker-packed operands (NTL, which the reference calls at
+        # examples/DHS/DHS.cu:219-221, is not installed in this image; it builds on GMP)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         o = O.Ctx(d, p, w, mn, cut, m)
+        q0 = o.coeff_modulus(0)
+        used = O.set_threads(0)
+        o.mul_raw(ha, hb, 0)                              # warm-up (thread pool, page faults)
         t1 = time.perf_counter()
         want = o.mul_raw(ha, hb, 0)
         cdt = time.perf_counter() - t1
+        O.set_threads(1)
         o.close()
         assert np.array_equal(got, want), "GPU full multiply differs from the oracle"
-        res["cpu_baseline"] = {"value": round(1.0 / cdt, 3), "unit": "full multiplies/s", "cores": 1, "kind": "port",
-                               "sample": "1 multiply (N=2^15, 32 primes) through oracle/oracle.c, %.1f s" % cdt}
+        res["cpu_baseline"] = {"value": round(1.0 / cdt, 3), "unit": "full multiplies/s", "cores": used, "kind": "port",
+                               "sample": "1 multiply (N=2^15, 32 primes) through oracle/oracle.c, OpenMP over the CRT primes, %.2f s" % cdt}
+        t1 = time.perf_counter()
+        gm = O.gmp_mul_xn1(ha, hb, q0)
+        gdt = time.perf_counter() - t1
+        res["cpu_baseline_gmp"] = None
+        if gm is not None:
+            assert np.array_equal(gm, want), "GMP product differs from the oracle"
+            res["cpu_baseline_gmp"] = {"value": round(1.0 / gdt, 3), "unit": "full multiplies/s", "cores": 1, "kind": "port",
+                                       "sample": "1 multiply: Kronecker substitution + one mpz_mul + coefficient reduction (libgmp opened at run time; "
+                                                 "stand-in for NTL's ZZX multiply, which is not installed), %.2f s" % gdt}
     return res
 
 
-def bench_mulrelin(lib, ck, torch, np, dev, args):
+def bench_mulrelin(lib, ck, torch, np, dev, args, params):
     """DHS ciphertext multiply + relinearise per second on 64K-point transforms (BASELINE config 4 shape:
     48 CRT primes < 2^24, w = 16).  NTT-domain operands -> reduced CRT-domain result, keys resident in HBM."""
-    d, p, w, mn, cut, m = args.relin_params
+    d, p, w, mn, cut, m = params
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
     ck(lib.cuhe_hip_set_negacyclic(0 if args.cyclic else -1))
     ck(lib.cuhe_hip_set_parameters(d, p, w, mn, cut, m))

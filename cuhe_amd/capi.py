@@ -115,6 +115,15 @@ SIGNATURES = {
     "cuhe_hip_crt_range": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "cuhe_hip_ntt_fwd_batched": (i32, [vp, vp, i32, i32, lng, i32, vp]),
     "cuhe_hip_ntt_inv_batched": (i32, [vp, vp, i32, i32, lng, i32, i32, i32, vp]),
+    "cuhe_hip_shard_bounds": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "cuhe_hip_comm_unique_id": (i32, [vp]),
+    "cuhe_hip_comm_init": (i32, [i32, i32, vp]),
+    "cuhe_hip_comm_destroy": (i32, []),
+    "cuhe_hip_comm_size": (i32, []),
+    "cuhe_hip_comm_rank": (i32, []),
+    "cuhe_hip_allgather_rows": (i32, [vp, i32, i32, vp]),
+    "cuhe_hip_mul_relin_sharded": (i32, [vp, vp, vp, i32, i32, vp]),
+    "cuhe_hip_mul_relin_sharded_inproc": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_ntt_prepare": (i32, [i32, i32]),
     "cuhe_hip_set_ntt_chunk": (i32, [i32]),
     "cuhe_hip_set_ntt_overlap": (i32, [i32]),

@@ -1,0 +1,58 @@
+// comm.hpp -- the one exchange of the CRT-prime-sharded multiply + relinearise: an all-gather of CRT rows
+// before ICRT, behind the C ABI so that it is enqueued on the caller's compute stream without Python in between.
+//
+// Two transports:
+//  * one process per GPU (bench.py / torchrun, any MPI-style launcher): RCCL.  librccl is opened at run time (dlopen),
+//    re-using the copy a host process already loaded (PyTorch ships one), so that libcuhe_hip.so has no link-time
+//    dependency on it and single-GPU clients never touch it.  The ranks' row blocks differ in size when the number of
+//    primes is not a multiple of the number of ranks, so the gather is a group of ncclBroadcast calls (root r sends its
+//    block in place) rather than one ncclAllGather.
+//  * one process driving several devices (the reference's multiGPUs(n) model, cuhe/CuHE.cu:217-256): peer copies over
+//    xGMI ordered by events (cuhe_hip.hip, cuhe_hip_mul_relin_sharded_inproc) -- every block goes straight over the
+//    link between its two devices, which is what a direct all-gather of 0.2-1.5 MiB blocks amounts to on a fully
+//    connected xGMI topology, and it also runs on the virtual devices the single-GPU tests use.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only; the symbols are resolved with dlsym
+
+namespace cuhe { namespace comm {
+
+struct Api {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    const char *error = nullptr;
+};
+
+inline Api &api() {
+    static Api a;
+    if (a.handle || a.error) return a;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) if ((a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // already in the process
+    if (!a.handle) for (const char *n : names) if ((a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!a.handle) { a.error = "librccl.so not found"; return a; }
+#define CUHE_SYM(field, name) *(void **)(&a.field) = dlsym(a.handle, name); if (!a.field) { a.error = "librccl lacks " name; return a; }
+    CUHE_SYM(GetUniqueId, "ncclGetUniqueId") CUHE_SYM(CommInitRank, "ncclCommInitRank") CUHE_SYM(CommDestroy, "ncclCommDestroy")
+    CUHE_SYM(GroupStart, "ncclGroupStart") CUHE_SYM(GroupEnd, "ncclGroupEnd") CUHE_SYM(Broadcast, "ncclBroadcast")
+    CUHE_SYM(AllGather, "ncclAllGather") CUHE_SYM(GetErrorString, "ncclGetErrorString")
+#undef CUHE_SYM
+    return a;
+}
+
+struct State { ncclComm_t comm = nullptr; int nranks = 1, rank = 0; };
+inline State &state() { static State s; return s; }
+
+// contiguous, balanced blocks: the first (np % nranks) ranks own one prime more (== cuhe_amd/sharded.py: shard_bounds)
+inline void shard_bounds(int np, int nranks, int rank, int *first, int *count) {
+    const int base = np / nranks, extra = np % nranks;
+    *count = base + (rank < extra ? 1 : 0);
+    *first = rank * base + (rank < extra ? rank : extra);
+}
+
+}}  // namespace cuhe::comm

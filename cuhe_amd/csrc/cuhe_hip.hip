@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.hpp"
 #include "host_math.hpp"
 #include "ntt_kernels.cuh"
 #include "ops_kernels.cuh"
@@ -68,6 +69,8 @@ struct Workspace {
     u32 *b_alias = nullptr;              // copy of the input when barrett() is asked to work in place
     u64 *relin = nullptr;                // NTT-domain windows of the ciphertext being relinearised
     u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows
+    // scratch of the CRT-prime-sharded multiply + relinearise (own operand rows, gathered CRT rows, raw, own result rows)
+    u64 *sh_a = nullptr, *sh_b = nullptr; u32 *sh_rows = nullptr, *sh_raw = nullptr, *sh_out = nullptr; bool sh_ready = false;
     hipStream_t last = nullptr; bool used = false;
     hipEvent_t ev = nullptr;             // orders this thread's work when it moves to another stream
     // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
@@ -94,6 +97,8 @@ struct DevCtx {
     std::vector<Workspace *> idle;       // workspaces of finished threads, adopted by later ones
     // allocator (cuhe/DeviceManager.cu:98-138)
     // helper streams/events for the pass-1 / pass-2 software pipeline
+    hipStream_t sh_stream = nullptr;     // in-process sharded multiply: this device's stream and its stage events
+    hipEvent_t sh_e1 = nullptr, sh_e2 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t ev_start = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     std::multimap<size_t, void *> freeBlocks;
@@ -243,7 +248,8 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 }
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
-    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw, w->mr_ntt, w->mr_crt};
+    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw, w->mr_ntt, w->mr_crt,
+                    w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     if (w->ev_lane) hipEventDestroy(w->ev_lane);
@@ -843,6 +849,7 @@ int cuhe_hip_shutdown(void) {
         DevCtx &D = G_.dev[d];
         for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
+        if (D.sh_stream) { hipStreamDestroy(D.sh_stream); hipEventDestroy(D.sh_e1); hipEventDestroy(D.sh_e2); }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek};
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);
@@ -1683,6 +1690,187 @@ int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0,
     hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab_at(D, prime0),
                        count, W, q.modLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
+
+// ---------------------------------------------------------------- CRT-prime-sharded multiply + relinearise
+// Rank / device r owns a contiguous block of the level's primes (comm::shard_bounds).  Pointwise product, inverse
+// transform (+ reduction), the key-switch inner product over the OWNED primes' keys and the last inverse transform need
+// no communication; the one exchange is the all-gather of the CRT rows before ICRT, which every participant repeats
+// (26-100 us) together with the k window transforms.
+static int ws_shard(Workspace &w) {
+    if (w.sh_ready) return CUHE_OK;
+    const Params &q = G_.prm;
+    const size_t np = q.numCrtPrime, Lc = ct_len();
+    CHK(ws_buffer(&w.sh_a, np * Lc)); CHK(ws_buffer(&w.sh_b, np * Lc));
+    CHK(ws_buffer(&w.sh_rows, np * q.crtLen)); CHK(ws_buffer(&w.sh_raw, (size_t)q.rawLen * q.wordsCoeff(0))); CHK(ws_buffer(&w.sh_out, np * q.crtLen));
+    w.sh_ready = true;
+    return CUHE_OK;
+}
+// stage 1 on one participant: products of the owned rows, back to the CRT domain into rows[first ..) of the gather buffer
+static int shard_stage1(u32 *rows, u64 *tmp, const u64 *a_own, const u64 *b_own, int first, int count, int dev, hipStream_t st) {
+    const Params &q = G_.prm;
+    const long pairs = (long)count * ct_len() / 2;
+    hipLaunchKernelGGL((k_ntt_binop<true>), dim3((int)std::min<long>((pairs + 255) / 256, 8192)), dim3(256), 0, st, tmp, a_own, b_own, pairs);
+    HIPCHK(hipGetLastError());
+    return ct_inverse(rows + (size_t)first * q.crtLen, tmp, count, first, 0, true, dev, st);
+}
+// stage 2: ICRT of the gathered rows, key switch over the owned primes, back to the CRT domain
+static int shard_stage2(u32 *out_own, u32 *raw, u64 *acc, const u32 *rows, int lvl, int first, int count, int dev, hipStream_t st) {
+    const Params &q = G_.prm;
+    if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(raw, 0, (size_t)q.rawLen * q.wordsCoeff(lvl) * sizeof(u32), st));
+    CHK(cuhe_hip_icrt(raw, rows, q.logCoeff(lvl), dev, (void *)st));
+    CHK(relin_range((uint64_t *)acc, raw, lvl, first, count, dev, (void *)st));
+    return ct_inverse(out_own, acc, count, first, 0, true, dev, st);
+}
+
+int cuhe_hip_shard_bounds(int lvl, int nranks, int rank, int *first, int *count) {
+    if (!G_.params_set || lvl < 0 || lvl >= G_.prm.depth || nranks < 1 || rank < 0 || rank >= nranks || !first || !count)
+        return fail(CUHE_EINVAL, "shard_bounds(lvl %d, nranks %d, rank %d)", lvl, nranks, rank);
+    comm::shard_bounds(G_.prm.numCrtPrimeAt(lvl), nranks, rank, first, count);
+    return CUHE_OK;
+}
+// ---- one process per GPU: RCCL
+int cuhe_hip_comm_unique_id(void *id128) {
+    comm::Api &A = comm::api();
+    if (A.error) return fail(CUHE_EHIP, "RCCL: %s", A.error);
+    ncclUniqueId id;
+    const ncclResult_t r = A.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(CUHE_EHIP, "ncclGetUniqueId: %s", A.GetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return CUHE_OK;
+}
+int cuhe_hip_comm_init(int nranks, int rank, const void *id128) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id128) return fail(CUHE_EINVAL, "comm_init(%d, %d)", nranks, rank);
+    comm::Api &A = comm::api();
+    if (A.error) return fail(CUHE_EHIP, "RCCL: %s", A.error);
+    comm::State &C = comm::state();
+    if (C.comm) return fail(CUHE_EINVAL, "communicator already initialised");
+    HIPCHK(hipSetDevice(phys_dev(0)));                   // the rank's GPU: cuhe_hip_set_device_base(LOCAL_RANK)
+    ncclUniqueId id; memcpy(&id, id128, sizeof id);
+    const ncclResult_t r = A.CommInitRank(&C.comm, nranks, id, rank);
+    if (r != ncclSuccess) { C.comm = nullptr; return fail(CUHE_EHIP, "ncclCommInitRank(%d of %d): %s", rank, nranks, A.GetErrorString(r)); }
+    C.nranks = nranks; C.rank = rank;
+    return CUHE_OK;
+}
+int cuhe_hip_comm_destroy(void) {
+    comm::State &C = comm::state();
+    if (C.comm) { comm::api().CommDestroy(C.comm); C.comm = nullptr; }
+    C.nranks = 1; C.rank = 0;
+    return CUHE_OK;
+}
+int cuhe_hip_comm_size(void) { return comm::state().nranks; }
+int cuhe_hip_comm_rank(void) { return comm::state().rank; }
+// rows: u32[np][crtLen] of level lvl on this rank's device, the rank's own block already in place; on return (in stream
+// order) every block is.  A group of broadcasts, root r sending its block in place, because the blocks differ in size
+// when np is not a multiple of the number of ranks.
+int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *st) {
+    CHK(need_init(dev));
+    if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    comm::State &C = comm::state();
+    if (C.nranks == 1) return CUHE_OK;
+    if (!C.comm) return fail(CUHE_ENOTINIT, "cuhe_hip_comm_init has not been called");
+    comm::Api &A = comm::api();
+    const int np = G_.prm.numCrtPrimeAt(lvl), cl = G_.prm.crtLen;
+    ncclResult_t r = A.GroupStart();
+    for (int rk = 0; rk < C.nranks && r == ncclSuccess; ++rk) {
+        int f, c; comm::shard_bounds(np, C.nranks, rk, &f, &c);
+        if (c == 0) continue;
+        u32 *blk = rows + (size_t)f * cl;
+        r = A.Broadcast(blk, blk, (size_t)c * cl, ncclUint32, rk, C.comm, S(st));
+    }
+    const ncclResult_t e = A.GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows: %s", A.GetErrorString(r));
+    return CUHE_OK;
+}
+// cAnd + relin with the level's primes sharded over the ranks of the communicator: a_own, b_own = ct rows of the rank's
+// own primes (u64[count][ct_len]), dst_own = the reduced CRT rows of the same primes (u32[count][crtLen]).  Everything,
+// the all-gather included, is enqueued on `stream`.
+int cuhe_hip_mul_relin_sharded(uint32_t *dst_own, const uint64_t *a_own, const uint64_t *b_own, int lvl, int dev, void *st_) {
+    CHK(need_init(dev));
+    if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
+    if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    comm::State &C = comm::state();
+    int f, c; comm::shard_bounds(G_.prm.numCrtPrimeAt(lvl), C.nranks, C.rank, &f, &c);
+    if (c < 1) return fail(CUHE_EINVAL, "rank %d owns no prime at level %d (%d ranks)", C.rank, lvl, C.nranks);
+    hipStream_t st = S(st_);
+    Workspace *Wp = nullptr;
+    CHK(workspace(dev, st, &Wp));
+    CHK(ws_shard(*Wp));
+    CHK(shard_stage1(Wp->sh_rows, Wp->sh_a, (const u64 *)a_own, (const u64 *)b_own, f, c, dev, st));
+    CHK(cuhe_hip_allgather_rows(Wp->sh_rows, lvl, dev, st_));
+    return shard_stage2(dst_own, Wp->sh_raw, Wp->sh_a, Wp->sh_rows, lvl, f, c, dev, st);
+}
+// ---- one process, several devices (multiGPUs(n)): a, b = ct rows of ALL primes on device dev0, dst = reduced CRT rows of
+// all primes on dev0.  Device d works on its own stream: it pulls its operand rows over the peer link, runs stage 1,
+// pulls the other devices' CRT rows once they are ready (events), runs stage 2 and pushes its result rows to dev0; the
+// caller's stream continues when every device is done.  Keys and constants are resident on every device (init).
+int cuhe_hip_mul_relin_sharded_inproc(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int dev0, void *st_) {
+    CHK(need_init(dev0));
+    if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    const int nd = G_.ndev, np = q.numCrtPrimeAt(lvl), cl = q.crtLen;
+    const size_t Lc = ct_len();
+    if (np < nd) return fail(CUHE_EINVAL, "%d primes at level %d cannot be split over %d devices", np, lvl, nd);
+    hipStream_t st0 = S(st_);
+    std::vector<Workspace *> W(nd, nullptr);
+    std::vector<hipStream_t> sd(nd, nullptr);
+    for (int d = 0; d < nd; ++d) {
+        CHK(need_init(d));
+        DevCtx &D = G_.dev[d];
+        if (!D.sh_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&D.sh_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&D.sh_e1, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&D.sh_e2, hipEventDisableTiming));
+        }
+        sd[d] = d == dev0 ? st0 : D.sh_stream;
+        CHK(workspace(d, sd[d], &W[d]));
+        CHK(ws_shard(*W[d]));
+    }
+    auto peer = [&](void *dp, int dd, const void *sp, int sdv, size_t bytes, hipStream_t s) -> int {
+        if (G_.virtual_devices || dd == sdv) HIPCHK(hipMemcpyAsync(dp, sp, bytes, hipMemcpyDeviceToDevice, s));
+        else HIPCHK(hipMemcpyPeerAsync(dp, phys_dev(dd), sp, phys_dev(sdv), bytes, s));
+        return CUHE_OK;
+    };
+    // operands ready on dev0
+    CHK(set_dev(dev0));
+    Workspace &W0 = *W[dev0];
+    if (!W0.ev_in) HIPCHK(hipEventCreateWithFlags(&W0.ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(W0.ev_in, st0));
+    for (int d = 0; d < nd; ++d) {                      // stage 1 everywhere
+        int f, c; comm::shard_bounds(np, nd, d, &f, &c);
+        CHK(set_dev(d));
+        const u64 *ao = (const u64 *)a + (size_t)f * Lc, *bo = (const u64 *)b + (size_t)f * Lc;
+        if (d != dev0) {
+            HIPCHK(hipStreamWaitEvent(sd[d], W0.ev_in, 0));
+            CHK(peer(W[d]->sh_a, d, ao, dev0, (size_t)c * Lc * sizeof(u64), sd[d]));
+            CHK(peer(W[d]->sh_b, d, bo, dev0, (size_t)c * Lc * sizeof(u64), sd[d]));
+            ao = W[d]->sh_a; bo = W[d]->sh_b;
+        }
+        CHK(shard_stage1(W[d]->sh_rows, W[d]->sh_a, ao, bo, f, c, d, sd[d]));
+        HIPCHK(hipEventRecord(G_.dev[d].sh_e1, sd[d]));
+    }
+    for (int e = 0; e < nd; ++e) {                      // the exchange, then stage 2
+        int fe, ce; comm::shard_bounds(np, nd, e, &fe, &ce);
+        CHK(set_dev(e));
+        for (int d = 0; d < nd; ++d) {
+            if (d == e) continue;
+            int f, c; comm::shard_bounds(np, nd, d, &f, &c);
+            HIPCHK(hipStreamWaitEvent(sd[e], G_.dev[d].sh_e1, 0));
+            CHK(peer(W[e]->sh_rows + (size_t)f * cl, e, W[d]->sh_rows + (size_t)f * cl, d, (size_t)c * cl * sizeof(u32), sd[e]));
+        }
+        u32 *out = e == dev0 ? dst + (size_t)fe * cl : W[e]->sh_out;
+        CHK(shard_stage2(out, W[e]->sh_raw, W[e]->sh_a, W[e]->sh_rows, lvl, fe, ce, e, sd[e]));
+        if (e != dev0) {
+            CHK(peer(dst + (size_t)fe * cl, dev0, out, e, (size_t)ce * cl * sizeof(u32), sd[e]));
+            HIPCHK(hipEventRecord(G_.dev[e].sh_e2, sd[e]));
+        }
+    }
+    CHK(set_dev(dev0));
+    for (int e = 0; e < nd; ++e) if (e != dev0) HIPCHK(hipStreamWaitEvent(st0, G_.dev[e].sh_e2, 0));
     return CUHE_OK;
 }
 

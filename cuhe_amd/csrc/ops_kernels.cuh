@@ -533,12 +533,16 @@ struct IcrtTab {
 //            one LDS read of t_i per FOUR multiply-adds, the m_i words arrive through scalar loads (8 primes x 4
 //            words per block, unguarded thanks to the zero padding) and a multiply-add is one v_mad_u64_u32 with an
 //            SGPR operand plus a carry add; q*M is folded in, q = floor(alpha);
-//   phase 3: wave 0 ripples the carries and applies the +-M fix-up; the block stores its 64*W-word slab coalesced.
+//   phase 3: every column sum is a 96-bit value at 32-bit spacing; ALL four waves first fold the three 32-bit pieces that
+//            land on one output word (low piece of column k, middle piece of column k-1, signed top piece of column k-2)
+//            into one small 64-bit sum per word, so that what is left for the sequential pass of wave 0 is a ripple of a
+//            short signed carry over W words (add, store, arithmetic shift) plus the rare +-M fix-up; the block stores its
+//            64*W-word slab coalesced.
 // (The reference runs one thread per coefficient with a 104-word register array, Base.cu:884.)
 static constexpr int kIcrtCoef = 64, kIcrtGroups = 4, kIcrtKB = 4;
 static inline size_t icrt_lds_bytes(int np, int W) {
     const size_t np8 = (size_t)(np + 7) & ~(size_t)7;
-    return (size_t)kIcrtCoef * (np8 * 4 + (size_t)W * 16 + kIcrtGroups * 8);
+    return (size_t)kIcrtCoef * (np8 * 4 + (size_t)W * 24 + kIcrtGroups * 8);
 }
 __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
@@ -550,7 +554,8 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
     const int np8 = (np + 7) & ~7, W4 = (W + 3) & ~3;
     u64 *colLo = reinterpret_cast<u64 *>(shraw);                         // [W][CB]
     double *alphaP = reinterpret_cast<double *>(colLo + (size_t)W * CB); // [NG][CB]
-    int *colHi = reinterpret_cast<int *>(alphaP + NG * CB);              // [W][CB]
+    long long *wsum = reinterpret_cast<long long *>(alphaP + NG * CB);   // [W][CB] per-word sums of phase 3
+    int *colHi = reinterpret_cast<int *>(wsum + (size_t)W * CB);         // [W][CB]
     u32 *tt = reinterpret_cast<u32 *>(colHi + (size_t)W * CB);           // [np8][CB]; reused for the result words
     const int ci = threadIdx.x % CB;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x / CB);
@@ -608,17 +613,27 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
     }
     __syncthreads();
     u32 *out = tt;                                   // [W][CB] result words (the t_i are no longer needed; W <= np8 + 8)
+    // word k receives the low 32 bits of column k, bits 32..63 of column k-1 and the (signed) part above 2^64 of column k-2
+    for (int k = g; k < W; k += NG) {
+        long long v = (long long)(u32)colLo[k * CB + ci];
+        if (k >= 1) v += (long long)(colLo[(k - 1) * CB + ci] >> 32);
+        if (k >= 2) v += (long long)colHi[(k - 2) * CB + ci];
+        wsum[k * CB + ci] = v;
+    }
+    __syncthreads();
     if (g == 0) {
-        typedef __int128 i128;
-        i128 carry = 0;
+        // pieces that fall beyond word W-1 (bits 32.. of column W-1, the tops of columns W-2 and W-1) only decide the sign
+        long long carry = 0;
         for (int k = 0; k < W; ++k) {
-            i128 total = carry + (i128)(unsigned __int128)colLo[k * CB + ci] + ((i128)colHi[k * CB + ci] << 64);
-            out[k * CB + ci] = (u32)total;
-            carry = total >> 32;
+            const long long t = wsum[k * CB + ci] + carry;
+            out[k * CB + ci] = (u32)t;
+            carry = t >> 32;
         }
-        // carry = floor((S - q*M) / 2^(32W)): -1 => negative, 0 => in [0, 2^(32W))
+        long long top = carry + (long long)(colLo[(W - 1) * CB + ci] >> 32) + (W >= 2 ? (long long)colHi[(W - 2) * CB + ci] : 0);
+        top += (long long)colHi[(W - 1) * CB + ci] << 32;              // weight 2^(32(W+1)) relative to word W-1: enough for the sign
+        // top = floor((S - q*M) / 2^(32W)): negative => S - qM < 0, zero => in [0, 2^(32W))
         int fix = 0;                          // +1: add M, -1: subtract M
-        if (carry < 0) fix = 1;
+        if (top < 0) fix = 1;
         else {
             bool ge = true;                   // out >= M ?
             for (int k = W - 1; k >= 0; --k) {

@@ -543,6 +543,18 @@ void copyTo(CuCtxt &dst, CuCtxt &src, int dstDev, cudaStream_t st) {
 	copy(dst, src, st);
 	moveTo(dst, dstDev, st);
 }
+void cAndRelinSharded(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
+	if (in0.device() != in1.device()) misuse("Error: Multiplication of different devices!");
+	if (in0.domain() != 3 || in1.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
+	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
+	if (&out == &in0 || &out == &in1) misuse("Error: cAndRelinSharded needs a separate result!");
+	in0.stream(st); in1.stream(st);
+	out.reset();
+	out.setLevelForOutput(in0.level(), 2, in0.device(), st);
+	CSC(cuhe_hip_mul_relin_sharded_inproc(out.cRep(), U64P(in0.nRep()), U64P(in1.nRep()), in0.level(), in0.device(), st));
+	out.isProd(false);
+	GATE_SYNC(out.device(), st);
+}
 
 // ------------------------------------------------------------------ NTL interface
 // The by-value parameters are the reference's signature (cuhe/CuHE.h:184); they are moved, not copied again, into
@@ -726,6 +738,33 @@ void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStrea
 	GATE_SYNC(dev, st);
 }
 void copy(CuCtxtArray &dst, CuCtxtArray &src, cudaStream_t st) { concat(dst, std::vector<CuCtxtArray *>(1, &src), st); }
+void slice(CuCtxtArray &dst, CuCtxtArray &src, int first, int count, cudaStream_t st) {
+	if (&dst == &src || first < 0 || count < 1 || first + count > src.count() || (src.domain() != 2 && src.domain() != 3)) arrayMisuse("slice: bad range or empty source");
+	{
+		GateScope chain;
+		dst.create(count, src.level(), src.domain(), src.device(), st);
+		src.touch(st);
+		if (src.domain() == 2) CSC(cuhe_hip_memcpy_d2d(src.device(), dst.cRep_, src.cRep(first), count * arrayCtWords(src.level()) * sizeof(uint32), st));
+		else CSC(cuhe_hip_memcpy_d2d(src.device(), dst.nRep_, src.nRep(first), count * arrayCtElems(src.level()) * sizeof(uint64), st));
+		dst.isProd_ = src.isProd_;
+	}
+	GATE_SYNC(src.device(), st);
+}
+// whole array to another device of this process (cuhe/CuHE.cu:217-256 for one ciphertext): a peer copy on `st`, a
+// stream of the SOURCE device, into a settled block of the destination; synchronous like moveTo(CuCtxt&)
+void moveTo(CuCtxtArray &arr, int dstDev, cudaStream_t st) {
+	if (dstDev == arr.device_ || arr.count_ == 0) { arr.device_ = dstDev; return; }
+	const int srcDev = arr.device_;
+	const size_t bytes = arr.domain_ == 2 ? arr.count_ * arrayCtWords(0) * sizeof(uint32) : arr.count_ * arrayCtElems(0) * sizeof(uint64);
+	const size_t used = arr.domain_ == 2 ? arr.count_ * arrayCtWords(arr.level_) * sizeof(uint32) : arr.count_ * arrayCtElems(arr.level_) * sizeof(uint64);
+	void *p = peerAlloc(dstDev, bytes);
+	void *from = arr.domain_ == 2 ? (void *)arr.cRep_ : (void *)arr.nRep_;
+	CSC(cuhe_hip_memcpy_peer(p, dstDev, from, srcDev, used, st));
+	CSC(cuhe_hip_stream_sync(srcDev, st));
+	devFree(srcDev, from, st);
+	if (arr.domain_ == 2) arr.cRep_ = (uint32 *)p; else arr.nRep_ = (uint64 *)p;
+	arr.device_ = dstDev; arr.stream_ = 0;
+}
 void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuIndexTable &b, cudaStream_t st) {
 	if (in.domain() != 3 || a.size() != b.size() || a.size() == 0 || &out == &in) arrayMisuse("cAnd on arrays: operands must be in the NTT domain, index tables of equal length");
 	{

@@ -147,5 +147,11 @@ void cXor(CuCtxt &x, CuCtxt &c, CuPtxt &p, cudaStream_t st = 0);
 void cNot(CuCtxt &x, CuCtxt &a, cudaStream_t st = 0);
 void moveTo(CuCtxt &x, int dstDev, cudaStream_t st = 0);
 void copyTo(CuCtxt &dst, CuCtxt &src, int dstDev, cudaStream_t st = 0);
+// (addition) x = relin(a * b) with the CRT primes of the level split over all numGPUs() devices of this process: a and b
+// in the NTT domain on one device, x comes back reduced in the CRT domain on the same device.  Each device multiplies,
+// transforms and key-switches its own block of primes; the one exchange is the all-gather of CRT rows before ICRT (peer
+// copies over xGMI).  Same result as cAnd(x, a, b); x.relin().  One ciphertext's latency, not throughput: independent
+// ciphertexts are better spread over the devices whole (moveTo / the dev argument), as the reference does.
+void cAndRelinSharded(CuCtxt &x, CuCtxt &a, CuCtxt &b, cudaStream_t st = 0);
 
 } // namespace cuHE

@@ -50,6 +50,8 @@ private:
 	CuCtxtArray(const CuCtxtArray &);
 	CuCtxtArray &operator=(const CuCtxtArray &);
 	friend void copy(CuCtxtArray &, CuCtxtArray &, cudaStream_t);
+	friend void slice(CuCtxtArray &, CuCtxtArray &, int, int, cudaStream_t);
+	friend void moveTo(CuCtxtArray &, int, cudaStream_t);
 	friend void concat(CuCtxtArray &, const std::vector<CuCtxtArray *> &, cudaStream_t);
 	friend void cAnd(CuCtxtArray &, CuCtxtArray &, const CuIndexTable &, const CuIndexTable &, cudaStream_t);
 	friend void cXor(CuCtxtArray &, CuCtxtArray &, CuCtxtArray *, const CuIndexTable &, const CuIndexTable &, const CuIndexTable &, cudaStream_t);
@@ -64,6 +66,9 @@ private:
 // dst = a copy of src; dst = the ciphertexts of all parts in order (parts of one level, domain and device)
 void copy(CuCtxtArray &dst, CuCtxtArray &src, cudaStream_t st = 0);
 void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStream_t st = 0);
+// dst = the ciphertexts [first, first + count) of src; the whole array to another device of this process (peer copy)
+void slice(CuCtxtArray &dst, CuCtxtArray &src, int first, int count, cudaStream_t st = 0);
+void moveTo(CuCtxtArray &arr, int dstDev, cudaStream_t st = 0);
 // out[t] = in[a[t]] * in[b[t]]  (NTT domain; `out` is created with a.size() ciphertexts; relin / x2c follow as for cAnd)
 void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuIndexTable &b, cudaStream_t st = 0);
 // out[o] = sum of the ciphertexts listed in list[offsets[o] .. offsets[o+1]) (+ 1 on the constant coefficient where

@@ -225,6 +225,28 @@ int cuhe_hip_intt_mod_range(uint32_t *x, const uint64_t *X, int lvl, int prime0,
 int cuhe_hip_relin_range(uint64_t *dst, const uint32_t *raw, int lvl, int prime0, int count, int dev, void *stream);
 int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0, int count, int dev, void *stream);
 
+/* ---- multi-GPU: cAnd + relin of ONE ciphertext with the level's CRT primes sharded over GPUs (new; the reference's
+ * multi-GPU mode is whole ciphertexts per GPU, cuhe/CuHE.cu:217-256, which the dev argument of every call above already
+ * serves).  Participant r owns the contiguous block cuhe_hip_shard_bounds(lvl, n, r) of the level's primes; the only
+ * exchange is the all-gather of CRT rows before ICRT.
+ * (1) one process per GPU: RCCL, opened at run time (no link-time dependency).  Rank 0 calls comm_unique_id, the
+ *     launcher distributes the 128 bytes (bench.py: torch.distributed broadcast), every rank calls comm_init after
+ *     cuhe_hip_set_device_base(local rank).  The collective is enqueued on the caller's stream. */
+int cuhe_hip_shard_bounds(int lvl, int nranks, int rank, int *first, int *count);
+int cuhe_hip_comm_unique_id(void *id_128_bytes);
+int cuhe_hip_comm_init(int nranks, int rank, const void *id_128_bytes);
+int cuhe_hip_comm_destroy(void);
+int cuhe_hip_comm_size(void);
+int cuhe_hip_comm_rank(void);
+/* rows = u32[np][crtLen] of level lvl with this rank's block in place -> every block in place (stream ordered) */
+int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *stream);
+/* a_own, b_own: ct rows of the rank's primes u64[count][ct_len]; dst_own: reduced CRT rows u32[count][crtLen] */
+int cuhe_hip_mul_relin_sharded(uint32_t *dst_own, const uint64_t *a_own, const uint64_t *b_own, int lvl, int dev, void *stream);
+/* (2) one process driving the multiGPUs(n) devices: a, b = ct rows of all primes on device dev0, dst = reduced CRT rows
+ *     of all primes on dev0; rows travel by peer copies over xGMI ordered by events, each device on its own stream; the
+ *     caller's stream continues when every device is done. */
+int cuhe_hip_mul_relin_sharded_inproc(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int dev0, void *stream);
+
 /* ---- batched transform primitives (the shape tests/test_ntt.cu:67-100 times):
  * `batch` independent length-`len` transforms, len in {16384, 32768, 65536}. */
 /* forward: src u32[batch][src_stride] (only the first len/2 of each row are read, zero padded),

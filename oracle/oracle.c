@@ -19,6 +19,19 @@
 
 typedef unsigned __int128 u128;
 
+/* OpenMP threads for the loops over CRT primes / coefficients of the ctx stages (1 = serial, the default; bench.py's CPU
+ * baseline sets all host cores: "OpenMP over primes").  Results do not depend on it. */
+static int g_threads = 1;
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_max_threads();
+    g_threads = n;
+#else
+    (void)n; g_threads = 1;
+#endif
+    return g_threads;
+}
+
 /* ------------------------------------------------------------------------ */
 /* field arithmetic mod P = 2^64 - 2^32 + 1      (cuhe/ModP.h:231-289)       */
 /* ------------------------------------------------------------------------ */
@@ -432,6 +445,7 @@ void orc_crt(const orc_ctx *c, uint32_t *dst, const uint32_t *src, int lvl) {
     const orc_params *q = &c->prm;
     int np = orc_num_crt_prime(q, lvl), W = orc_words_coeff(q, lvl);
     memset(dst, 0, sizeof(uint32_t) * (size_t)np * q->crtLen);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int i = 0; i < np; i++) {
         uint32_t p = c->primes[i];
         for (int idx = 0; idx < q->modLen; idx++) {
@@ -450,8 +464,9 @@ void orc_icrt(const orc_ctx *c, uint32_t *dst, const uint32_t *src, int lvl) {
     int np = orc_num_crt_prime(q, lvl), W = orc_words_coeff(q, lvl);
     const uint32_t *M = c->M[lvl];
     memset(dst, 0, sizeof(uint32_t) * (size_t)q->rawLen * W);
-    uint32_t acc[ORC_MAX_WORDS + 2];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int idx = 0; idx < q->modLen; idx++) {
+        uint32_t acc[ORC_MAX_WORDS + 2];
         memset(acc, 0, sizeof acc);
         for (int i = 0; i < np; i++) {
             uint32_t p = c->primes[i];
@@ -477,11 +492,13 @@ void orc_icrt(const orc_ctx *c, uint32_t *dst, const uint32_t *src, int lvl) {
 
 void orc_ntt(const orc_ctx *c, uint64_t *dst, const uint32_t *src, int np) {
     const orc_params *q = &c->prm;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int i = 0; i < np; i++)
         orc_ntt_ext(dst + (size_t)i * q->nttLen, src + (size_t)i * q->crtLen, q->nttLen);
 }
 void orc_intt_hold(const orc_ctx *c, uint32_t *dst, const uint64_t *src, int np) {
     const orc_params *q = &c->prm;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int i = 0; i < np; i++)
         orc_intt_modp(dst + (size_t)i * q->nttLen, src + (size_t)i * q->nttLen, q->nttLen, c->primes[i]);
 }
@@ -498,8 +515,9 @@ void orc_intt(const orc_ctx *c, uint32_t *dst, const uint64_t *src, int np) {
 void orc_poly_reduce_exact(const orc_ctx *c, uint32_t *dst, const uint32_t *src, int np) {
     const orc_params *q = &c->prm;
     int n = q->modLen, L = q->nttLen, m = q->mSize;
-    uint32_t *f = (uint32_t *)malloc(sizeof(uint32_t) * L);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int i = 0; i < np; i++) {
+        uint32_t *f = (uint32_t *)malloc(sizeof(uint32_t) * L);
         uint32_t p = c->primes[i];
         for (int k = 0; k < L; k++) f[k] = src[(size_t)i * L + k] % p;
         int top = L - 1;
@@ -521,8 +539,8 @@ void orc_poly_reduce_exact(const orc_ctx *c, uint32_t *dst, const uint32_t *src,
         }
         memset(dst + (size_t)i * q->crtLen, 0, sizeof(uint32_t) * q->crtLen);
         memcpy(dst + (size_t)i * q->crtLen, f, sizeof(uint32_t) * n);
+        free(f);
     }
-    free(f);
 }
 
 void orc_barrett(const orc_ctx *c, uint32_t *dst, const uint32_t *src_in, int np) {
@@ -575,6 +593,7 @@ void orc_intt_mod(const orc_ctx *c, uint32_t *dst, const uint64_t *src, int np) 
 
 void orc_ntt_mul(const orc_ctx *c, uint64_t *z, const uint64_t *x, const uint64_t *y, int np) {
     size_t n = (size_t)np * c->prm.nttLen;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (size_t i = 0; i < n; i++) z[i] = orc_mul_modP(x[i], y[i]);
 }
 void orc_ntt_add(const orc_ctx *c, uint64_t *z, const uint64_t *x, const uint64_t *y, int np) {
@@ -790,6 +809,69 @@ int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, i
     }
     orc_nc_intt_modp(dst, acc, n, p);
     free(acc); free(A); free(B);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* optional CPU baseline: the multiplication the reference delegates to NTL   */
+/* (examples/DHS/DHS.cu:219-221: t = a * b; t %= Phi; coefficients mod q) done */
+/* the way a big-number library does it -- Kronecker substitution, ONE mpz_mul */
+/* of two integers of n * S bits -- with GMP opened at run time when the box   */
+/* has it (NTL itself is absent from this image; NTL builds on GMP).  Used by  */
+/* bench.py as a labelled second cpu_baseline and by a CPU test against the    */
+/* oracle's own path; never by the product.                                    */
+/* ------------------------------------------------------------------------ */
+#include <dlfcn.h>
+typedef struct { int alloc, size; unsigned long *d; } gmp_mpz[1];
+static struct {
+    void *h; int tried;
+    void (*init)(gmp_mpz); void (*clear)(gmp_mpz);
+    void (*import)(gmp_mpz, size_t, int, size_t, int, size_t, const void *);
+    void *(*export)(void *, size_t *, int, size_t, int, size_t, const gmp_mpz);
+    void (*mul)(gmp_mpz, const gmp_mpz, const gmp_mpz); void (*sub)(gmp_mpz, const gmp_mpz, const gmp_mpz);
+    void (*fdiv_r)(gmp_mpz, const gmp_mpz, const gmp_mpz);
+} GMP;
+static int gmp_load(void) {
+    if (GMP.tried) return GMP.h != NULL;
+    GMP.tried = 1;
+    const char *names[] = {"libgmp.so.10", "libgmp.so", "/opt/conda/lib/libgmp.so"};
+    for (int i = 0; i < 3 && !GMP.h; i++) GMP.h = dlopen(names[i], RTLD_NOW);
+    if (!GMP.h) return 0;
+    *(void **)&GMP.init = dlsym(GMP.h, "__gmpz_init"); *(void **)&GMP.clear = dlsym(GMP.h, "__gmpz_clear");
+    *(void **)&GMP.import = dlsym(GMP.h, "__gmpz_import"); *(void **)&GMP.export = dlsym(GMP.h, "__gmpz_export");
+    *(void **)&GMP.mul = dlsym(GMP.h, "__gmpz_mul"); *(void **)&GMP.sub = dlsym(GMP.h, "__gmpz_sub");
+    *(void **)&GMP.fdiv_r = dlsym(GMP.h, "__gmpz_fdiv_r");
+    if (!GMP.init || !GMP.clear || !GMP.import || !GMP.export || !GMP.mul || !GMP.sub || !GMP.fdiv_r) { GMP.h = NULL; return 0; }
+    return 1;
+}
+int orc_gmp_available(void) { return gmp_load(); }
+/* out = (a * b mod x^n + 1) mod q; a, b, out raw u32[n][W] little-endian words, q as qW words.  -1 without GMP. */
+int orc_gmp_mul_xn1(uint32_t *out, const uint32_t *a, const uint32_t *b, int n, int W, const uint32_t *qwords, int qW) {
+    if (!gmp_load()) return -1;
+    const int slot = (64 * W + ilog2(n) + 2 + 63) / 64;               /* 64-bit limbs per coefficient slot: no overlap of products */
+    const size_t limbs = (size_t)n * slot;
+    uint64_t *pa = (uint64_t *)calloc(limbs, 8), *pb = (uint64_t *)calloc(limbs, 8), *pc = (uint64_t *)calloc(2 * limbs + 2, 8);
+    for (int i = 0; i < n; i++) { memcpy(pa + (size_t)i * slot, a + (size_t)i * W, 4 * (size_t)W); memcpy(pb + (size_t)i * slot, b + (size_t)i * W, 4 * (size_t)W); }
+    gmp_mpz A, B, Cc, Q, x, y;
+    GMP.init(A); GMP.init(B); GMP.init(Cc); GMP.init(Q); GMP.init(x); GMP.init(y);
+    GMP.import(A, limbs, -1, 8, 0, 0, pa); GMP.import(B, limbs, -1, 8, 0, 0, pb);
+    GMP.import(Q, (size_t)qW, -1, 4, 0, 0, qwords);
+    GMP.mul(Cc, A, B);                                                /* the one big multiplication */
+    size_t got = 0;
+    GMP.export(pc, &got, -1, 8, 0, 0, Cc);
+    uint32_t *w = (uint32_t *)calloc((size_t)W + 2, 4);
+    for (int i = 0; i < n; i++) {                                     /* c[i] - c[i + n] mod q   (x^n = -1) */
+        GMP.import(x, (size_t)slot, -1, 8, 0, 0, pc + (size_t)i * slot);
+        GMP.import(y, (size_t)slot, -1, 8, 0, 0, pc + (size_t)(i + n) * slot);
+        GMP.sub(x, x, y);
+        GMP.fdiv_r(x, x, Q);
+        size_t cnt = 0;
+        memset(w, 0, 4 * ((size_t)W + 2));
+        GMP.export(w, &cnt, -1, 4, 0, 0, x);
+        memcpy(out + (size_t)i * W, w, 4 * (size_t)W);
+    }
+    free(w); free(pa); free(pb); free(pc);
+    GMP.clear(A); GMP.clear(B); GMP.clear(Cc); GMP.clear(Q); GMP.clear(x); GMP.clear(y);
     return 0;
 }
 

@@ -31,6 +31,10 @@ extern "C" {
 #define ORC_MAX_PRIMES 103                   /* cuhe/Base.cu:139 maxNumPrimes */
 #define ORC_MAX_WORDS 112                    /* >= 103 primes * <=32 bits / 32, + slack */
 
+/* OpenMP threads used by the per-prime / per-coefficient loops of the ctx stages below (default 1; 0 = all cores);
+ * returns the count in effect.  Results are independent of it. */
+int orc_set_threads(int n);
+
 /* ---- field arithmetic mod P (cuhe/ModP.h:231-289, canonical results) ---- */
 uint64_t orc_add_modP(uint64_t x, uint64_t y);
 uint64_t orc_sub_modP(uint64_t x, uint64_t y);
@@ -144,6 +148,12 @@ void orc_nc_ntt(uint64_t *dst, const uint32_t *src, int n);
 int orc_nc_intt_modp(uint32_t *dst, const uint64_t *src, int n, uint32_t p);
 /* sum_j win[j] * key[j] mod (x^n + 1) mod p over k window / key rows of n coefficients (cuhe/Relinearization.cu:76-88) */
 int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, int k, int n, uint32_t p);
+
+/* ---- optional second CPU baseline (bench.py): the product the reference delegates to NTL (examples/DHS/DHS.cu:219-221) on
+ * x^n + 1 by Kronecker substitution and ONE big-integer multiplication through GMP, opened at run time (NTL is not in
+ * this image; it builds on GMP).  orc_gmp_mul_xn1 returns -1 when no libgmp is found. */
+int orc_gmp_available(void);
+int orc_gmp_mul_xn1(uint32_t *out, const uint32_t *a, const uint32_t *b, int n, int W, const uint32_t *qwords, int qW);
 
 /* seeded generator shared by tests / bench: splitmix64 */
 uint64_t orc_splitmix64(uint64_t *state);

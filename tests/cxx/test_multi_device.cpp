@@ -79,6 +79,20 @@ int main(int argc, char **argv) {
 		for (int d = 0; d < NDEV; ++d) ok = ok && pc[d] == hostMul(pa[d], pb[d], phi, q[1], n);
 		CHECK(ok, "one host thread per device, concurrently");
 	}
+	// one ciphertext with its CRT primes sharded over the devices (cAndRelinSharded): equal to cAnd + relin on one device,
+	// at both levels that have enough primes, from device 0 and from device 1, several times in a row (buffer reuse)
+	for (int lvl = 0; lvl <= 1; ++lvl)
+		for (int dev0 = 0; dev0 <= 1; ++dev0) {
+			ZZX pa = randomPoly(n, q[lvl]), pb = randomPoly(n, q[lvl]);
+			CuCtxt x, y, z, w;
+			x.setLevel(lvl, dev0, pa); y.setLevel(lvl, dev0, pb);
+			x.x2n(); y.x2n();
+			cAnd(z, x, y); z.relin(); z.x2z();
+			bool ok = true;
+			for (int r = 0; r < 3; ++r) { cAndRelinSharded(w, x, y); CuCtxt c; copy(c, w); c.x2z(); ok = ok && c.zRep() == z.zRep() && w.device() == dev0 && w.domain() == 2; }
+			char what[128]; snprintf(what, sizeof what, "cAndRelinSharded over %d devices == cAnd + relin (level %d, home device %d)", NDEV, lvl, dev0);
+			CHECK(ok, what);
+		}
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;
 }

@@ -84,6 +84,9 @@ def lib():
         L.orc_negacyclic_mul_modp_naive.restype = None; L.orc_negacyclic_mul_modp_naive.argtypes = [vp, vp, vp, i32, u32]
         L.orc_negacyclic_mul_modp.restype = i32; L.orc_negacyclic_mul_modp.argtypes = [vp, vp, vp, i32, u32]
         L.orc_nc_relin_modp.restype = i32; L.orc_nc_relin_modp.argtypes = [vp, vp, vp, i32, i32, u32]
+        L.orc_gmp_available.restype = i32; L.orc_gmp_available.argtypes = []
+        L.orc_gmp_mul_xn1.restype = i32; L.orc_gmp_mul_xn1.argtypes = [vp, vp, vp, i32, i32, vp, i32]
+        L.orc_set_threads.restype = i32; L.orc_set_threads.argtypes = [i32]
         L.orc_fill_u32_below.restype = None; L.orc_fill_u32_below.argtypes = [vp, C.c_size_t, u32, u64]
         _LIB = L
     return _LIB
@@ -149,6 +152,24 @@ def nc_relin_modp(win, key, p):
     out = np.empty(n, dtype=np.uint32)
     assert lib().orc_nc_relin_modp(_p(out), _p(win), _p(key), k, n, p) == 0
     return out
+
+
+def gmp_mul_xn1(a_raw, b_raw, q):
+    """(a * b mod x^n + 1) mod q through GMP (Kronecker substitution, one mpz_mul), or None when libgmp is absent;
+    a_raw, b_raw: u32[n][W]"""
+    a_raw = np.ascontiguousarray(a_raw, dtype=np.uint32); b_raw = np.ascontiguousarray(b_raw, dtype=np.uint32)
+    n, W = a_raw.shape
+    qW = (q.bit_length() + 31) // 32
+    qw = np.frombuffer(q.to_bytes(4 * qW, "little"), dtype=np.uint32).copy()
+    out = np.zeros((n, W), dtype=np.uint32)
+    if lib().orc_gmp_mul_xn1(_p(out), _p(a_raw), _p(b_raw), n, W, _p(qw), qW) != 0:
+        return None
+    return out
+
+
+def set_threads(n):
+    """OpenMP threads of the Ctx stage loops (0 = all cores); returns the count in effect"""
+    return lib().orc_set_threads(n)
 
 
 def set_param(d, p, w, mn, cut, m):

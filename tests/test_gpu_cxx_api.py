@@ -67,7 +67,7 @@ def test_prince_known_answer(flags):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
-    assert r.stdout.count("right") == 13
+    assert r.stdout.count("right") == (1 if "--no-round-checks" in flags else 13)
 
 
 def test_prince_known_answer_on_arrays():
@@ -108,7 +108,8 @@ def test_in_process_multi_device_on_virtual_devices():
     assert "ALL PASSED" in r.stdout
 
 
-@pytest.mark.parametrize("flags", [[], ["--async"]], ids=["sync", "async"])
+@pytest.mark.parametrize("flags", [[], ["--async"], ["--devices", "3", "--virtual"], ["--devices", "8", "--virtual", "--async", "--no-round-checks"]],
+                         ids=["sync", "async", "3-virtual-devices", "8-virtual-devices-async"])
 def test_prince_known_answer_on_cxx_array_classes(flags):
     """The same circuit through the C++ array classes of cuhe_amd/cxx/CuHEArray.h (CuCtxtArray / CuIndexTable: cAnd over
     index pairs, cXor over index lists, relin / modSwitch / x2n / x2c on whole arrays, copy / concat): known answer and
@@ -126,4 +127,4 @@ def test_prince_known_answer_on_cxx_array_classes(flags):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
-    assert r.stdout.count("right") == 13
+    assert r.stdout.count("right") == (1 if "--no-round-checks" in flags else 13)

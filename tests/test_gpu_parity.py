@@ -964,3 +964,71 @@ def test_degree_65536_ring(gu):
         assert lib.cuhe_hip_intt_mod(out.data_ptr(), na.data_ptr(), g.logq(lvl), 0, None) != 0
     finally:
         g.close()
+
+
+def test_sharded_multiply_through_the_c_abi(gu):
+    """CRT-prime-sharded cAnd + relin behind the C ABI (include/cuhe_hip.h, "multi-GPU"): (1) the one-process-per-GPU
+    form on a communicator of one rank -- RCCL is opened, the unique id made and the communicator initialised, the
+    all-gather is a no-op: the chain must equal the unsharded one; (2) the in-process form over three VIRTUAL devices
+    (own context each on the one GPU): rows travel by peer copies ordered by events; equal to the single-device result,
+    called repeatedly and from two different home devices.  Both on a cyclic and on a negacyclic ring."""
+    import ctypes
+    import oracle_lib as O
+    lib, ck = gu.lib, gu.ck
+    for args in (PSETS["toy1155"], PSETS["pow2_32768"]):
+        o = O.Ctx(*args)
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE900 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        try:
+            # (1) communicator of one rank
+            g = gu.GpuCtx(*args)
+            try:
+                g.init_relin(ek_raw)
+                uid = (ctypes.c_uint8 * 128)()
+                ck(lib.cuhe_hip_comm_unique_id(uid))
+                ck(lib.cuhe_hip_comm_init(1, 0, uid))
+                assert lib.cuhe_hip_comm_size() == 1 and lib.cuhe_hip_comm_rank() == 0
+                f, c = ctypes.c_int(), ctypes.c_int()
+                ck(lib.cuhe_hip_shard_bounds(1, 3, 1, ctypes.byref(f), ctypes.byref(c)))
+                from cuhe_amd.sharded import shard_bounds
+                assert (f.value, c.value) == shard_bounds(o.np_(1), 3, 1)
+                for lvl in (0, 1):
+                    npr = o.np_(lvl)
+                    a, b = _rand_crt(o, npr, 91 + lvl), _rand_crt(o, npr, 92 + lvl)
+                    na, nb = gu.to_dev(g.ct_ntt(a, lvl)), gu.to_dev(g.ct_ntt(b, lvl))
+                    out = gu.empty_u32(npr, q.crtLen)
+                    ck(lib.cuhe_hip_mul_relin_sharded(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, 0, None))
+                    assert np.array_equal(gu.host_u32(out), o.mul_relin_crt(a, b, lvl, ek)), lvl
+                ck(lib.cuhe_hip_comm_destroy())
+            finally:
+                lib.cuhe_hip_comm_destroy(); g.close()
+            # (2) three virtual devices in this process
+            lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+            ck(lib.cuhe_hip_set_virtual_devices(1))
+            try:
+                ck(lib.cuhe_hip_set_parameters(*args))
+                ck(lib.cuhe_hip_multi_gpus(3))
+                ck(lib.cuhe_hip_init(None, 0))
+                ekc = np.ascontiguousarray(ek_raw, dtype=np.uint32)
+                ck(lib.cuhe_hip_init_relin(ekc.ctypes.data_as(ctypes.c_void_p)))
+                ctlen = lib.cuhe_hip_ct_len()
+                for lvl in (0, 1):
+                    npr, logq = o.np_(lvl), o.logq(lvl)
+                    a, b = _rand_crt(o, npr, 93 + lvl), _rand_crt(o, npr, 94 + lvl)
+                    want = o.mul_relin_crt(a, b, lvl, ek)
+                    for dev0 in (0, 2):
+                        na, nb = gu.empty_u64(npr, ctlen), gu.empty_u64(npr, ctlen)
+                        ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), gu.to_dev(a).data_ptr(), logq, dev0, None))
+                        ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), gu.to_dev(b).data_ptr(), logq, dev0, None))
+                        out = gu.empty_u32(npr, q.crtLen)
+                        for rep in range(3):
+                            out.zero_()
+                            ck(lib.cuhe_hip_mul_relin_sharded_inproc(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, dev0, None))
+                            ck(lib.cuhe_hip_stream_sync(dev0, None))
+                            assert np.array_equal(gu.host_u32(out), want), (lvl, dev0, rep)
+            finally:
+                lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_virtual_devices(0); lib.cuhe_hip_multi_gpus(1)
+        finally:
+            o.close()

@@ -90,3 +90,23 @@ def test_degree_65536_parameters_match_the_library():
     pr = O.gen_crt_primes(q)
     assert all(int(p) < (1 << 23) for p in pr) and 2 * 65536 * (int(max(pr)) - 1) ** 2 < O.P
     capi.lib.cuhe_hip_reset_parameters()
+
+
+def test_gmp_kronecker_baseline_equals_the_oracle_path():
+    """the optional GMP baseline of bench.py (one mpz_mul of Kronecker-packed operands, the shape of the NTL call the
+    reference makes at examples/DHS/DHS.cu:219-221) against the oracle's own multiply; threads do not change results"""
+    if not O.lib().orc_gmp_available():
+        pytest.skip("no libgmp on this box")
+    o = O.Ctx(3, 2, 16, 50, 25, 16384)
+    try:
+        q = o.prm
+        for lvl in (0, 2):
+            M, W = o.coeff_modulus(lvl), o.words(lvl)
+            a, _ = O.random_raw(q.rawLen, q.modLen, W, M, 31 + lvl); b, _ = O.random_raw(q.rawLen, q.modLen, W, M, 41 + lvl)
+            want = o.mul_raw(a, b, lvl)
+            assert np.array_equal(O.gmp_mul_xn1(a, b, M), want)
+            assert O.set_threads(0) >= 1
+            assert np.array_equal(o.mul_raw(a, b, lvl), want)
+            O.set_threads(1)
+    finally:
+        O.set_threads(1); o.close()
