@@ -1469,7 +1469,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
                 const double f = (double)np / slots;
                 if (f >= eff) { eff = f; best = pb; }
             }
-            const dim3 grid(L / CBr, (batch + BB - 1) / BB), block(kMacLdsThreads);
+            const dim3 grid((L / CBr) * ((batch + BB - 1) / BB)), block(kMacLdsThreads);       // (tile, group) pairs, see the kernel
 #define MACL(PB_, CB_) do { \
                 if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_relin_mac_lds<PB_, BB, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
                 hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB, CB_>), grid, block, lds, st, Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, \
@@ -1487,13 +1487,13 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     return reduce_rows(dst, Ws.bt_ntt);
 }
 
-// Groups of four ciphertexts (the unit that shares key fetches) go round-robin to `lanes` streams: the caller's and
-// helper streams of the calling thread, each with its own scratch.  The inner product of one group streams keys from
-// HBM while the transforms of another keep the vector units busy; the caller's stream waits for the helpers at the
-// end.  Short groups matter: with one long chunk per stream all streams run the same stage at the same time and nothing
-// overlaps.  Only where a group is substantial work (>= 1 GiB of keys per level, e.g. 64K-point rings with dozens of
-// primes): on small rings one launch sequence over the whole batch is faster (profiles/r01_experiments_log.txt).
-static int g_relin_lanes = 3;
+// Optional: groups of four ciphertexts go round-robin to `lanes` streams (the caller's and helper streams of the calling
+// thread, each with its own scratch), so that the inner product of one group streams keys while the transforms of
+// another keep the vector units busy.  This was the default on rings with >= 1 GiB of keys per level in round 1; since
+// the inner-product kernel places the ciphertext groups of one column tile next to each other on one XCD (a key value
+// then leaves HBM once per BATCH, not once per group) one launch sequence over the whole batch is faster on every ring
+// measured (profiles/r02_relin_lanes_ab.txt), so the default is 1 lane; cuhe_hip_set_relin_lanes(n) still selects more.
+static int g_relin_lanes = 1;
 static bool g_relin_lanes_any_size = false;          // -n: n lanes whatever the ring size (tests)
 int cuhe_hip_set_relin_lanes(int n) {
     const int m = n < 0 ? -n : n;

@@ -362,8 +362,14 @@ void k_relin_mac_lds(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64
     extern __shared__ __attribute__((aligned(16))) u64 wl[];   // [BB][k][CB]
     constexpr int NG = kMacLdsThreads / CB;                  // prime groups per workgroup
     const int col = threadIdx.x % CB, pg = threadIdx.x / CB;
-    const long col0 = (long)blockIdx.x * CB;
-    const int b0 = blockIdx.y * BB;
+    // 1-D grid over (column tile, group of BB ciphertexts).  Workgroup ids go round-robin over the 8 XCDs (id % 8); within
+    // an XCD consecutive ids take the ciphertext groups of ONE column tile, so that the groups that read the same key rows
+    // run next to each other on one L2: a key value then comes from HBM once per batch instead of once per group
+    // (L / CB is a multiple of 8).
+    const int ngroups = (ncts + BB - 1) / BB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long col0 = (long)((slot / ngroups) * 8 + xcd) * CB;
+    const int b0 = (slot % ngroups) * BB;
     for (int e = threadIdx.x; e < BB * k * CB; e += CB * NG) {
         const int cc = e % CB, j = (e / CB) % k, b = e / (CB * k);
         wl[e] = c[(long)min(b0 + b, ncts - 1) * c_ct_stride + (long)j * L + col0 + cc];
@@ -532,17 +538,17 @@ struct IcrtTab {
 //   phase 2: wave g owns the output words k = 4g + 16t + j, j < 4: the 96-bit column sums  sum_i t_i * m_i[k]  take
 //            one LDS read of t_i per FOUR multiply-adds, the m_i words arrive through scalar loads (8 primes x 4
 //            words per block, unguarded thanks to the zero padding) and a multiply-add is one v_mad_u64_u32 with an
-//            SGPR operand plus a carry add; q*M is folded in, q = floor(alpha);
-//   phase 3: every column sum is a 96-bit value at 32-bit spacing; ALL four waves first fold the three 32-bit pieces that
-//            land on one output word (low piece of column k, middle piece of column k-1, signed top piece of column k-2)
-//            into one small 64-bit sum per word, so that what is left for the sequential pass of wave 0 is a ripple of a
-//            short signed carry over W words (add, store, arithmetic shift) plus the rare +-M fix-up; the block stores its
-//            64*W-word slab coalesced.
-// (The reference runs one thread per coefficient with a 104-word register array, Base.cu:884.)
+//            SGPR operand plus a carry add; q*M is folded in, q = floor(alpha).  The wave then adds its four columns up
+//            (they sit 32 bits apart) into four result words and ONE signed 64-bit carry towards the next block of words,
+//            so that only 24 bytes per coefficient and block go through LDS;
+//   phase 3: wave 0 ripples the block carries (W/4 steps instead of W) and applies the rare +-M fix-up; the block stores
+//            its 64*W-word slab coalesced.
+// 28 KB of LDS at 48 primes (5 workgroups per CU); the first version kept every column in LDS (70 KB, 2 per CU) and
+// rippled W words on one wave.  (The reference runs one thread per coefficient with a 104-word register array, Base.cu:884.)
 static constexpr int kIcrtCoef = 64, kIcrtGroups = 4, kIcrtKB = 4;
 static inline size_t icrt_lds_bytes(int np, int W) {
-    const size_t np8 = (size_t)(np + 7) & ~(size_t)7;
-    return (size_t)kIcrtCoef * (np8 * 4 + (size_t)W * 24 + kIcrtGroups * 8);
+    const size_t np8 = (size_t)(np + 7) & ~(size_t)7, nb = (size_t)(W + kIcrtKB - 1) / kIcrtKB;
+    return (size_t)kIcrtCoef * (np8 * 4 + nb * 24 + kIcrtGroups * 8);
 }
 __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
@@ -551,12 +557,11 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
     dst += (long)blockIdx.y * dst_ct_stride;
     extern __shared__ __attribute__((aligned(16))) unsigned char shraw[];
     constexpr int CB = kIcrtCoef, NG = kIcrtGroups, KB = kIcrtKB;
-    const int np8 = (np + 7) & ~7, W4 = (W + 3) & ~3;
-    u64 *colLo = reinterpret_cast<u64 *>(shraw);                         // [W][CB]
-    double *alphaP = reinterpret_cast<double *>(colLo + (size_t)W * CB); // [NG][CB]
-    long long *wsum = reinterpret_cast<long long *>(alphaP + NG * CB);   // [W][CB] per-word sums of phase 3
-    int *colHi = reinterpret_cast<int *>(wsum + (size_t)W * CB);         // [W][CB]
-    u32 *tt = reinterpret_cast<u32 *>(colHi + (size_t)W * CB);           // [np8][CB]; reused for the result words
+    const int np8 = (np + 7) & ~7, W4 = (W + 3) & ~3, nb = W4 / KB;
+    uint4 *blk = reinterpret_cast<uint4 *>(shraw);                       // [nb][CB] four result words of a block (before the incoming carry)
+    long long *bcar = reinterpret_cast<long long *>(blk + (size_t)nb * CB);   // [nb][CB] carry out of the block
+    double *alphaP = reinterpret_cast<double *>(bcar + (size_t)nb * CB); // [NG][CB]
+    u32 *tt = reinterpret_cast<u32 *>(alphaP + NG * CB);                 // [np8][CB]
     const int ci = threadIdx.x % CB;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x / CB);
     const long base = (long)blockIdx.x * CB;
@@ -580,7 +585,8 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
 #pragma unroll
     for (int gg = 0; gg < NG; ++gg) alpha += alphaP[gg * CB + ci];
     const u32 q = (u32)alpha;            // floor; may be off by one either way -> fixed below
-    for (int k0 = g * KB; k0 < W; k0 += NG * KB) {
+    typedef __int128 i128;
+    for (int k0 = g * KB; k0 < W4; k0 += NG * KB) {
         u64 lo[KB]; u32 hi[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j) { lo[j] = 0; hi[j] = 0; }
@@ -601,43 +607,42 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
                 }
             }
         }
+        // the four columns, 32 bits apart, minus q * M: four words and a signed carry (column < 2^71, so the carry fits)
+        u32 w[KB];
+        long long carry = 0;
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const int k = k0 + j;
-            if (k < W) {
-                const u64 qm = (u64)q * it.M[k];
-                colLo[k * CB + ci] = lo[j] - qm;
-                colHi[k * CB + ci] = (int)hi[j] - (lo[j] < qm);      // column value = lo + h * 2^64, h may be -1
-            }
+            const u64 qm = k < W ? (u64)q * it.M[k] : 0;
+            const i128 col = (i128)(unsigned __int128)lo[j] + ((i128)hi[j] << 64) - (i128)(unsigned __int128)qm + (i128)carry;
+            w[j] = (u32)col;
+            carry = (long long)(col >> 32);
         }
+        blk[(k0 / KB) * CB + ci] = make_uint4(w[0], w[1], w[2], w[3]);
+        bcar[(k0 / KB) * CB + ci] = carry;
     }
     __syncthreads();
-    u32 *out = tt;                                   // [W][CB] result words (the t_i are no longer needed; W <= np8 + 8)
-    // word k receives the low 32 bits of column k, bits 32..63 of column k-1 and the (signed) part above 2^64 of column k-2
-    for (int k = g; k < W; k += NG) {
-        long long v = (long long)(u32)colLo[k * CB + ci];
-        if (k >= 1) v += (long long)(colLo[(k - 1) * CB + ci] >> 32);
-        if (k >= 2) v += (long long)colHi[(k - 2) * CB + ci];
-        wsum[k * CB + ci] = v;
-    }
-    __syncthreads();
+    u32 *out = reinterpret_cast<u32 *>(blk);         // word k of coefficient c: out[((k / 4) * CB + c) * 4 + k % 4]
     if (g == 0) {
-        // pieces that fall beyond word W-1 (bits 32.. of column W-1, the tops of columns W-2 and W-1) only decide the sign
-        long long carry = 0;
-        for (int k = 0; k < W; ++k) {
-            const long long t = wsum[k * CB + ci] + carry;
-            out[k * CB + ci] = (u32)t;
-            carry = t >> 32;
+        long long cin = 0;
+        for (int b = 0; b < nb; ++b) {
+            uint4 v = blk[b * CB + ci];
+            long long t = (long long)v.x + cin; v.x = (u32)t; t >>= 32;
+            t += (long long)v.y; v.y = (u32)t; t >>= 32;
+            t += (long long)v.z; v.z = (u32)t; t >>= 32;
+            t += (long long)v.w; v.w = (u32)t; t >>= 32;
+            blk[b * CB + ci] = v;
+            cin = t + bcar[b * CB + ci];
         }
-        long long top = carry + (long long)(colLo[(W - 1) * CB + ci] >> 32) + (W >= 2 ? (long long)colHi[(W - 2) * CB + ci] : 0);
-        top += (long long)colHi[(W - 1) * CB + ci] << 32;              // weight 2^(32(W+1)) relative to word W-1: enough for the sign
-        // top = floor((S - q*M) / 2^(32W)): negative => S - qM < 0, zero => in [0, 2^(32W))
+        // S - q*M lies in (-M, 2M) and M < 2^(32W): everything above word W-1 (the zero-padded words of the last block and
+        // the final carry) is its sign extension: cin < 0  <=>  negative
+        auto word = [&](int k) -> u32 & { return out[((k >> 2) * CB + ci) * 4 + (k & 3)]; };
         int fix = 0;                          // +1: add M, -1: subtract M
-        if (top < 0) fix = 1;
+        if (cin < 0) fix = 1;
         else {
             bool ge = true;                   // out >= M ?
             for (int k = W - 1; k >= 0; --k) {
-                u32 x = out[k * CB + ci], y = it.M[k];
+                const u32 x = word(k), y = it.M[k];
                 if (x != y) { ge = x > y; break; }
             }
             if (ge) fix = -1;
@@ -645,8 +650,8 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
         if (fix != 0) {
             long long cy = 0;
             for (int k = 0; k < W; ++k) {
-                long long t = (long long)out[k * CB + ci] + (long long)fix * (long long)it.M[k] + cy;
-                out[k * CB + ci] = (u32)t;
+                const long long t = (long long)word(k) + (long long)fix * (long long)it.M[k] + cy;
+                word(k) = (u32)t;
                 cy = t >> 32;
             }
         }
@@ -655,7 +660,7 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
     const long slab = (long)nvalid * W;
     for (long e = threadIdx.x; e < slab; e += CB * NG) {
         const int c2 = (int)(e / W), k = (int)(e % W);
-        dst[base * W + e] = out[k * CB + c2];
+        dst[base * W + e] = out[((k >> 2) * CB + c2) * 4 + (k & 3)];
     }
 }
 

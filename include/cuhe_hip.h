@@ -186,11 +186,11 @@ int cuhe_hip_mul_relin_batch(uint32_t *dst, const uint64_t *a_ntt, const uint64_
 /* CuCtxt::relin for `batch` reduced CRT-domain ciphertexts of one level: src, dst = u32[batch][np][crtLen]
    (dst may be src); bit-identical to icrt, relinearization, intt_mod per ciphertext */
 int cuhe_hip_relin_batch(uint32_t *dst, const uint32_t *src_crt, int lvl, int batch, int dev, void *stream);
-/* On large rings (>= 1 GiB of keys per level) the two calls above hand groups of four ciphertexts round-robin to `n`
-   streams: the caller's stream and n-1 helper streams of the calling thread, own scratch each; the caller's stream
-   waits for the helpers before the call's work counts as done on it.  The HBM-bound inner product of one group
-   overlaps the transforms of another.  n = 1..4, default 3; 1 = everything on
-   the caller's stream; -n = n streams whatever the ring size (tests).  Results do not depend on n. */
+/* Optional: on large rings (>= 1 GiB of keys per level) the two calls above can hand groups of four ciphertexts round-robin
+   to `n` streams: the caller's stream and n-1 helper streams of the calling thread, own scratch each; the caller's stream
+   waits for the helpers before the call's work counts as done on it.  n = 1..4, default 1 = everything on the caller's
+   stream in one launch sequence (fastest since the inner product shares key fetches across the whole batch);
+   -n = n streams whatever the ring size (tests).  Results do not depend on n. */
 int cuhe_hip_set_relin_lanes(int n);
 /* `batch` independent full multiplications raw -> raw of one level in one call (mulZZX without the host staging,
    CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the

@@ -629,7 +629,7 @@ def test_reentrant_host_threads(gu):
         threads = [threading.Thread(target=work2, args=(t,)) for t in range(T)]
         for th in threads: th.start()
         for th in threads: th.join()
-        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(3))
+        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(1))
         assert not errors, errors
         for t in range(T):
             got = gu.host_u32(stacks[t][2]).reshape(B2, npr, q.crtLen)
@@ -728,7 +728,7 @@ def test_mul_relin_batch_equals_single(gu, args):
             got2 = gu.host_u32(out).reshape(B, npr, q.crtLen)
             for i in range(B):
                 assert np.array_equal(got2[i], again[i]), ("relin_batch", lvl, B, i)
-        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(3))
+        gu.ck(gu.lib.cuhe_hip_set_relin_lanes(1))
         assert gu.lib.cuhe_hip_set_relin_lanes(0) != 0 and gu.lib.cuhe_hip_set_relin_lanes(5) != 0 and gu.lib.cuhe_hip_set_relin_lanes(-5) != 0
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, 0, 0, None) != 0      # batch < 1
         assert gu.lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 99, 1, 0, None) != 0     # bad level
