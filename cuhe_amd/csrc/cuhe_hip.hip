@@ -1384,9 +1384,18 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
                        (size_t)W * kWinCoef * 4, S(st), Wp->win, src, W, q.logRelin, k, q.crtLen, q.crtLen, 0L, 0L);
     HIPCHK(hipGetLastError());
     CHK(ct_forward(Wp->relin, Wp->win, k, dev, S(st)));
-    constexpr int PB = 4;
-    hipLaunchKernelGGL((k_relin_mac<PB, 1>), dim3((L / 512) * ((count + PB - 1) / PB), 1, 1), dim3(256), 0, S(st), (u64 *)dst, Wp->relin,
-                       D.ek + (size_t)prime0 * q.numEvalKey * L, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
+    // primes per workgroup (each window value fetched from cache serves PB key streams): as many as still leave ~6
+    // workgroups per CU -- the kernel streams the keys from HBM and needs that many loads in flight (12 waves per CU reach
+    // 4.3 TB/s, 24 reach 6 TB/s: profiles/r02_experiments_log.txt)
+    const u64 *ekp = D.ek + (size_t)prime0 * q.numEvalKey * L;
+    const long target = 6L * 256;
+    auto blocks = [&](int pb) { return (long)(L / 512) * ((count + pb - 1) / pb); };
+    if (blocks(4) >= target || count <= 1)
+        hipLaunchKernelGGL((k_relin_mac<4, 1>), dim3((unsigned)blocks(4)), dim3(256), 0, S(st), (u64 *)dst, Wp->relin, ekp, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
+    else if (blocks(2) >= target || count <= 2)
+        hipLaunchKernelGGL((k_relin_mac<2, 1>), dim3((unsigned)blocks(2)), dim3(256), 0, S(st), (u64 *)dst, Wp->relin, ekp, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
+    else
+        hipLaunchKernelGGL((k_relin_mac<1, 1>), dim3((unsigned)blocks(1)), dim3(256), 0, S(st), (u64 *)dst, Wp->relin, ekp, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
