@@ -1,23 +1,28 @@
 #!/bin/bash
 # End-of-round evidence run on the GPU box: test-suite, default bench line, kernel trace of the same command, and the
-# PMC passes (one counter family per pass, each with --kernel-trace only).  Text summaries land in gpurun_out/final/.
-# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests]
+# PMC passes (one counter family per pass, each with --kernel-trace only).  Text summaries land in gpurun_out/final/;
+# tools/make_traffic_json.py turns the PMC passes into profiles/traffic_rNN.json (bytes and VALU lane-instructions per
+# transform, tagged with the hash of the kernel sources bench.py checks).
+# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r02]
 export TMPDIR=/tmp
+tag=${2:-r02}
 out=$PWD/gpurun_out/final; mkdir -p $out
-if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
-python bench.py 2>/dev/null | tail -1 > $out/bench_n1.json
+if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
+timeout 600 python bench.py 2>/dev/null | tail -1 > $out/bench_n1.json
 python - <<PY
 import json; d = json.load(open("$out/bench_n1.json")); r = d["roofline"]
 print("NTT/s", d["value"], "frac", r["frac"], "copy GB/s", r.get("measured_copy_GBs"), "mul_relin ms", d["mul_relin"]["ms"], "batched", d["mul_relin"]["batched"]["ms_per_ciphertext"],
-      "mul_full ms", d["mul_full"]["ms"], "batched", d["mul_full"]["batched"]["ms_per_multiply"])
+      "mul_full ms", d["mul_full"]["ms"], "batched", d["mul_full"]["batched"]["ms_per_multiply"], "prince", (d.get("prince") or {}).get("value"))
 PY
+R=$PWD
 cd /tmp
 rm -rf /tmp/pf_*
-rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o s -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu > /dev/null 2>&1
-python $OLDPWD/tools/rocpd_summary.py /tmp/pf_stats/s_results.db > $out/kernel_trace_stats.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-prince > /dev/null 2>&1
+python $R/tools/rocpd_summary.py /tmp/pf_stats/s_results.db > $out/kernel_trace_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pf_$c -o p -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-mulrelin --no-cpu > /dev/null 2>&1
-  python $OLDPWD/tools/rocpd_summary.py /tmp/pf_$c/p_results.db 2>&1 | grep -E "^==|^kernel|ntt_pass" > $out/pmc_$c.txt
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pf_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-mulrelin --no-cpu --no-prince > /dev/null 2>&1
+  python $R/tools/rocpd_summary.py /tmp/pf_$c/p_results.db 2>&1 | grep -E "^==|^kernel|ntt_pass" > $out/pmc_$c.txt
 done
-cd $OLDPWD
-head -4 $out/kernel_trace_stats.txt | cut -c1-200; cat $out/pmc_*.txt | grep -E "FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU" | cut -c1-44,100-220
+cd $R
+python tools/make_traffic_json.py $out $tag > $out/traffic_$tag.json && cat $out/traffic_$tag.json
+head -14 $out/kernel_trace_stats.txt | cut -c1-72,110-200
