@@ -50,6 +50,7 @@ int fail(int code, const char *fmt, ...) {
 struct NttTab {
     u64 *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of pass 1; T2 / T2inv: outer twiddles (x L^-1)
     u64 *tw = nullptr, *twinv = nullptr;                    // negacyclic twist psi^j and psi^-j, psi^2 = w_L (ensure_twist)
+    u64 *Wn1 = nullptr;                                     // w_N1^e, e < N1: stage twiddles of the low-latency pass 1
     int chunk = 0;                             // transforms per launch pair (slab size / transform size)
 };
 // Mutable scratch of ONE host thread on one device.  The reference keeps a single set per device and is therefore
@@ -285,6 +286,9 @@ int make_ntt_tables(NttTab &tab) {
     std::vector<u64> t1w((size_t)N1);
     for (int c = 0; c < RA; ++c)
         for (int b = 0; b < 64; ++b) t1w[(size_t)c * 64 + b] = r[(64L * b * c) % L];
+    std::vector<u64> wn1((size_t)N1);
+    for (int e = 0; e < N1; ++e) wn1[e] = r[64L * e];
+    CHK(upload(&tab.Wn1, wn1));
     CHK(upload(&tab.T1w, t1w));
     CHK(upload(&tab.T2, t2));
     CHK(upload(&tab.T2inv, t2i));
@@ -350,14 +354,23 @@ struct AttrOnce {
         return CUHE_OK;
     }
 };
+// rows per call up to which the low-latency kernels (4 values per thread, ntt_kernels.cuh) replace the throughput ones
+int g_ll_rows = getenv("CUHE_LL_ROWS") ? atoi(getenv("CUHE_LL_ROWS")) : 40;     // (environment override: A/B runs of whole programs)
 template <int LG, int MODE>
-int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st) {
+int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st, bool ll) {
+    if (MODE == kSrcU32Twist && !tab.tw) return fail(CUHE_EINVAL, "negacyclic twist table missing");
+    if (ll) {
+        using Gl = P1llGeom<LG>;
+        const int grid = ((nb + 7) / 8) * 8 * (64 / Gl::CW);
+        hipLaunchKernelGGL((ntt_pass1_ll<LG, MODE>), dim3(grid), dim3(Gl::T), Gl::bytes, st, src, scratch, (const u64 *)tab.Wn1, src_stride, nb, wa, (const u64 *)tab.tw);
+        HIPCHK(hipGetLastError());
+        return CUHE_OK;
+    }
     using Gw = P1wGeom<LG>;
     static AttrOnce once;
     auto kern = ntt_pass1w<LG, MODE>;
     CHK(once.set(kern, (int)Gw::bytes));
     const int grid = ((nb + 7) / 8) * 8 * (64 / Gw::NC);
-    if (MODE == kSrcU32Twist && !tab.tw) return fail(CUHE_EINVAL, "negacyclic twist table missing");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa, (const u64 *)tab.tw);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
@@ -367,15 +380,19 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stri
 struct Epilogue { int kind = 0; const u32 *aux = nullptr; long aux_stride = 0; FoldGeom fg{0, 0, 0, 0, 0}; };
 template <int LG, int OUT>
 int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stride, int nb, int nstore, const u32 *primes,
-                 const u64 *pinv, int prime0, hipStream_t st, int np_mod = 0, const Epilogue *ep = nullptr, const u64 *xtab = nullptr) {
+                 const u64 *pinv, int prime0, hipStream_t st, bool ll, int np_mod = 0, const Epilogue *ep = nullptr, const u64 *xtab = nullptr) {
     constexpr int N1 = (1 << LG) / 64;
     if ((OUT == kOutU64Mul || OUT == kOutModPNc) && !xtab) return fail(CUHE_EINVAL, "pass 2: table missing");
-    const int grid = ((nb + 7) / 8) * 8 * (N1 / kP2wCols);
     const Epilogue none;
     const Epilogue &e = ep ? *ep : none;
-    hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(grid), dim3(256), kP2wLdsBytes, st, dst, scratch,
-                       out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
-                       e.aux, e.aux_stride, e.fg, xtab);
+    if (ll)
+        hipLaunchKernelGGL((ntt_pass2_ll<LG, OUT>), dim3(((nb + 7) / 8) * 8 * (N1 / kP2llCols)), dim3(256), 0, st, dst, scratch,
+                           out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
+                           e.aux, e.aux_stride, e.fg, xtab);
+    else
+        hipLaunchKernelGGL((ntt_pass2w<LG, OUT>), dim3(((nb + 7) / 8) * 8 * (N1 / kP2wCols)), dim3(256), kP2wLdsBytes, st, dst, scratch,
+                           out_is_inverse(OUT) ? tab.T2inv : tab.T2, dst_stride, nb, nstore, primes, pinv, prime0, np_mod,
+                           e.aux, e.aux_stride, e.fg, xtab);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -414,6 +431,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         HIPCHK(hipStreamWaitEvent(D.s1, D.ev_start, 0));
         HIPCHK(hipStreamWaitEvent(D.s2, D.ev_start, 0));
     }
+    const bool ll = batch <= g_ll_rows;                  // few rows: the duration of one workgroup is what counts
     int c = 0, last = 0;
     for (int b0 = 0; b0 < batch; b0 += chunk, ++c) {
         const int nb = std::min(chunk, batch - b0);
@@ -423,16 +441,16 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
         if (mode == kSrcU32Ext) {
             const u32 *s = (const u32 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU32Ext>(s, slab, tab, src_stride, nb, wa, q1)));
+            CHK((launch_pass1<LG, kSrcU32Ext>(s, slab, tab, src_stride, nb, wa, q1, ll)));
         } else if (mode == kSrcU32Twist) {
             const u32 *s = (const u32 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU32Twist>(s, slab, tab, src_stride, nb, wa, q1)));
+            CHK((launch_pass1<LG, kSrcU32Twist>(s, slab, tab, src_stride, nb, wa, q1, ll)));
         } else if (mode == kSrcWindow) {
             WindowArgs w2 = wa; w2.wid0 += b0;
-            CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, 0, nb, w2, q1)));
+            CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, 0, nb, w2, q1, ll)));
         } else {
             const u64 *s = (const u64 *)src + (long)b0 * src_stride;
-            CHK((launch_pass1<LG, kSrcU64Neg>(s, slab, tab, src_stride, nb, wa, q1)));
+            CHK((launch_pass1<LG, kSrcU64Neg>(s, slab, tab, src_stride, nb, wa, q1, ll)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p1[sl], q1)); HIPCHK(hipStreamWaitEvent(q2, D.ev_p1[sl], 0)); }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
@@ -441,15 +459,15 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             if (ep && ep->kind) {
                 Epilogue e = *ep;
                 if (e.aux) e.aux += (long)b0 * e.aux_stride;
-                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod, &e)));
-                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod, &e)));
-            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, np_mod, nullptr, tab.twinv)));
-            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, np_mod)));
-            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, np_mod)));
+                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
+                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
+            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, nullptr, tab.twinv)));
+            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
+            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, np_mod, nullptr, mul_tab)));
-            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll, np_mod, nullptr, mul_tab)));
+            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
@@ -847,7 +865,7 @@ int cuhe_hip_shutdown(void) {
         if (hipSetDevice(phys_dev(d)) != hipSuccess) { (void)hipGetLastError(); continue; }
         (void)hipDeviceSynchronize();
         DevCtx &D = G_.dev[d];
-        for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); t = NttTab(); }
+        for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); hipFree(t.Wn1); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         if (D.sh_stream) { hipStreamDestroy(D.sh_stream); hipEventDestroy(D.sh_e1); hipEventDestroy(D.sh_e2); }
         void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek};
@@ -1893,6 +1911,7 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     return CUHE_OK;
 }
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
+int cuhe_hip_set_ll_rows(int rows) { if (rows < 0) return fail(CUHE_EINVAL, "rows %d", rows); g_ll_rows = rows; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {
     CHK(set_dev(dev));
     if (lg_index(len) < 0) return fail(CUHE_EINVAL, "length %d", len);

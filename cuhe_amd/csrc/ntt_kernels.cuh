@@ -42,6 +42,32 @@ __device__ __forceinline__ void xcd_map(int tiles, int &batch, int &tile) {
 
 struct WindowArgs { int words, w, wid0; };
 
+// sample `idx` of transform `batch` as pass 1 sees it, for every source kind (see the enum above)
+template <int LG, int MODE>
+__device__ __forceinline__ u64 load_sample(const void *__restrict__ src_, long src_stride, int batch, int idx, const WindowArgs &wa,
+                                           const u64 *__restrict__ tw) {
+    constexpr int L = 1 << LG;
+    if constexpr (MODE == kSrcU32Ext) {
+        const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
+        return src[idx];
+    } else if constexpr (MODE == kSrcWindow) {
+        // cuhe/Base.cu:361-371: w-bit window `wid` of a W-word coefficient
+        const u32 *co = (const u32 *)src_ + (long)idx * wa.words;
+        const int bit = wa.w * (wa.wid0 + batch);
+        const int wi = bit >> 5;
+        u64 sv = co[wi];
+        if (wi + 1 < wa.words) sv |= (u64)co[wi + 1] << 32;
+        sv >>= (bit & 31);
+        return sv & (u64)((1u << wa.w) - 1u);
+    } else if constexpr (MODE == kSrcU32Twist) {
+        const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
+        return mulp_u32(tw[idx], src[idx]);
+    } else {
+        const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
+        return src[(L - idx) & (L - 1)];
+    }
+}
+
 // first DIF stage when the upper half of the input is zero (u + 0, (u - 0)*w^j)
 template <int N, int J>
 struct ExtStage {
@@ -114,6 +140,92 @@ struct StepAWrite {
     }
 };
 
+// Store epilogue of pass 2, shared by both forms of the kernel: the thread holds the four outputs X[k1 + N1*(b + 16c)],
+// c < 4, of column k1 in y[bitrev4(c)] (what dft_regs<4> leaves) and applies what OUT asks for (see the enum above).
+struct P2Store {
+    void *dst_; long dst_stride; int nstore; const u32 *aux; long aux_stride; FoldGeom fg; const u64 *xtab;
+    u32 p; u64 m; int pidx, k2full, rem;
+};
+template <int LG, int OUT>
+__device__ __forceinline__ void pass2_store(const u64 (&y)[4], int b, int k1, int batch, const P2Store &A) {
+    constexpr int L = 1 << LG, N1 = L / 64;
+    const u32 p = A.p; const u64 m = A.m;
+    if constexpr (OUT == kOutU64) {
+        u64 *dst = (u64 *)A.dst_ + (long)batch * A.dst_stride + k1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(y[bitrev<4>(c)], &dst[(long)(b + 16 * c) * N1]);
+    } else if constexpr (OUT == kOutU64Mul) {
+        u64 *dst = (u64 *)A.dst_ + (long)batch * A.dst_stride + k1;
+        const u64 *tab = A.xtab + (long)A.pidx * L + k1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long o = (long)(b + 16 * c) * N1;
+            __builtin_nontemporal_store(mulp(y[bitrev<4>(c)], tab[o]), &dst[o]);
+        }
+    } else if constexpr (OUT == kOutModP) {
+        u32 *dst = (u32 *)A.dst_ + (long)batch * A.dst_stride + k1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k2 = b + 16 * c;
+            if (k2 < A.k2full || (k2 == A.k2full && k1 < A.rem)) dst[(long)k2 * N1] = mod_small(y[bitrev<4>(c)], p, m);
+        }
+    } else if constexpr (OUT == kOutModPNc) {
+        u32 *dst = (u32 *)A.dst_ + (long)batch * A.dst_stride + k1;
+        const u64 *ti = A.xtab + k1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long o = (long)(b + 16 * c) * N1;
+            const u64 v = mulp(y[bitrev<4>(c)], ti[o]);
+            const bool neg = v > (kP >> 1);                       // centred lift: v - P < 0
+            const u32 rr = mod_small(neg ? kP - v : v, p, m);
+            dst[o] = (neg && rr) ? p - rr : rr;
+        }
+    } else if constexpr (OUT == kOutModPRevQ) {
+        u32 *dst = (u32 *)A.dst_ + (long)batch * A.dst_stride;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = (b + 16 * c) * N1 + k1;
+            if (idx < A.fg.Kq) dst[A.fg.Kq - 1 - idx] = mod_small(y[bitrev<4>(c)], p, m);
+            else if (idx < A.nstore) dst[idx] = 0u;
+        }
+    } else if constexpr (OUT == kOutFoldFinal) {
+        u32 *dst = (u32 *)A.dst_ + (long)batch * A.dst_stride;
+        const u32 *frow = A.aux + (long)batch * A.aux_stride;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = (b + 16 * c) * N1 + k1;
+            if (idx < A.fg.n) {
+                u32 a = fold_g(frow, idx, A.fg, p);
+                if (idx + A.fg.Lh < A.fg.D) { a += fold_g(frow, idx + A.fg.Lh, A.fg, p); if (a >= p) a -= p; }
+                const u32 qphi = mod_small(y[bitrev<4>(c)], p, m);
+                dst[idx] = a >= qphi ? a - qphi : a + p - qphi;
+            } else if (idx < A.nstore) dst[idx] = 0u;
+        }
+    } else {
+        // inverse transform of a product fused with the reduction modulo x^(L/2) + 1 (inttMod when Phi_m = x^n + 1,
+        // n = L/2): the thread owns f[i] (k2 = b + 16c) and f[i + n] (k2 + 32, i.e. c + 2); r[i] = (f[i] - f[i+n]) mod p_i.
+        // The values are the exact integer coefficients (< P), so the signed difference is reduced once.
+        u32 *dst = (u32 *)A.dst_ + (long)batch * A.dst_stride + k1;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const u64 a = y[bitrev<4>(c)], bb = y[bitrev<4>(c + 2)];
+            const bool neg = a < bb;
+            const u32 rr = mod_small(neg ? bb - a : a - bb, p, m);
+            dst[(long)(b + 16 * c) * N1] = (neg && rr) ? p - rr : rr;
+        }
+    }
+}
+template <int LG, int OUT>
+__device__ __forceinline__ P2Store pass2_store_args(void *dst_, long dst_stride, int nstore, const u32 *primes, const u64 *pinv, int prime0, int np_mod,
+                                                    const u32 *aux, long aux_stride, const FoldGeom &fg, const u64 *xtab, int batch) {
+    constexpr int N1 = (1 << LG) / 64;
+    constexpr bool INV = out_is_inverse(OUT);
+    P2Store A{dst_, dst_stride, nstore, aux, aux_stride, fg, xtab, 0u, 0ull, 0, 64, 0};
+    A.pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
+    if constexpr (INV) { A.p = primes[A.pidx]; A.m = pinv[A.pidx]; A.k2full = nstore / N1; A.rem = nstore % N1; }
+    return A;
+}
+
 template <int LG, int OUT>
 __global__ __launch_bounds__(256, 4)
 void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
@@ -151,10 +263,7 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
     }
     __syncthreads();
     const int w = r;
-    u32 p = 0; u64 m = 0;
-    const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
-    if constexpr (INV) { p = primes[pidx]; m = pinv[pidx]; }
-    const int k2full = INV ? nstore / N1 : 64, rem = INV ? nstore % N1 : 0;
+    const P2Store A = pass2_store_args<LG, OUT>(dst_, dst_stride, nstore, primes, pinv, prime0, np_mod, aux, aux_stride, fg, xtab, batch);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int b = 4 * i + w;
@@ -162,70 +271,7 @@ void ntt_pass2w(void *__restrict__ dst_, const u64 *__restrict__ scratch, const 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) y[rr] = lds[(b * 4 + rr) * kP2wCols + lane];
         dft_regs<4, false>(y);                                           // y[bitrev4(c)] = X[b + 16c]
-        if constexpr (OUT == kOutU64) {
-            u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(y[bitrev<4>(c)], &dst[(long)(b + 16 * c) * N1]);
-        } else if constexpr (OUT == kOutU64Mul) {
-            u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + k1;
-            const u64 *tab = xtab + (long)pidx * L + k1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const long o = (long)(b + 16 * c) * N1;
-                __builtin_nontemporal_store(mulp(y[bitrev<4>(c)], tab[o]), &dst[o]);
-            }
-        } else if constexpr (OUT == kOutModP) {
-            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int k2 = b + 16 * c;
-                if (k2 < k2full || (k2 == k2full && k1 < rem)) dst[(long)k2 * N1] = mod_small(y[bitrev<4>(c)], p, m);
-            }
-        } else if constexpr (OUT == kOutModPNc) {
-            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
-            const u64 *ti = xtab + k1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const long o = (long)(b + 16 * c) * N1;
-                const u64 v = mulp(y[bitrev<4>(c)], ti[o]);
-                const bool neg = v > (kP >> 1);                       // centred lift: v - P < 0
-                const u32 rr = mod_small(neg ? kP - v : v, p, m);
-                dst[o] = (neg && rr) ? p - rr : rr;
-            }
-        } else if constexpr (OUT == kOutModPRevQ) {
-            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int idx = (b + 16 * c) * N1 + k1;
-                if (idx < fg.Kq) dst[fg.Kq - 1 - idx] = mod_small(y[bitrev<4>(c)], p, m);
-                else if (idx < nstore) dst[idx] = 0u;
-            }
-        } else if constexpr (OUT == kOutFoldFinal) {
-            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride;
-            const u32 *frow = aux + (long)batch * aux_stride;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int idx = (b + 16 * c) * N1 + k1;
-                if (idx < fg.n) {
-                    u32 a = fold_g(frow, idx, fg, p);
-                    if (idx + fg.Lh < fg.D) { a += fold_g(frow, idx + fg.Lh, fg, p); if (a >= p) a -= p; }
-                    const u32 qphi = mod_small(y[bitrev<4>(c)], p, m);
-                    dst[idx] = a >= qphi ? a - qphi : a + p - qphi;
-                } else if (idx < nstore) dst[idx] = 0u;
-            }
-        } else {
-            // inverse transform of a product fused with the reduction modulo x^(L/2) + 1 (inttMod when Phi_m = x^n + 1,
-            // n = L/2): the thread owns f[i] (k2 = b + 16c) and f[i + n] (k2 + 32, i.e. c + 2); r[i] = (f[i] - f[i+n]) mod p_i.
-            // The values are the exact integer coefficients (< P), so the signed difference is reduced once.
-            u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + k1;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const u64 a = y[bitrev<4>(c)], bb = y[bitrev<4>(c + 2)];
-                const bool neg = a < bb;
-                const u32 rr = mod_small(neg ? bb - a : a - bb, p, m);
-                dst[(long)(b + 16 * c) * N1] = (neg && rr) ? p - rr : rr;
-            }
-        }
+        pass2_store<LG, OUT>(y, b, k1, batch, A);
     }
 }
 
@@ -288,24 +334,7 @@ void ntt_pass1w(const void *__restrict__ src_, u64 *__restrict__ scratch,
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             const int idx = (a * 64 + b) * 64 + col0 + col;
-            if constexpr (MODE == kSrcU32Ext) {
-                const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
-                x[a] = src[idx];
-            } else if constexpr (MODE == kSrcWindow) {
-                const u32 *co = (const u32 *)src_ + (long)idx * wa.words;
-                const int bit = wa.w * (wa.wid0 + batch);
-                const int wi = bit >> 5;
-                u64 sv = co[wi];
-                if (wi + 1 < wa.words) sv |= (u64)co[wi + 1] << 32;
-                sv >>= (bit & 31);
-                x[a] = sv & (u64)((1u << wa.w) - 1u);
-            } else if constexpr (MODE == kSrcU32Twist) {
-                const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
-                x[a] = mulp_u32(tw[idx], src[idx]);
-            } else {
-                const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
-                x[a] = src[(L - idx) & (L - 1)];
-            }
+            x[a] = load_sample<LG, MODE>(src_, src_stride, batch, idx, wa, tw);
         }
         dft_regs<RA, EXT>(x);
 #pragma unroll
@@ -345,6 +374,178 @@ void ntt_pass1w(const void *__restrict__ src_, u64 *__restrict__ scratch,
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) out[RA * (bb + 16 * cc)] = z[bitrev<4>(cc)];
     }
+}
+
+// ===============================================================================================================
+// Low-latency forms of both passes, for calls with FEW rows (a lone ciphertext operation transforms 1-100 rows).
+// The kernels above give every thread 16 values in each of three dependent register stages: with a few dozen
+// workgroups on a 256-CU chip their duration (13 + 9 us) is the latency of ONE workgroup, not a throughput.  Here a
+// thread carries FOUR values per stage and every stage is a radix-4 decimation-in-frequency step done in place in
+// LDS (general twiddles from a table in pass 1, powers of two in pass 2): 4x the threads per transform, a quarter of the
+// work per thread between barriers.  More instructions per point than the 16-value forms (the in-register stages of
+// those need no twiddle multiplications), so the host uses these only below a row count (cuhe_hip_set_ll_rows).
+// Same inputs (every MODE), same slab layout scratch[j2][k1], same store epilogues (every OUT): bit-identical results.
+// ===============================================================================================================
+// x * 2^(3e) mod P for a run-time e in [0, 64): 2^k is 1 << k below 2^64, eps << (k - 64) up to 2^96, and 2^96 = -1
+__device__ __forceinline__ u64 mul_w64(u64 x, int e) {
+    int k = 3 * e;
+    const bool neg = k >= 96;
+    if (neg) k -= 96;
+    const u64 c = k < 64 ? (1ULL << k) : ((u64)0xffffffffu << (k - 64));
+    const u64 y = mulp(x, c);
+    return neg ? negp(y) : y;
+}
+// in-place radix-4 DIF step on the four values x[a] = v[pos + a * Q] of a block (Q = a quarter of the block length):
+// y[b] = sum_a x[a] w4^(ab), left in x[bitrev4(b)]
+__device__ __forceinline__ void ll_dft4(u64 (&x)[4]) { dft_regs<4, false>(x); }
+
+template <int LG> struct P1llGeom {
+    static constexpr int N1 = (1 << LG) / 64, CW = 4, Q = N1 / 4, T = CW * Q, S = N1 + 8;      // T = N1 threads; S = 8 (mod 32): conflict-free columns
+    static constexpr size_t bytes = (size_t)CW * S * sizeof(u64);
+    static constexpr bool HALF = (LG == 15);              // N1 = 512 = 2 * 4^4: one radix-2 step first
+};
+// one radix-4 stage on block length M of the column buffer: thread i owns butterfly (block i / (M/4), offset i % (M/4))
+template <int N1, int M>
+__device__ __forceinline__ void ll_stage(u64 *buf, int i, const u64 *__restrict__ Wn1) {
+    constexpr int Qm = M / 4;
+    const int blk = i / Qm, o = i % Qm;
+    u64 *v = buf + blk * M + o;
+    u64 x[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) x[a] = v[a * Qm];
+    ll_dft4(x);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        u64 y = x[bitrev<4>(b)];
+        if constexpr (M > 4) { if (b) y = mulp(y, Wn1[(o * b) * (N1 / M)]); }
+        v[b * Qm] = y;
+    }
+}
+template <int N1> __host__ __device__ constexpr int ll_rev(int i, int digits4, bool lead2) {
+    // position -> output index of the in-place DIF: base-4 digit reversal (after an optional leading binary digit)
+    (void)lead2;
+    int r = 0;
+    for (int d = 0; d < digits4; ++d) { r = r * 4 + (i & 3); i >>= 2; }
+    return r;
+}
+
+template <int LG, int MODE>
+__global__ __launch_bounds__(P1llGeom<LG>::T)
+void ntt_pass1_ll(const void *__restrict__ src_, u64 *__restrict__ scratch, const u64 *__restrict__ Wn1,
+                  long src_stride, int nbatch, WindowArgs wa, const u64 *__restrict__ tw) {
+    using G = P1llGeom<LG>;
+    constexpr int L = 1 << LG, N1 = G::N1, CW = G::CW, Q = G::Q;
+    constexpr bool EXT = src_is_ext(MODE);
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    int batch, tile;
+    xcd_map(64 / CW, batch, tile);
+    if (batch >= nbatch) return;
+    const int col = threadIdx.x % CW, i = threadIdx.x / CW;            // adjacent lanes: adjacent columns (16 B of a u32 row)
+    const int j2 = tile * CW + col;
+    u64 *buf = lds + col * G::S;
+    // ---- first step, from global memory: the samples j1 = i + Q a of column j2 (the zero-padded half is never read)
+    u64 x[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (EXT && a >= 2) x[a] = 0;
+        else x[a] = load_sample<LG, MODE>(src_, src_stride, batch, (i + Q * a) * 64 + j2, wa, tw);
+    }
+    if constexpr (G::HALF) {
+        // N1 = 512: radix-2 over (a, a + 2), twiddle w_512^(i + Q a') on the differences; then blocks of 256
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const u64 u = x[a], v = x[a + 2];
+            x[a] = EXT ? u : addp(u, v);
+            const u64 d = EXT ? u : subp(u, v);
+            buf[i + Q * (a + 2)] = mulp(d, Wn1[i + Q * a]);
+            buf[i + Q * a] = x[a];
+        }
+        __syncthreads();
+        ll_stage<N1, 256>(buf, i, Wn1); __syncthreads();
+    } else {
+        ll_dft4(x);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            u64 y = x[bitrev<4>(b)];
+            if (b) y = mulp(y, Wn1[i * b]);
+            buf[i + Q * b] = y;
+        }
+        __syncthreads();
+        if constexpr (N1 == 1024) { ll_stage<N1, 256>(buf, i, Wn1); __syncthreads(); }
+    }
+    ll_stage<N1, 64>(buf, i, Wn1); __syncthreads();
+    ll_stage<N1, 16>(buf, i, Wn1); __syncthreads();
+    // ---- last step (blocks of 4) straight to the slab: position 4 i + b holds X[k1], k1 = digit reversal of the position
+    {
+        u64 *v = buf + 4 * i;
+        u64 y[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) y[a] = v[a];
+        ll_dft4(y);
+        u64 *out = scratch + (long)batch * L + (long)j2 * N1;
+        constexpr int D4 = (LG == 14) ? 4 : (LG == 15 ? 4 : 5);         // base-4 digits of a position (after the leading bit at 512)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int pos = 4 * i + b;
+            int k1;
+            if constexpr (G::HALF) {
+                // pos = h * 256 + r, r in base 4 (4 digits): k1 = h + 2 * rev4(r)
+                k1 = (pos >> 8) + 2 * ll_rev<N1>(pos & 255, 4, false);
+            } else k1 = ll_rev<N1>(pos, D4, false);
+            out[k1] = y[bitrev<4>(b)];
+        }
+    }
+}
+
+// pass 2: 16 adjacent k1 per workgroup (128-byte runs of the slab and of the output), 16 threads x 4 values per column
+static constexpr int kP2llCols = 16, kP2llRS = 65;                    // odd row stride (u64): the 16 columns of a lane group fall on distinct bank pairs
+template <int LG, int OUT>
+__global__ __launch_bounds__(256)
+void ntt_pass2_ll(void *__restrict__ dst_, const u64 *__restrict__ scratch, const u64 *__restrict__ T2,
+                  long dst_stride, int nbatch, int nstore,
+                  const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
+                  const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab) {
+    constexpr int L = 1 << LG, N1 = L / 64;
+    constexpr bool INV = out_is_inverse(OUT);
+    __shared__ __attribute__((aligned(16))) u64 lds[kP2llCols * kP2llRS];
+    int batch, tile;
+    xcd_map(N1 / kP2llCols, batch, tile);
+    if (batch >= nbatch) return;
+    const int c = threadIdx.x & 15, t = threadIdx.x >> 4;               // column within the tile, butterfly index 0..15
+    const int k1 = tile * kP2llCols + c;
+    const u64 *in = scratch + (long)batch * L + k1;
+    const u64 *tw = T2 + k1;
+    u64 *v = lds + c * kP2llRS;
+    u64 x[4];
+    // block of 64: samples j2 = t + 16 a (outer twiddle on load), then * w_64^(t b)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int j2 = t + 16 * a;
+        u64 s = __builtin_nontemporal_load(&in[(long)j2 * N1]);
+        if (INV || j2 != 0) s = mulp(s, tw[(long)j2 * N1]);
+        x[a] = s;
+    }
+    ll_dft4(x);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[t + 16 * b] = b ? mul_w64(x[bitrev<4>(b)], t * b) : x[0];
+    __syncthreads();
+    // blocks of 16: w_16^(o b) = w_64^(4 o b)
+    {
+        const int blk = t >> 2, o = t & 3;
+        u64 *q = v + 16 * blk + o;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) x[a] = q[4 * a];
+        ll_dft4(x);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[4 * b] = b ? mul_w64(x[bitrev<4>(b)], 4 * o * b) : x[0];
+    }
+    __syncthreads();
+    // blocks of 4: position 4 t + b holds X[k2], k2 = rev16(t) + 16 b -- exactly what the store epilogue takes
+#pragma unroll
+    for (int a = 0; a < 4; ++a) x[a] = v[4 * t + a];
+    ll_dft4(x);
+    const P2Store A = pass2_store_args<LG, OUT>(dst_, dst_stride, nstore, primes, pinv, prime0, np_mod, aux, aux_stride, fg, xtab, batch);
+    pass2_store<LG, OUT>(x, ((t & 3) << 2) | (t >> 2), k1, batch, A);
 }
 
 }  // namespace cuhe

@@ -264,6 +264,10 @@ int cuhe_hip_set_ntt_chunk(int chunk);
 /* 1 (default): pass 2 of chunk c runs concurrently with pass 1 of chunk c+1 on two internal streams
  * (joined back into `stream` before the call returns control of it); 0: strictly serial launches */
 int cuhe_hip_set_ntt_overlap(int on);
+/* Transform calls of at most `rows` rows take the low-latency kernel pair (4 values per thread, 4x the workgroups: the
+ * duration of a lone ciphertext operation is the latency of its small kernels); larger calls the throughput pair (16
+ * values per thread).  Same results.  Default 40; 0 = never; a large value = always (tests run the suite both ways). */
+int cuhe_hip_set_ll_rows(int rows);
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,

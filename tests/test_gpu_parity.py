@@ -1032,3 +1032,81 @@ def test_sharded_multiply_through_the_c_abi(gu):
                 lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_virtual_devices(0); lib.cuhe_hip_multi_gpus(1)
         finally:
             o.close()
+
+
+@pytest.mark.parametrize("name,args", [("toy1155", (3, 2, 8, 40, 20, 1155)), ("prince_small", (3, 2, 16, 25, 25, 21845)),
+                                       ("pow2_16384", (3, 2, 16, 50, 25, 16384)), ("pow2_32768", (3, 2, 16, 48, 24, 32768)),
+                                       ("c3_65536", (9, 2, 16, 576, 24, 65536)), ("n65536", (3, 2, 16, 46, 23, 131072))])
+def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
+    """Both forms of the transform kernels (16 values per thread: throughput; 4 values per thread, radix-4 through LDS:
+    low latency, taken below cuhe_hip_set_ll_rows rows) give the same bits on every source / store variant: zero-padded
+    and full forward transforms (all three lengths), window transforms, index-negated inverses with `% p` and a ragged store
+    count, the fused x^n+1 reduction, the folded generic reduction's two epilogues, table products, the negacyclic twist
+    and untwist.  One run of each operation per form, compared with each other and (once) with the oracle."""
+    import oracle_lib as O
+    lib, ck = gu.lib, gu.ck
+    ALL, NONE = 1 << 30, 0
+    o = O.Ctx(*args) if name != "n65536" else None
+    res = {}
+    try:
+        for form in (NONE, ALL):
+            g = gu.GpuCtx(*args)
+            ck(lib.cuhe_hip_set_ll_rows(form))
+            try:
+                q = g.prm
+                K, W0, M0 = q.numEvalKey, g.words(0), g.coeff_modulus(0)
+                ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xEA00 + j)[0] for j in range(K)])
+                g.init_relin(ek_raw)
+                out = {}
+                for lvl in (0, q.depth - 1):
+                    npr, W, M = g.np_(lvl), g.words(lvl), g.coeff_modulus(lvl)
+                    a, _ = O.random_raw(q.rawLen, q.modLen, W, M, 0xA900 + lvl)
+                    b, _ = O.random_raw(q.rawLen, q.modLen, W, M, 0xB900 + lvl)
+                    ca, cb = g.crt(a, lvl), g.crt(b, lvl)
+                    out[("mul", lvl)] = g.mul_raw(a, b, lvl)
+                    out[("mulrelin", lvl)] = g.mul_relin_crt(ca, cb, lvl)
+                    out[("ctrt", lvl)] = g.ct_intt(g.ct_ntt(ca, lvl), lvl, False)
+                    if name != "n65536":
+                        X = g.ntt(ca, lvl)
+                        out[("ntt", lvl)] = X
+                        out[("intt", lvl)] = g.intt(X, lvl)
+                        out[("inttdd", lvl)] = g.intt_double_deg(g.ntt_mul(X, g.ntt(cb, lvl), lvl), lvl)
+                        out[("inttmod", lvl)] = g.intt_mod(g.ntt_mul(X, g.ntt(cb, lvl), lvl), lvl)
+                        out[("nttw", lvl)] = g.nttw(a, lvl)
+                        gu.ck(lib.cuhe_hip_force_generic_reduce(1))
+                        out[("generic", lvl)] = g.intt_mod(g.ntt_mul(X, g.ntt(cb, lvl), lvl), lvl)
+                        gu.ck(lib.cuhe_hip_force_generic_reduce(0))
+                        d = gu.empty_u32(3, q.nttLen)                       # ragged store count, prime offset
+                        nst = q.nttLen // 3 + 5
+                        ck(lib.cuhe_hip_ntt_inv_batched(d.data_ptr(), gu.to_dev(X[:3] if npr >= 3 else np.repeat(X[:1], 3, 0)).data_ptr(),
+                                                        q.nttLen, 3, q.nttLen, nst, 0 if npr < 4 else 1, 0, None))
+                        out[("ragged", lvl)] = gu.host_u32(d)
+                if form == NONE:
+                    res = out
+                    if o is not None:
+                        a0 = O.random_raw(q.rawLen, q.modLen, W0, M0, 0xA900)[0]
+                        b0 = O.random_raw(q.rawLen, q.modLen, W0, M0, 0xB900)[0]
+                        assert np.array_equal(out[("mul", 0)], o.mul_raw(a0, b0, 0))
+                else:
+                    for k, v in out.items():
+                        assert np.array_equal(v, res[k]), (name, k)
+            finally:
+                ck(lib.cuhe_hip_set_ll_rows(40))
+                g.close()
+        # the standalone batched forward entry point at all three lengths, odd batch
+        for length in (16384, 32768, 65536):
+            x = np.stack([O.splitmix_u32_below(length // 2, 0xFFFFFFFF, 900 + b) for b in range(5)])
+            ck(lib.cuhe_hip_ntt_prepare(length, 0))
+            got = []
+            for form in (NONE, ALL):
+                ck(lib.cuhe_hip_set_ll_rows(form))
+                dX = gu.empty_u64(5, length)
+                ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), gu.to_dev(x).data_ptr(), length, 5, length // 2, 0, None))
+                got.append(gu.host_u64(dX))
+            ck(lib.cuhe_hip_set_ll_rows(40))
+            assert np.array_equal(got[0], got[1]), length
+            assert np.array_equal(got[1][4], O.ntt_ext(x[4], length)), length
+    finally:
+        ck(lib.cuhe_hip_set_ll_rows(40))
+        if o is not None:
+            o.close()
