@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -51,6 +52,10 @@ struct NttTab {
     u64 *T1w = nullptr, *T2 = nullptr, *T2inv = nullptr;    // T1w: inner twiddles of pass 1; T2 / T2inv: outer twiddles (x L^-1)
     u64 *tw = nullptr, *twinv = nullptr;                    // negacyclic twist psi^j and psi^-j, psi^2 = w_L (ensure_twist)
     u64 *Wn1 = nullptr;                                     // w_N1^e, e < N1: stage twiddles of the low-latency pass 1
+    std::atomic<int> ready{0};                              // (ntt_chunk setting + 1) the tables and `chunk` below were prepared for
+    NttTab() {}
+    NttTab(const NttTab &o) : T1w(o.T1w), T2(o.T2), T2inv(o.T2inv), tw(o.tw), twinv(o.twinv), Wn1(o.Wn1), ready(o.ready.load()), chunk(o.chunk) {}
+    NttTab &operator=(const NttTab &o) { T1w = o.T1w; T2 = o.T2; T2inv = o.T2inv; tw = o.tw; twinv = o.twinv; Wn1 = o.Wn1; ready.store(o.ready.load()); chunk = o.chunk; return *this; }
     int chunk = 0;                             // transforms per launch pair (slab size / transform size)
 };
 // Mutable scratch of ONE host thread on one device.  The reference keeps a single set per device and is therefore
@@ -299,6 +304,10 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     (void)batch_hint;
     const int li = lg_index(len);
     if (li < 0) return fail(CUHE_EINVAL, "unsupported transform length %d (16384/32768/65536 only)", len);
+    {
+        const NttTab &t0 = G_.dev[dev].ntt[li];         // launch path: tables exist and the chunk setting is unchanged -> no lock
+        if (t0.ready.load(std::memory_order_acquire) == (G_.ntt_chunk + 1)) return CUHE_OK;
+    }
     std::lock_guard<std::mutex> lk(G_.mu);
     NttTab &tab = G_.dev[dev].ntt[li];
     if (!tab.T1w) {
@@ -320,6 +329,7 @@ int ensure_ntt(int dev, int len, int batch_hint) {
             HIPCHK(hipEventCreateWithFlags(&D.ev_p2[i], hipEventDisableTiming));
         }
     }
+    tab.ready.store(G_.ntt_chunk + 1, std::memory_order_release);
     return CUHE_OK;
 }
 
@@ -342,20 +352,26 @@ int ensure_twist(int dev, int len) {
 
 // hipFuncSetAttribute once per (kernel instantiation, device); host threads may race to be first
 struct AttrOnce {
-    std::mutex mu; bool done[64] = {false};
+    std::mutex mu; std::atomic<uint64_t> done{0};
     template <typename K> int set(K kern, int bytes) {
         int cur = 0;
         HIPCHK(hipGetDevice(&cur));
+        const uint64_t bit = 1ull << (cur & 63);
+        if (done.load(std::memory_order_acquire) & bit) return CUHE_OK;        // the common case: no lock on the launch path
         std::lock_guard<std::mutex> lk(mu);
-        if (!done[cur & 63]) {
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-            done[cur & 63] = true;
+            done.fetch_or(bit, std::memory_order_release);
         }
         return CUHE_OK;
     }
 };
 // rows per call up to which the low-latency kernels (4 values per thread, ntt_kernels.cuh) replace the throughput ones
-int g_ll_rows = getenv("CUHE_LL_ROWS") ? atoi(getenv("CUHE_LL_ROWS")) : 40;     // (environment override: A/B runs of whole programs)
+// measured crossover (profiles/r02_small_batch_latency.txt): the low-latency pair wins up to ~24 rows of 32K points, ~12 rows of
+// 64K points -- the threshold is in units of 32K-point rows and scales with the transform length
+int g_ll_rows = getenv("CUHE_LL_ROWS") ? atoi(getenv("CUHE_LL_ROWS")) : 24;     // (environment override: A/B runs of whole programs)
+int g_ll2_rows = getenv("CUHE_LL2_ROWS") ? atoi(getenv("CUHE_LL2_ROWS")) : -1;     // pass 2 alone (the two forms share the slab layout); -1: as pass 1
+
 template <int LG, int MODE>
 int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st, bool ll) {
     if (MODE == kSrcU32Twist && !tab.tw) return fail(CUHE_EINVAL, "negacyclic twist table missing");
@@ -431,7 +447,8 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         HIPCHK(hipStreamWaitEvent(D.s1, D.ev_start, 0));
         HIPCHK(hipStreamWaitEvent(D.s2, D.ev_start, 0));
     }
-    const bool ll = batch <= g_ll_rows;                  // few rows: the duration of one workgroup is what counts
+    const bool ll = (long)batch * L <= (long)g_ll_rows * 32768;      // few rows: the duration of one workgroup is what counts
+    const bool ll2 = g_ll2_rows < 0 ? ll : (long)batch * L <= (long)g_ll2_rows * 32768;
     int c = 0, last = 0;
     for (int b0 = 0; b0 < batch; b0 += chunk, ++c) {
         const int nb = std::min(chunk, batch - b0);
@@ -459,15 +476,15 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             if (ep && ep->kind) {
                 Epilogue e = *ep;
                 if (e.aux) e.aux += (long)b0 * e.aux_stride;
-                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
-                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
-            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, nullptr, tab.twinv)));
-            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
-            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
+                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, &e)));
+                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, &e)));
+            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, nullptr, tab.twinv)));
+            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod)));
+            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll, np_mod, nullptr, mul_tab)));
-            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll2, np_mod, nullptr, mul_tab)));
+            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll2)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }

@@ -264,9 +264,11 @@ int cuhe_hip_set_ntt_chunk(int chunk);
 /* 1 (default): pass 2 of chunk c runs concurrently with pass 1 of chunk c+1 on two internal streams
  * (joined back into `stream` before the call returns control of it); 0: strictly serial launches */
 int cuhe_hip_set_ntt_overlap(int on);
-/* Transform calls of at most `rows` rows take the low-latency kernel pair (4 values per thread, 4x the workgroups: the
- * duration of a lone ciphertext operation is the latency of its small kernels); larger calls the throughput pair (16
- * values per thread).  Same results.  Default 40; 0 = never; a large value = always (tests run the suite both ways). */
+/* Transform calls of at most rows * 32768 points in total (`rows` rows of 32K points, half as many of 64K points) take
+ * the low-latency kernel pair (4 values per thread, 4x the workgroups: the duration of a lone ciphertext operation is
+ * the latency of its small kernels); larger calls the throughput pair (16 values per thread).  Same results.  Default
+ * 24 = the measured crossover (profiles/r02_small_batch_latency.txt); 0 = never; a large value = always (the parity
+ * tests run both forms).  Environment CUHE_LL_ROWS overrides the default for A/B runs of whole programs. */
 int cuhe_hip_set_ll_rows(int rows);
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
