@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="transforms per launch pair (0 = library default)")
     ap.add_argument("--overlap", type=int, default=0, help="1: pass-1/pass-2 two-stream pipeline, 0: serial launches (default)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
-    ap.add_argument("--relin-batch", type=int, default=24, help="ciphertexts per call of the batched multiply+relinearise leg")
+    ap.add_argument("--relin-batch", type=int, default=32, help="ciphertexts per call of the batched multiply+relinearise leg")
     ap.add_argument("--relin-lanes", type=int, default=0, help="streams the batched multiply+relinearise spreads groups of 4 ciphertexts over (0 = library default)")
     ap.add_argument("--relin-threads", type=int, default=4, help="host threads of the concurrent multiply+relinearise leg (4 ciphertexts per call each)")
     ap.add_argument("--mul-batch", type=int, default=16, help="operand pairs per call of the batched full-multiply leg")

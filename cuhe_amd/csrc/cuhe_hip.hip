@@ -99,6 +99,7 @@ struct DevCtx {
     u32 *m_crt = nullptr;
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *ek = nullptr;
+    unsigned char *ekd = nullptr; MacDigGeom ekg{0, 0, 0, 0, 0};      // signed base-256 digits of the keys in MFMA operand order (built on first use)
     std::vector<Workspace *> spaces;     // every workspace of this device (owned here)
     std::vector<Workspace *> idle;       // workspaces of finished threads, adopted by later ones
     // allocator (cuhe/DeviceManager.cu:98-138)
@@ -373,12 +374,14 @@ int g_ll_rows = getenv("CUHE_LL_ROWS") ? atoi(getenv("CUHE_LL_ROWS")) : 24;     
 int g_ll2_rows = getenv("CUHE_LL2_ROWS") ? atoi(getenv("CUHE_LL2_ROWS")) : -1;     // pass 2 alone (the two forms share the slab layout); -1: as pass 1
 
 template <int LG, int MODE>
-int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st, bool ll) {
+int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st, bool ll, const u64 *second = nullptr) {
+    const u64 *tw = MODE == kSrcU64NegMul ? second : (const u64 *)tab.tw;
+    if (MODE == kSrcU64NegMul && !second) return fail(CUHE_EINVAL, "second operand missing");
     if (MODE == kSrcU32Twist && !tab.tw) return fail(CUHE_EINVAL, "negacyclic twist table missing");
     if (ll) {
         using Gl = P1llGeom<LG>;
         const int grid = ((nb + 7) / 8) * 8 * (64 / Gl::CW);
-        hipLaunchKernelGGL((ntt_pass1_ll<LG, MODE>), dim3(grid), dim3(Gl::T), Gl::bytes, st, src, scratch, (const u64 *)tab.Wn1, src_stride, nb, wa, (const u64 *)tab.tw);
+        hipLaunchKernelGGL((ntt_pass1_ll<LG, MODE>), dim3(grid), dim3(Gl::T), Gl::bytes, st, src, scratch, (const u64 *)tab.Wn1, src_stride, nb, wa, tw);
         HIPCHK(hipGetLastError());
         return CUHE_OK;
     }
@@ -387,7 +390,7 @@ int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stri
     auto kern = ntt_pass1w<LG, MODE>;
     CHK(once.set(kern, (int)Gw::bytes));
     const int grid = ((nb + 7) / 8) * 8 * (64 / Gw::NC);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa, (const u64 *)tab.tw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kP1wThreads), Gw::bytes, st, src, scratch, tab.T1w, src_stride, nb, wa, tw);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -465,13 +468,16 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         } else if (mode == kSrcWindow) {
             WindowArgs w2 = wa; w2.wid0 += b0;
             CHK((launch_pass1<LG, kSrcWindow>(src, slab, tab, 0, nb, w2, q1, ll)));
+        } else if (mode == kSrcU64NegMul) {                 // inverse transform of a product: the second operand rides in `mul_tab`
+            const u64 *s = (const u64 *)src + (long)b0 * src_stride;
+            CHK((launch_pass1<LG, kSrcU64NegMul>(s, slab, tab, src_stride, nb, wa, q1, ll, mul_tab ? mul_tab + (long)b0 * src_stride : nullptr)));
         } else {
             const u64 *s = (const u64 *)src + (long)b0 * src_stride;
             CHK((launch_pass1<LG, kSrcU64Neg>(s, slab, tab, src_stride, nb, wa, q1, ll)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p1[sl], q1)); HIPCHK(hipStreamWaitEvent(q2, D.ev_p1[sl], 0)); }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
-        if (mode == kSrcU64Neg) {
+        if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
             u32 *d = (u32 *)dst + (long)b0 * dst_stride;
             if (ep && ep->kind) {
                 Epilogue e = *ep;
@@ -626,17 +632,19 @@ bool fused_xn1() {
 }
 // ct rows -> CRT rows u32[rows][crtLen]; row r is reduced modulo prime prime0 + r (row r mod np_mod when np_mod > 0, prime0
 // = 0 then); is_prod: the rows are products of two reduced polynomials (cyclic representation: reduce modulo Phi_m)
-int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st) {
+// Y != null: the rows are the pointwise products X * Y, multiplied as pass 1 loads them (kSrcU64NegMul)
+int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st, const u64 *Y = nullptr) {
     const Params &q = G_.prm;
     const int n = q.modLen, L = q.nttLen, cl = q.crtLen;
     const WindowArgs wa{0, 0, 0};
-    if (G_.nc) return run_ntt(n, kSrcU64Neg, dst, X, rows, n, cl, kNcInverse, prime0, wa, dev, st, nullptr, nullptr, np_mod);
-    if (!is_prod) return run_ntt(L, kSrcU64Neg, dst, X, rows, L, cl, cl, prime0, wa, dev, st, nullptr, nullptr, np_mod);
-    if (fused_xn1()) return run_ntt(L, kSrcU64Neg, dst, X, rows, L, cl, kFoldXn1, prime0, wa, dev, st, nullptr, nullptr, np_mod);
+    const int mode = Y ? kSrcU64NegMul : kSrcU64Neg;
+    if (G_.nc) return run_ntt(n, mode, dst, X, rows, n, cl, kNcInverse, prime0, wa, dev, st, nullptr, Y, np_mod);
+    if (!is_prod) return run_ntt(L, mode, dst, X, rows, L, cl, cl, prime0, wa, dev, st, nullptr, Y, np_mod);
+    if (fused_xn1()) return run_ntt(L, mode, dst, X, rows, L, cl, kFoldXn1, prime0, wa, dev, st, nullptr, Y, np_mod);
     Workspace *Wp = nullptr;
     CHK(workspace(dev, st, &Wp));
     CHK(ws_barrett(*Wp, rows));
-    CHK(run_ntt(L, kSrcU64Neg, Wp->hold, X, rows, L, L, L, prime0, wa, dev, st, nullptr, nullptr, np_mod));
+    CHK(run_ntt(L, mode, Wp->hold, X, rows, L, L, L, prime0, wa, dev, st, nullptr, Y, np_mod));
     return barrett_impl(dst, Wp->hold, prime0, rows, dev, st, np_mod);
 }
 
@@ -765,6 +773,56 @@ void shl_dispatch(int l, uint64_t *z, const uint64_t *x, size_t n, hipStream_t s
     }
 }
 
+// ---- key-switch inner product on the matrix cores: key digits, launch
+bool mac_mfma_supported(int K) { return K >= 1 && K <= 128; }          // at most two K steps are instantiated
+int ensure_key_digits(int dev, hipStream_t st) {
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    if (D.ekd) return CUHE_OK;
+    const Params &q = G_.prm;
+    const int K = q.numEvalKey, np = q.numCrtPrime, L = ct_len();
+    MacDigGeom g;
+    g.nfull = K / 64;
+    const int r = K % 64;
+    g.tail = r == 0 ? 0 : r <= 32 ? 32 : 64;
+    g.tail_groups = g.tail == 32 ? (r + 7) / 8 : g.tail == 64 ? (r + 15) / 16 : 0;
+    g.lb_bytes = g.nfull * 1024 + g.tail_groups * (g.tail == 32 ? 128 : 256);
+    g.npt = (np + 15) / 16;
+    const size_t bytes = (size_t)L * g.npt * 8 * g.lb_bytes;
+    HIPCHK(hipMalloc((void **)&D.ekd, bytes));
+    D.ekg = g;
+    hipLaunchKernelGGL(k_ek_digits, dim3((L + 255) / 256, g.npt * 16, g.nfull * 4 + g.tail_groups), dim3(256), 0, st,
+                       D.ekd, (const u64 *)D.ek, K, np, L, (long)K * L, g);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));            // other host threads' streams may use the digits right after the lock is released
+    return CUHE_OK;
+}
+template <int NFULL, int TAIL>
+int launch_mac_mfma(u64 *dst, const u64 *c, const DevCtx &D, int k, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts, hipStream_t st) {
+    static AttrOnce once;
+    const int JS = (k + 2) & ~1, NPAD = ((np + 15) / 16) * 16;
+    const size_t lds = (size_t)kMacMfmaCols * (kMacMfmaCts * std::max(JS, NPAD) + 1) * sizeof(u64);
+    if (lds > 160 * 1024) return fail(CUHE_EINVAL, "window tile of %zu bytes", lds);
+    CHK(once.set(k_relin_mac_mfma<NFULL, TAIL>, 160 * 1024));
+    const int ngroups = (ncts + kMacMfmaCts - 1) / kMacMfmaCts;
+    hipLaunchKernelGGL((k_relin_mac_mfma<NFULL, TAIL>), dim3((L / kMacMfmaCols) * ngroups), dim3(kMacMfmaThreads), lds, st,
+                       dst, c, (const unsigned char *)D.ekd, k, L, np, c_ct_stride, dst_ct_stride, ncts, D.ekg);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+int run_mac_mfma(u64 *dst, const u64 *c, const DevCtx &D, int k, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts, hipStream_t st) {
+    const int key = D.ekg.nfull * 100 + D.ekg.tail;
+    switch (key) {
+    case 32: return launch_mac_mfma<0, 32>(dst, c, D, k, L, np, c_ct_stride, dst_ct_stride, ncts, st);
+    case 64: return launch_mac_mfma<0, 64>(dst, c, D, k, L, np, c_ct_stride, dst_ct_stride, ncts, st);
+    case 100: return launch_mac_mfma<1, 0>(dst, c, D, k, L, np, c_ct_stride, dst_ct_stride, ncts, st);
+    case 132: return launch_mac_mfma<1, 32>(dst, c, D, k, L, np, c_ct_stride, dst_ct_stride, ncts, st);
+    case 164: return launch_mac_mfma<1, 64>(dst, c, D, k, L, np, c_ct_stride, dst_ct_stride, ncts, st);
+    case 200: return launch_mac_mfma<2, 0>(dst, c, D, k, L, np, c_ct_stride, dst_ct_stride, ncts, st);
+    }
+    return fail(CUHE_EINVAL, "no matrix-core inner product for %d evaluation keys", G_.prm.numEvalKey);
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -885,7 +943,7 @@ int cuhe_hip_shutdown(void) {
         for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); hipFree(t.Wn1); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         if (D.sh_stream) { hipStreamDestroy(D.sh_stream); hipEventDestroy(D.sh_e1); hipEventDestroy(D.sh_e2); }
-        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek};
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek, D.ekd};
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);
         for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
@@ -1292,6 +1350,7 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
         CHK(set_dev(dev));
         DevCtx &D = G_.dev[dev];
         if (D.ek) { hipFree(D.ek); D.ek = nullptr; }
+        if (D.ekd) { hipFree(D.ekd); D.ekd = nullptr; }
         HIPCHK(hipMalloc((void **)&D.ek, (size_t)np * K * L * sizeof(u64)));
         u32 *raw = nullptr, *crt = nullptr; u64 *ntt = nullptr;
         HIPCHK(hipMalloc((void **)&raw, rawBytes));
@@ -1397,6 +1456,7 @@ int cuhe_hip_relin_import(const void *src, size_t bytes) {
         CHK(set_dev(dev));
         DevCtx &D = G_.dev[dev];
         if (!D.ek) HIPCHK(hipMalloc((void **)&D.ek, h.payload_bytes));
+        if (D.ekd) { hipFree(D.ekd); D.ekd = nullptr; }
         HIPCHK(hipMemcpy(D.ek, payload, h.payload_bytes, hipMemcpyHostToDevice));
     }
     G_.relin_ready = true;
@@ -1438,6 +1498,14 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
     return relin_range(dst, src, lvl, 0, G_.prm.numCrtPrimeAt(lvl < 0 ? 0 : lvl), dev, st);
 }
 
+// ---- key digits for the inner product on the matrix cores (k_relin_mac_mfma): built on the first batched call that
+// wants them, from the ct-domain keys; as large as the keys themselves.
+static int g_mac_mfma_min = getenv("CUHE_MAC_MFMA_MIN") ? atoi(getenv("CUHE_MAC_MFMA_MIN")) : 8;     // smallest batch that takes the MFMA kernel; 0 = never
+int cuhe_hip_set_relin_mfma(int min_batch) {
+    if (min_batch < 0) return fail(CUHE_EINVAL, "min_batch %d", min_batch);
+    g_mac_mfma_min = min_batch;
+    return CUHE_OK;
+}
 // ---------------------------------------------------------------- batched multiply + relinearise
 // `batch` independent (cAnd ; relin) chains of one level in a single call: NTT-domain operands a, b as
 // u64[batch][np][L], reduced CRT-domain results as u32[batch][np][crtLen].  Same arithmetic as `batch` calls of
@@ -1475,12 +1543,8 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     auto reduce_rows = [&](u32 *out, const u64 *in) -> int { return ct_inverse(out, in, rows, 0, np, true, dev, st); };
     const u32 *crt_rows = crt_in;
     if (!crt_in) {
-        // 1. pointwise products
-        const long pairs = (long)rows * L / 2;
-        const int grid = (int)std::min<long>((pairs + 255) / 256, 65535L * 16);
-        hipLaunchKernelGGL((k_ntt_binop<true>), dim3(grid), dim3(256), 0, st, Ws.bt_ntt, (const u64 *)a, (const u64 *)b, pairs);
-        // 2. x2r: INTT + reduction
-        CHK(reduce_rows(Ws.bt_crt, Ws.bt_ntt));
+        // 1.-2. x2r of the pointwise products: INTT + reduction; the products are formed as the first pass loads its samples
+        CHK(ct_inverse(Ws.bt_crt, (const u64 *)a, rows, 0, np, true, dev, st, (const u64 *)b));
         crt_rows = Ws.bt_crt;
     }
     // ICRT of every ciphertext
@@ -1502,7 +1566,20 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     // window tiles of 4 ciphertexts resident in LDS, every key value fetched once per 4 ciphertexts (k_relin_mac_lds);
     // PB (primes per thread and pass) is the one of 2, 3, 4 that wastes the fewest of the 8 x PB prime slots per pass.
     // Falls back to the register-blocked kernel (2 primes x 4 ciphertexts per workgroup) when the tile exceeds LDS.
-    {
+    // Batches of >= g_mac_mfma_min ciphertexts: the products run on the matrix cores in groups of 16 ciphertexts
+    // (k_relin_mac_mfma); a remainder of fewer than 8 ciphertexts and small batches take the VALU kernel below.
+    int done = 0;
+    if (g_mac_mfma_min > 0 && batch >= g_mac_mfma_min && mac_mfma_supported(q.numEvalKey) && (L % 64) == 0) {
+        CHK(ensure_key_digits(dev, st));
+        const int rem = batch % kMacMfmaCts;
+        done = (rem >= 8 || batch < kMacMfmaCts) ? batch : batch - rem;
+        CHK(run_mac_mfma(Ws.bt_ntt, Ws.relin, D, k, L, np, (long)k * L, (long)np * L, done, st));
+    }
+    if (done < batch) {
+        const int batch_all = batch;
+        const int batch = batch_all - done;                          // (shadows: the VALU kernels below see only the remainder)
+        u64 *const out_rows = Ws.bt_ntt + (size_t)done * np * L;
+        const u64 *const win_rows = Ws.relin + (size_t)done * k * L;
         constexpr int BB = 4;
         constexpr int CBr = 32, NGr = kMacLdsThreads / CBr;      // 16-column tiles (3 workgroups per CU) measured the same
         const size_t lds = (size_t)BB * k * CBr * sizeof(u64);
@@ -1516,14 +1593,14 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
             const dim3 grid((L / CBr) * ((batch + BB - 1) / BB)), block(kMacLdsThreads);       // (tile, group) pairs, see the kernel
 #define MACL(PB_, CB_) do { \
                 if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_relin_mac_lds<PB_, BB, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB, CB_>), grid, block, lds, st, Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, \
+                hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB, CB_>), grid, block, lds, st, out_rows, win_rows, D.ek, k, (long)q.numEvalKey * L, L, np, \
                                    (long)k * L, (long)np * L, batch); } while (0)
             if (best == 2) MACL(2, CBr); else if (best == 3) MACL(3, CBr); else MACL(4, CBr);
 #undef MACL
         } else {
             constexpr int PB = 2;
             hipLaunchKernelGGL((k_relin_mac<PB, BB, 1>), dim3((L / 512) * ((np + PB - 1) / PB), 1, (batch + BB - 1) / BB), dim3(256), 0, st,
-                               Ws.bt_ntt, Ws.relin, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
+                               out_rows, win_rows, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
         }
     }
     HIPCHK(hipGetLastError());

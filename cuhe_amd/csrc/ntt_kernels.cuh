@@ -28,7 +28,9 @@ namespace cuhe {
 // kSrcU32Twist: NEGACYCLIC forward transform of a full-length u32 row: x[j] * psi^j on load (psi a primitive 2L-th root of
 // unity, psi^2 = w_L; table `tw`), then the plain length-L cyclic transform: X[k] = sum_j x[j] psi^(j(2k+1)).  Products of
 // such transforms are products modulo x^L + 1 -- no zero padding, no reduction step (cuhe/Operations.cu:460-501 vanishes).
-enum : int { kSrcU32Ext = 0, kSrcWindow = 1, kSrcU64Neg = 2, kSrcU32Twist = 3 };
+// kSrcU64NegMul: inverse transform of the pointwise PRODUCT of two rows (the second operand's rows behind `tw`, same stride):
+// the product never exists in memory (cAnd followed by n2c: cuhe/CuHE.cu:570-581 writes it and reads it back).
+enum : int { kSrcU32Ext = 0, kSrcWindow = 1, kSrcU64Neg = 2, kSrcU32Twist = 3, kSrcU64NegMul = 4 };
 __host__ __device__ constexpr bool src_is_ext(int mode) { return mode == kSrcU32Ext || mode == kSrcWindow; }
 
 // blockIdx -> (batch, tile) with every tile of one transform on one XCD
@@ -62,6 +64,9 @@ __device__ __forceinline__ u64 load_sample(const void *__restrict__ src_, long s
     } else if constexpr (MODE == kSrcU32Twist) {
         const u32 *src = (const u32 *)src_ + (long)batch * src_stride;
         return mulp_u32(tw[idx], src[idx]);
+    } else if constexpr (MODE == kSrcU64NegMul) {
+        const long o = (long)batch * src_stride + ((L - idx) & (L - 1));
+        return mulp(((const u64 *)src_)[o], tw[o]);
     } else {
         const u64 *src = (const u64 *)src_ + (long)batch * src_stride;
         return src[(L - idx) & (L - 1)];

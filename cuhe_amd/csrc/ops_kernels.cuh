@@ -425,6 +425,235 @@ void k_relin_mac_lds(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64
     }
 }
 
+// ---------------------------------------------------------------- key-switch inner product on the matrix cores
+// For one column c the inner product  out[b][i] = sum_j win[b][j] * ek[j][i]  (b: ciphertexts of a batch, j < k windows,
+// i < np primes; cuhe/Relinearization.cu:76-88 evaluates it one ciphertext at a time) is a (B x k) x (k x np) matrix
+// product over Z_P -- a real contraction over j, not a reshaped stream.  Written in signed base-256 digits
+//     win = sum_la a_la 256^la,   ek = sum_lb e_lb 256^lb      (a_la, e_lb in [-128, 128), of a representative of the
+//                                                               value in [-0x8080808080808080, 2^64 - 0x8080808080808080))
+// it becomes 64 int8 products per 64-bit product, accumulated exactly in int32 by v_mfma_i32_16x16x64_i8:
+//     D_t[b][i] = sum over la + lb = t of  sum_j a_la[b][j] * e_lb[j][i]            (15 accumulator tiles, |D_t| < 2^24)
+//     out[b][i] = sum_t D_t 256^t  mod P                                           (a few dozen VALU operations per output)
+// against 8 VALU instructions (four of them v_mad_u64_u32) per 64-bit product in k_relin_mac_lds.  One MFMA tile is
+// 16 ciphertexts x 16 primes x 64 windows; the K order inside an instruction is irrelevant as long as both operands use
+// the same one, so only the row / column maps of the instruction matter (rows = lane & 15 of the first operand, columns
+// = lane & 15 of the second; result: column = lane & 15, row = 4 (lane >> 4) + register).
+// The key digits are laid out once (k_ek_digits) exactly as the second operand wants them: for every column, 16-prime
+// tile and digit, the 64-window steps as [lane][16 bytes] and the tail of K mod 64 windows as [lane group][prime][8 or 16
+// bytes] holding only the groups that exist -- the kernel streams the keys from HBM once per 16 ciphertexts with
+// wave-wide contiguous loads and no padding bytes.
+typedef int v4i __attribute__((ext_vector_type(4)));
+static constexpr u64 kDigC = 0x8080808080808080ull, kDigT = 0x7F7F7F7F7F7F7F80ull;
+// bytes of the result = two's complement signed digits of a' = (a < T ? a : a - P), a' == a (mod P)
+__device__ __forceinline__ u64 signed_digits(u64 a) {
+    const u64 y = a + kDigC + (a >= kDigT ? 0xffffffffull : 0ull);       // a' + C  in [0, 2^64)   (-P == 2^32 - 1 mod 2^64)
+    return y ^ kDigC;                                                   // unsigned byte u -> signed digit u - 128
+}
+struct MacDigGeom {
+    int nfull;           // K / 64 steps of 64 windows
+    int tail;            // 0, 32 (K mod 64 in 1..32: 8-byte lanes) or 64 (33..63: 16-byte lanes)
+    int tail_groups;     // lane groups of the tail step that hold windows
+    int lb_bytes;        // bytes of one (column, prime tile, digit) block
+    int npt;             // prime tiles (of the top level)
+};
+static constexpr int kMacMfmaCols = 8, kMacMfmaCts = 16;
+// key digits: one thread per (column, prime slot, chunk of 16 / 8 windows); reads coalesced over columns
+__global__ __launch_bounds__(256)
+void k_ek_digits(unsigned char *__restrict__ ekd, const u64 *__restrict__ ek, int K, int np, int L, long ek_prime_stride, MacDigGeom G) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int slot = blockIdx.y, pt = slot >> 4, n = slot & 15, i = slot;
+    const int q = blockIdx.z;                               // chunk: full steps first (4 groups each), then the tail groups
+    if (c >= L) return;
+    int j0, nj, off;
+    if (q < G.nfull * 4) { j0 = q * 16; nj = 16; off = (q >> 2) * 1024 + ((q & 3) * 16 + n) * 16; }
+    else {
+        const int g = q - G.nfull * 4;
+        if (G.tail == 32) { j0 = G.nfull * 64 + g * 8; nj = 8; off = G.nfull * 1024 + (g * 16 + n) * 8; }
+        else { j0 = G.nfull * 64 + g * 16; nj = 16; off = G.nfull * 1024 + (g * 16 + n) * 16; }
+    }
+    u64 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int j = j0 + t;
+        w[t] = (t < nj && j < K && i < np) ? signed_digits(ek[(long)i * ek_prime_stride + (long)j * L + c]) : 0ull;
+    }
+    unsigned char *base = ekd + ((long)c * G.npt + pt) * 8 * G.lb_bytes + off;
+#pragma unroll
+    for (int lb = 0; lb < 8; ++lb) {
+        u32 d[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            d[x] = (u32)((w[4 * x] >> (8 * lb)) & 0xff) | (u32)((w[4 * x + 1] >> (8 * lb)) & 0xff) << 8 |
+                   (u32)((w[4 * x + 2] >> (8 * lb)) & 0xff) << 16 | (u32)((w[4 * x + 3] >> (8 * lb)) & 0xff) << 24;
+        u32 *o = (u32 *)(base + (long)lb * G.lb_bytes);
+        o[0] = d[0]; o[1] = d[1];
+        if (nj == 16) { o[2] = d[2]; o[3] = d[3]; }
+    }
+}
+// sum_t D_t 256^t mod P with 2^64 = 2^32 - 1, 2^96 = -1 (|D_t| < 2^24, t < 15)
+__device__ __forceinline__ u64 fold_digits(const int (&D)[15]) {
+    long LO = 0, HI = 0;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+        const int d12 = (12 + r < 15) ? D[12 + r] : 0;
+        const long lo = (long)D[r] - D[8 + r] - d12;              // 256^r (D_r + 2^32 D_4+r + 2^64 D_8+r + 2^96 D_12+r)
+        const long hi = (long)D[4 + r] + D[8 + r];
+        LO = LO * 256 + lo;
+        HI = HI * 256 + hi;
+    }
+    const long h1 = HI >> 32, h0 = (long)(u32)HI;                  // 2^32 HI = 2^32 h0 + 2^64 h1 = 2^32 (h0 + h1) - h1
+    const __int128 U = (__int128)(LO - h1) + ((__int128)(h0 + h1) << 32) + (__int128)kP;       // in [0, 2^66)
+    return reduce128((u64)U, (u64)(U >> 64));
+}
+template <int NFULL, int TAIL> struct MacFrag {
+    v4i f[8][NFULL ? NFULL : 1];
+    v4i t64[TAIL == 64 ? 8 : 1];
+    long t32[TAIL == 32 ? 8 : 1];
+};
+template <int NFULL, int TAIL>
+__device__ __forceinline__ void mac_load_keys(MacFrag<NFULL, TAIL> &B, const unsigned char *p, int lb_bytes, int lane, int tail_groups) {
+#pragma unroll
+    for (int lb = 0; lb < 8; ++lb) {
+        const unsigned char *q = p + (long)lb * lb_bytes;
+#pragma unroll
+        for (int s = 0; s < NFULL; ++s) B.f[lb][s] = __builtin_nontemporal_load((const v4i *)(q + s * 1024 + lane * 16));
+        if (TAIL == 32) B.t32[lb] = (lane >> 4) < tail_groups ? __builtin_nontemporal_load((const long *)(q + NFULL * 1024 + lane * 8)) : 0l;
+        if (TAIL == 64) B.t64[lb] = (lane >> 4) < tail_groups ? __builtin_nontemporal_load((const v4i *)(q + NFULL * 1024 + lane * 16)) : v4i{0, 0, 0, 0};
+    }
+}
+__device__ __forceinline__ u32 pack_digit(u64 w0, u64 w1, u64 w2, u64 w3, int la) {
+    return (u32)((w0 >> (8 * la)) & 0xff) | (u32)((w1 >> (8 * la)) & 0xff) << 8 | (u32)((w2 >> (8 * la)) & 0xff) << 16 |
+           (u32)((w3 >> (8 * la)) & 0xff) << 24;
+}
+static constexpr int kMacMfmaThreads = 256;
+template <int NFULL, int TAIL>
+__global__ __launch_bounds__(kMacMfmaThreads, (2 * NFULL + (TAIL == 64 ? 2 : TAIL == 32 ? 1 : 0)) <= 3 ? 2 : 1)
+void k_relin_mac_mfma(u64 *__restrict__ dst, const u64 *__restrict__ c, const unsigned char *__restrict__ ekd,
+                      int k, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts, MacDigGeom G) {
+    extern __shared__ __attribute__((aligned(16))) u64 sa[];          // [8 columns][16 ciphertexts x JS + 1]: signed-digit words
+    const int npt = (np + 15) >> 4, NPAD = npt * 16;
+    const int JS = (k + 2) & ~1, CS = kMacMfmaCts * (JS > NPAD ? JS : NPAD) + 1;
+    const int ngroups = (ncts + kMacMfmaCts - 1) / kMacMfmaCts;
+    // Workgroup ids go round-robin over the XCDs (id % 8).  On one XCD consecutive ids take the ciphertext groups of one
+    // column block (they read the same keys) and then the NEIGHBOURING column block: the two share every 128-byte line of
+    // window and result rows (8 columns = 64 bytes), so the second finds its half in that XCD's L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, cq = slot / ngroups;
+    const long col0 = (long)((cq >> 1) * 16 + xcd * 2 + (cq & 1)) * kMacMfmaCols;
+    const int b0 = (slot % ngroups) * kMacMfmaCts;
+    {   // window tile: a thread owns column cc and the windows jl, jl + 32, ...; 8 ciphertexts x 4 windows of loads in flight
+        const int cc = threadIdx.x & 7, jl = threadIdx.x >> 3;
+        const u64 *src = c + (long)b0 * c_ct_stride + col0 + cc;
+#pragma unroll
+        for (int bh = 0; bh < kMacMfmaCts; bh += 8) {
+            u64 v[8][4];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = jl + 32 * m;
+                    v[b][m] = (j < k && b0 + bh + b < ncts) ? src[(long)(bh + b) * c_ct_stride + (long)j * L] : kDigC;     // kDigC: digits 0
+                }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = jl + 32 * m;
+                    if (j < k) sa[cc * CS + (bh + b) * JS + j] = (b0 + bh + b < ncts) ? signed_digits(v[b][m]) : 0ull;
+                }
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int ntask = 2 * npt;                                      // a wave: 2 of the 8 columns x the prime tiles
+    const long blk = (long)8 * G.lb_bytes;                          // bytes of a (column, prime tile) block
+    auto keys_of = [&](int task) { return ekd + ((col0 + 2 * wave + task / npt) * G.npt + task % npt) * blk; };
+    MacFrag<NFULL, TAIL> A, B0, B1;
+    mac_load_keys<NFULL, TAIL>(B0, keys_of(0), G.lb_bytes, lane, G.tail_groups);
+    auto build_rows = [&](int cc) {                                  // first operand: row = ciphertext n, digits la of 16 / 8 windows
+        const u64 *row = sa + cc * CS + n * JS;
+#pragma unroll
+        for (int s = 0; s < NFULL; ++s) {
+            u64 w[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const int j = s * 64 + g * 16 + t; w[t] = j < k ? row[j] : 0ull; }
+#pragma unroll
+            for (int la = 0; la < 8; ++la)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) A.f[la][s][x] = (int)pack_digit(w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3], la);
+        }
+        if (TAIL == 32) {
+            u64 w[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const int j = NFULL * 64 + g * 8 + t; w[t] = j < k ? row[j] : 0ull; }
+#pragma unroll
+            for (int la = 0; la < 8; ++la)
+                A.t32[la] = (long)((u64)pack_digit(w[0], w[1], w[2], w[3], la) | (u64)pack_digit(w[4], w[5], w[6], w[7], la) << 32);
+        }
+        if (TAIL == 64) {
+            u64 w[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const int j = NFULL * 64 + g * 16 + t; w[t] = j < k ? row[j] : 0ull; }
+#pragma unroll
+            for (int la = 0; la < 8; ++la)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) A.t64[la][x] = (int)pack_digit(w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3], la);
+        }
+    };
+    auto run = [&](int task, const MacFrag<NFULL, TAIL> &B) {
+        v4i acc[15];
+#pragma unroll
+        for (int t = 0; t < 15; ++t) acc[t] = v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int lb = 0; lb < 8; ++lb) {
+#pragma unroll
+            for (int s = 0; s < NFULL; ++s)
+#pragma unroll
+                for (int la = 0; la < 8; ++la)
+                    acc[la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A.f[la][s], B.f[lb][s], acc[la + lb], 0, 0, 0);
+            if (TAIL == 32) {
+#pragma unroll
+                for (int la = 0; la < 8; ++la)
+                    acc[la + lb] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A.t32[la], B.t32[lb], acc[la + lb], 0, 0, 0);
+            }
+            if (TAIL == 64) {
+#pragma unroll
+                for (int la = 0; la < 8; ++la)
+                    acc[la + lb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A.t64[la], B.t64[lb], acc[la + lb], 0, 0, 0);
+            }
+        }
+        // result tile: column = prime slot n, rows 4 g + r = ciphertexts.  It goes to the LDS slice of this column (the
+        // window words there are in registers by now; only this wave uses the slice) as [ciphertext][prime], and leaves
+        // the workgroup as 64-byte row segments after the last task
+        u64 *out = sa + (2 * wave + task / npt) * CS + (task % npt) * 16 + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int D[15];
+#pragma unroll
+            for (int t = 0; t < 15; ++t) D[t] = acc[t][r];
+            out[(4 * g + r) * NPAD] = fold_digits(D);
+        }
+    };
+    for (int task = 0; task < ntask; task += 2) {                    // keys of the next task are in flight during the products of this one
+        if (task + 1 < ntask) mac_load_keys<NFULL, TAIL>(B1, keys_of(task + 1), G.lb_bytes, lane, G.tail_groups);
+        if (task % npt == 0) build_rows(2 * wave + task / npt);
+        run(task, B0);
+        if (task + 1 < ntask) {
+            if (task + 2 < ntask) mac_load_keys<NFULL, TAIL>(B0, keys_of(task + 2), G.lb_bytes, lane, G.tail_groups);
+            if ((task + 1) % npt == 0) build_rows(2 * wave + (task + 1) / npt);
+            run(task + 1, B1);
+        }
+    }
+    __syncthreads();
+    {   // result rows leave as 64-byte segments (8 columns); a thread: column cc, primes il, il + 32, ... of every ciphertext
+        const int cc = threadIdx.x & 7, il = threadIdx.x >> 3;
+        u64 *o = dst + (long)b0 * dst_ct_stride + col0 + cc;
+        const int nb = min(kMacMfmaCts, ncts - b0);
+        for (int b = 0; b < nb; ++b)
+            for (int i = il; i < np; i += kMacMfmaThreads / 8)
+                __builtin_nontemporal_store(sa[cc * CS + b * NPAD + i], &o[(long)b * dst_ct_stride + (long)i * L]);
+    }
+}
+
 // ---------------------------------------------------------------- relinearisation windows
 // win[j][idx] = bits [w*j, w*j + w) of coefficient idx (cuhe/Base.cu:361-371), for all j < k: the raw slab is read
 // ONCE, coalesced, through LDS and every window row is written coalesced, so that the k window transforms run on a

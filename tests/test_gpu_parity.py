@@ -736,6 +736,47 @@ def test_mul_relin_batch_equals_single(gu, args):
         g.close(); o.close()
 
 
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 48, 24, 32768), (25, 2, 16, 25, 25, 21845), (5, 2, 2, 28, 25, 16384),
+                                  (12, 2, 4, 25, 25, 16384), (4, 2, 1, 61, 20, 8191), (5, 2, 1, 28, 25, 16384)],
+                         ids=["toy1155-10keys", "pow2_32768-negacyclic-6keys", "prince-40keys-25primes", "64keys", "75keys-12primes",
+                              "121keys-prime_m", "128keys"])
+def test_matrix_core_inner_product_equals_valu_kernel(gu, args):
+    """The key-switch inner product of the batched calls on the matrix cores (k_relin_mac_mfma: signed base-256 digits,
+    int8 MFMA, exact int32 accumulation) against the VALU kernel (k_relin_mac_lds), which the other tests pin to the
+    single-ciphertext sequence and the oracle: bit-identical CRT rows.  The rings cover every instantiated shape of the
+    window dimension (tails of 8- and 16-byte lanes, one and two 64-window steps), prime tiles that are not full (4, 6,
+    12, 25 primes), levels with fewer windows and primes than the key digits were laid out for, and batch sizes with an
+    unfilled tile (8, 27 = 16 + 11) or a remainder that goes to the VALU kernel (21 = 16 + 5)."""
+    import oracle_lib as O
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        rng = np.random.default_rng(0xE300)
+        ek_raw = np.zeros((K, q.rawLen, W0), dtype=np.uint32)
+        ek_raw[:, :q.modLen] = rng.integers(0, 1 << 32, (K, q.modLen, W0), dtype=np.uint64).astype(np.uint32)
+        ek_raw[:, :, W0 - 1] &= (1 << max(0, (o.logq(0) - 1) % 32)) - 1        # below the coefficient modulus
+        g.init_relin(ek_raw)
+        for lvl, B in ((0, 16), (1, 8), (1, 21), (0, 27)):
+            npr = o.np_(lvl)
+            rows = np.concatenate([_rand_crt(o, npr, 5000 + 100 * lvl + i) for i in range(B)])
+            src = gu.to_dev(rows)
+            outs = []
+            for mfma in (0, 1):
+                gu.ck(gu.lib.cuhe_hip_set_relin_mfma(mfma))
+                out = gu.empty_u32(B * npr, q.crtLen)
+                gu.ck(gu.lib.cuhe_hip_relin_batch(out.data_ptr(), src.data_ptr(), lvl, B, 0, None))
+                outs.append(gu.host_u32(out).reshape(B, npr, q.crtLen))
+            assert np.array_equal(outs[0], outs[1]), (lvl, B, [i for i in range(B) if not np.array_equal(outs[0][i], outs[1][i])][:8])
+            one = g.relin_crt(g.icrt(rows[:npr], lvl), lvl)                     # the single-ciphertext sequence, once
+            assert np.array_equal(outs[1][0], one), (lvl, B)
+        gu.ck(gu.lib.cuhe_hip_set_relin_mfma(8))
+        assert gu.lib.cuhe_hip_set_relin_mfma(-1) != 0
+    finally:
+        gu.lib.cuhe_hip_set_relin_mfma(8)
+        g.close(); o.close()
+
+
 @pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
                          ids=["toy1155-generic", "pow2_16384-fused", "dhs_simple-prime_m", "pow2_32768-negacyclic"])
 def test_mul_raw_batch_equals_single(gu, args):
