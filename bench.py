@@ -589,8 +589,8 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
         torch.cuda.synchronize()
         bdt = (time.perf_counter() - t0) / breps / B
         batched = {"value": round(1.0 / bdt, 2), "unit": "mul+relin/s", "ms_per_ciphertext": round(bdt * 1e3, 4), "batch": B,
-                   "key_bytes_per_ciphertext": key_bytes // 4,
-                   "note": "B independent chains per call; each key value read once per 4 ciphertexts; groups of 4 on 3 streams of the calling thread"}
+                   "key_bytes_per_ciphertext": key_bytes // min(B, 16),
+                   "note": "B independent chains per call on one stream; products formed on load by the inverse transforms; key-switch inner product on the matrix cores (int8 MFMA over signed base-256 digits) in tiles of 16 ciphertexts"}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
     # ---- the batched call from several host threads at once (own stream and own scratch each: the library is

@@ -523,6 +523,19 @@ int need_init(int dev) {
 }
 PrimeTab prime_tab(const DevCtx &D) { return PrimeTab{D.p, D.pinv, D.e64, D.pow32, D.maxW}; }
 
+// ICRT of `batch` ciphertexts of level lvl (np primes, W words)
+int launch_icrt(u32 *dst, const u32 *src, const DevCtx &D, int lvl, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st) {
+    const Params &q = G_.prm;
+    const IcrtLevel &I = D.icrt[lvl];
+    IcrtTab it{I.M, I.mi, I.bi, I.rp};
+    const dim3 grid((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), block(kIcrtCoef * kIcrtGroups);
+    const size_t lds = icrt_lds_bytes(np, W);
+    CHK(icrt_lds_attr(lds));
+    hipLaunchKernelGGL(k_icrt, grid, block, lds, st, dst, src, prime_tab(D), it, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
 int level_of(int logq, int *lvl, int *np, int *W) {
     const Params &q = G_.prm;
     *lvl = q.getLevel(logq);
@@ -1139,14 +1152,7 @@ int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *s
     if (lvl < 0) return fail(CUHE_EINVAL, "icrt below level 0");
     DevCtx &D = G_.dev[dev];
     const Params &q = G_.prm;
-    const IcrtLevel &I = D.icrt[lvl];
-    IcrtTab it{I.M, I.mi, I.bi, I.rp};
-    const size_t lds = icrt_lds_bytes(np, W);
-    CHK(icrt_lds_attr(lds));
-    hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef), dim3(kIcrtCoef * kIcrtGroups), lds, S(st), dst,
-                       src, prime_tab(D), it, np, W, q.modLen, q.crtLen, 0L, 0L);
-    HIPCHK(hipGetLastError());
-    return CUHE_OK;
+    return launch_icrt(dst, src, D, lvl, np, W, 1, 0L, 0L, S(st));
 }
 int cuhe_hip_crt_add(uint32_t *sum, const uint32_t *x, const uint32_t *y, int logq, int dev, void *st) {
     CHK(need_init(dev));
@@ -1549,14 +1555,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     }
     // ICRT of every ciphertext
     if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(Ws.bt_raw, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
-    {
-        const IcrtLevel &I = D.icrt[lvl];
-        IcrtTab it{I.M, I.mi, I.bi, I.rp};
-        const size_t lds = icrt_lds_bytes(np, W);
-        CHK(icrt_lds_attr(lds));
-        hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, Ws.bt_raw,
-                           crt_rows, prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
-    }
+    CHK(launch_icrt(Ws.bt_raw, crt_rows, D, lvl, np, W, batch, (long)np * cl, (long)q.rawLen * W, st));
     // 3. windows of every ciphertext and their transforms: batch*k rows
     hipLaunchKernelGGL(k_extract_windows, dim3((cl + kWinCoef - 1) / kWinCoef, batch), dim3(kWinCoef * kWinGroups), (size_t)W * kWinCoef * 4, st,
                        Ws.win, Ws.bt_raw, W, q.logRelin, k, cl, cl, (long)q.rawLen * W, (long)k * cl);
@@ -1769,14 +1768,7 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     CHK(ct_forward(na, ca, rows, dev, st, nb));
     CHK(ct_inverse(ca, na, rows, 0, np, true, dev, st));
     if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(dst, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
-    const IcrtLevel &I = D.icrt[lvl];
-    IcrtTab it{I.M, I.mi, I.bi, I.rp};
-    const size_t lds = icrt_lds_bytes(np, W);
-    CHK(icrt_lds_attr(lds));
-    hipLaunchKernelGGL(k_icrt, dim3((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), dim3(kIcrtCoef * kIcrtGroups), lds, st, dst, ca,
-                       prime_tab(D), it, np, W, q.modLen, cl, (long)np * cl, (long)q.rawLen * W);
-    HIPCHK(hipGetLastError());
-    return CUHE_OK;
+    return launch_icrt(dst, ca, D, lvl, np, W, batch, (long)np * cl, (long)q.rawLen * W, st);
 }
 
 // ---------------------------------------------------------------- CRT-prime-sharded variants

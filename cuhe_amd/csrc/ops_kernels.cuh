@@ -779,6 +779,53 @@ static inline size_t icrt_lds_bytes(int np, int W) {
     const size_t np8 = (size_t)(np + 7) & ~(size_t)7, nb = (size_t)(W + kIcrtKB - 1) / kIcrtKB;
     return (size_t)kIcrtCoef * (np8 * 4 + nb * 24 + kIcrtGroups * 8);
 }
+// phase 3 of the ICRT kernels: wave 0 ripples the block carries and applies the +-M fix-up, then the block stores its slab
+__device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, const long long *bcar, int nb, int W, const IcrtTab &it,
+                                            int ci, int g, long base, int nvalid) {
+    constexpr int CB = kIcrtCoef, NG = kIcrtGroups;
+    u32 *out = reinterpret_cast<u32 *>(blk);         // word k of coefficient c: out[((k / 4) * CB + c) * 4 + k % 4]
+    if (g == 0) {
+        long long cin = 0;
+        for (int b = 0; b < nb; ++b) {
+            uint4 v = blk[b * CB + ci];
+            long long t = (long long)v.x + cin; v.x = (u32)t; t >>= 32;
+            t += (long long)v.y; v.y = (u32)t; t >>= 32;
+            t += (long long)v.z; v.z = (u32)t; t >>= 32;
+            t += (long long)v.w; v.w = (u32)t; t >>= 32;
+            blk[b * CB + ci] = v;
+            cin = t + bcar[b * CB + ci];
+        }
+        // S - q*M lies in (-M, 2M) and M < 2^(32W): everything above word W-1 (the zero-padded words of the last block and
+        // the final carry) is its sign extension: cin < 0  <=>  negative
+        auto word = [&](int k) -> u32 & { return out[((k >> 2) * CB + ci) * 4 + (k & 3)]; };
+        int fix = 0;                          // +1: add M, -1: subtract M
+        if (cin < 0) fix = 1;
+        else {
+            bool ge = true;                   // out >= M ?
+            for (int k = W - 1; k >= 0; --k) {
+                const u32 x = word(k), y = it.M[k];
+                if (x != y) { ge = x > y; break; }
+            }
+            if (ge) fix = -1;
+        }
+        if (fix != 0) {
+            long long cy = 0;
+            for (int k = 0; k < W; ++k) {
+                const long long t = (long long)word(k) + (long long)fix * (long long)it.M[k] + cy;
+                word(k) = (u32)t;
+                cy = t >> 32;
+            }
+        }
+    }
+    __syncthreads();
+    const int slab = nvalid * W, dc = (CB * NG) / W, dk = (CB * NG) % W;       // coalesced: (coefficient, word) advance without a division per element
+    int c2 = (int)threadIdx.x / W, k = (int)threadIdx.x % W;
+    for (int e = threadIdx.x; e < slab; e += CB * NG) {
+        dst[base * W + e] = out[((k >> 2) * CB + c2) * 4 + (k & 3)];
+        c2 += dc; k += dk;
+        if (k >= W) { k -= W; ++c2; }
+    }
+}
 __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
             int np, int W, int mlen, int clen, long src_ct_stride, long dst_ct_stride) {
@@ -797,16 +844,25 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
     const int nvalid = (int)min((long)CB, (long)mlen - base);
     const bool live = ci < nvalid;
     double a = 0.0;
-    for (int i = g; i < np8; i += NG) {
-        u32 v = 0;
-        if (live && i < np) {
-            const u32 p = pt.p[i];
-            const u64 m = pt.pinv[i];
-            const u32 x = mod_small(src[(long)i * clen + base + ci], p, m);
-            v = mod_small((u64)x * it.bi[i], p, m);
-            a += (double)v * it.rp[i];
+    // phase 1 is straight-line per block of PU primes (clamped index, results masked): the per-prime constants are
+    // wave-uniform scalar loads, and a branch per prime made every one of them wait for the previous (scalar-latency bound)
+    constexpr int PU = 8;
+    for (int i0 = g; i0 < np8; i0 += NG * PU) {
+        u32 xr[PU], pp[PU], bb[PU]; u64 mm[PU]; double rr[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int ic = min(i0 + NG * u, np - 1);
+            pp[u] = pt.p[ic]; mm[u] = pt.pinv[ic]; bb[u] = it.bi[ic]; rr[u] = it.rp[ic];
+            xr[u] = live ? src[(long)ic * clen + base + ci] : 0u;
         }
-        tt[i * CB + ci] = v;
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int i = i0 + NG * u;
+            u32 v = mod_small((u64)xr[u] * bb[u], pp[u], mm[u]);          // (x mod p) b mod p = x b mod p: x < 2^32, b < p < 2^31
+            if (i >= np) v = 0;
+            a += (double)v * rr[u];
+            if (i < np8) tt[i * CB + ci] = v;
+        }
     }
     alphaP[g * CB + ci] = a;
     __syncthreads();
@@ -851,46 +907,7 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
         bcar[(k0 / KB) * CB + ci] = carry;
     }
     __syncthreads();
-    u32 *out = reinterpret_cast<u32 *>(blk);         // word k of coefficient c: out[((k / 4) * CB + c) * 4 + k % 4]
-    if (g == 0) {
-        long long cin = 0;
-        for (int b = 0; b < nb; ++b) {
-            uint4 v = blk[b * CB + ci];
-            long long t = (long long)v.x + cin; v.x = (u32)t; t >>= 32;
-            t += (long long)v.y; v.y = (u32)t; t >>= 32;
-            t += (long long)v.z; v.z = (u32)t; t >>= 32;
-            t += (long long)v.w; v.w = (u32)t; t >>= 32;
-            blk[b * CB + ci] = v;
-            cin = t + bcar[b * CB + ci];
-        }
-        // S - q*M lies in (-M, 2M) and M < 2^(32W): everything above word W-1 (the zero-padded words of the last block and
-        // the final carry) is its sign extension: cin < 0  <=>  negative
-        auto word = [&](int k) -> u32 & { return out[((k >> 2) * CB + ci) * 4 + (k & 3)]; };
-        int fix = 0;                          // +1: add M, -1: subtract M
-        if (cin < 0) fix = 1;
-        else {
-            bool ge = true;                   // out >= M ?
-            for (int k = W - 1; k >= 0; --k) {
-                const u32 x = word(k), y = it.M[k];
-                if (x != y) { ge = x > y; break; }
-            }
-            if (ge) fix = -1;
-        }
-        if (fix != 0) {
-            long long cy = 0;
-            for (int k = 0; k < W; ++k) {
-                const long long t = (long long)word(k) + (long long)fix * (long long)it.M[k] + cy;
-                word(k) = (u32)t;
-                cy = t >> 32;
-            }
-        }
-    }
-    __syncthreads();
-    const long slab = (long)nvalid * W;
-    for (long e = threadIdx.x; e < slab; e += CB * NG) {
-        const int c2 = (int)(e / W), k = (int)(e % W);
-        dst[base * W + e] = out[((k >> 2) * CB + c2) * 4 + (k & 3)];
-    }
+    icrt_finish(dst, blk, bcar, nb, W, it, ci, g, base, nvalid);
 }
 
 }  // namespace cuhe
