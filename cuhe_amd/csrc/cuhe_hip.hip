@@ -371,8 +371,6 @@ struct AttrOnce {
 // measured crossover (profiles/r02_small_batch_latency.txt): the low-latency pair wins up to ~24 rows of 32K points, ~12 rows of
 // 64K points -- the threshold is in units of 32K-point rows and scales with the transform length
 int g_ll_rows = getenv("CUHE_LL_ROWS") ? atoi(getenv("CUHE_LL_ROWS")) : 24;     // (environment override: A/B runs of whole programs)
-int g_ll2_rows = getenv("CUHE_LL2_ROWS") ? atoi(getenv("CUHE_LL2_ROWS")) : -1;     // pass 2 alone (the two forms share the slab layout); -1: as pass 1
-
 template <int LG, int MODE>
 int launch_pass1(const void *src, u64 *scratch, const NttTab &tab, long src_stride, int nb, WindowArgs wa, hipStream_t st, bool ll, const u64 *second = nullptr) {
     const u64 *tw = MODE == kSrcU64NegMul ? second : (const u64 *)tab.tw;
@@ -451,7 +449,6 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         HIPCHK(hipStreamWaitEvent(D.s2, D.ev_start, 0));
     }
     const bool ll = (long)batch * L <= (long)g_ll_rows * 32768;      // few rows: the duration of one workgroup is what counts
-    const bool ll2 = g_ll2_rows < 0 ? ll : (long)batch * L <= (long)g_ll2_rows * 32768;
     int c = 0, last = 0;
     for (int b0 = 0; b0 < batch; b0 += chunk, ++c) {
         const int nb = std::min(chunk, batch - b0);
@@ -482,15 +479,15 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             if (ep && ep->kind) {
                 Epilogue e = *ep;
                 if (e.aux) e.aux += (long)b0 * e.aux_stride;
-                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, &e)));
-                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, &e)));
-            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, nullptr, tab.twinv)));
-            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod)));
-            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod)));
+                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
+                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
+            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, nullptr, tab.twinv)));
+            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
+            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll2, np_mod, nullptr, mul_tab)));
-            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll2)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll, np_mod, nullptr, mul_tab)));
+            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }
