@@ -490,20 +490,26 @@ void k_ek_digits(unsigned char *__restrict__ ekd, const u64 *__restrict__ ek, in
         if (nj == 16) { o[2] = d[2]; o[3] = d[3]; }
     }
 }
-// sum_t D_t 256^t mod P with 2^64 = 2^32 - 1, 2^96 = -1 (|D_t| < 2^24, t < 15)
-__device__ __forceinline__ u64 fold_digits(const int (&D)[15]) {
-    long LO = 0, HI = 0;
+// sum_t D_t 256^t mod P with 2^64 = 2^32 - 1, 2^96 = -1 (|D_t| < 2^24, t < 15).  The accumulators start at kDigBias, so the
+// fold sees POSITIVE 25-bit numbers E_t = D_t + 2^24 and needs no sign handling: four words  w_q = sum_r E_(4q+r) 256^r
+// (three v_mad_u64_u32 each, < 2^50) with  sum_q w_q 2^(32q) = (w_0 - w_2 - w_3) + 2^32 (w_1 + w_2)  (mod P), and the bias
+// 2^24 sum_t 256^t leaves through the constant that also keeps the 128-bit sum non-negative.
+static constexpr int kDigBias = 1 << 24;
+constexpr u64 dig_bias_mod_p() {
+    unsigned __int128 s = 0, w = (unsigned __int128)kDigBias;
+    for (int t = 0; t < 15; ++t) { s = (s + w) % kP; w = (w << 8) % kP; }
+    return (u64)s;
+}
+__device__ __forceinline__ u64 fold_digits(const u32 (&E)[15]) {
+    u64 w[4];
 #pragma unroll
-    for (int r = 3; r >= 0; --r) {
-        const int d12 = (12 + r < 15) ? D[12 + r] : 0;
-        const long lo = (long)D[r] - D[8 + r] - d12;              // 256^r (D_r + 2^32 D_4+r + 2^64 D_8+r + 2^96 D_12+r)
-        const long hi = (long)D[4 + r] + D[8 + r];
-        LO = LO * 256 + lo;
-        HI = HI * 256 + hi;
+    for (int q = 0; q < 4; ++q) {
+        w[q] = (u64)E[4 * q] + ((u64)E[4 * q + 1] << 8) + ((u64)E[4 * q + 2] << 16);
+        if (4 * q + 3 < 15) w[q] += (u64)E[4 * q + 3] << 24;
     }
-    const long h1 = HI >> 32, h0 = (long)(u32)HI;                  // 2^32 HI = 2^32 h0 + 2^64 h1 = 2^32 (h0 + h1) - h1
-    const __int128 U = (__int128)(LO - h1) + ((__int128)(h0 + h1) << 32) + (__int128)kP;       // in [0, 2^66)
-    return reduce128((u64)U, (u64)(U >> 64));
+    constexpr unsigned __int128 kFix = 2 * (unsigned __int128)kP - dig_bias_mod_p();       // >= P > 2^51 >= w_2 + w_3
+    const unsigned __int128 U = kFix + w[0] - w[2] - w[3] + ((unsigned __int128)(w[1] + w[2]) << 32);      // in [0, 2^84)
+    return mad_eps((u32)(U >> 64), (u64)U);                      // lo + hi (2^32 - 1), canonical (hi < 2^20)
 }
 template <int NFULL, int TAIL> struct MacFrag {
     v4i f[8][NFULL ? NFULL : 1];
@@ -602,7 +608,7 @@ void k_relin_mac_mfma(u64 *__restrict__ dst, const u64 *__restrict__ c, const un
     auto run = [&](int task, const MacFrag<NFULL, TAIL> &B) {
         v4i acc[15];
 #pragma unroll
-        for (int t = 0; t < 15; ++t) acc[t] = v4i{0, 0, 0, 0};
+        for (int t = 0; t < 15; ++t) acc[t] = v4i{kDigBias, kDigBias, kDigBias, kDigBias};
 #pragma unroll
         for (int lb = 0; lb < 8; ++lb) {
 #pragma unroll
@@ -627,10 +633,10 @@ void k_relin_mac_mfma(u64 *__restrict__ dst, const u64 *__restrict__ c, const un
         u64 *out = sa + (2 * wave + task / npt) * CS + (task % npt) * 16 + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int D[15];
+            u32 E[15];
 #pragma unroll
-            for (int t = 0; t < 15; ++t) D[t] = acc[t][r];
-            out[(4 * g + r) * NPAD] = fold_digits(D);
+            for (int t = 0; t < 15; ++t) E[t] = (u32)acc[t][r];
+            out[(4 * g + r) * NPAD] = fold_digits(E);
         }
     };
     for (int task = 0; task < ntask; task += 2) {                    // keys of the next task are in flight during the products of this one

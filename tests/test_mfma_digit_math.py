@@ -18,21 +18,24 @@ def signed_digits(a):
     return [((w >> (8 * l)) & 0xFF) - 256 * (((w >> (8 * l)) & 0xFF) >> 7) for l in range(8)]
 
 
+BIAS = 1 << 24
+BIAS_MOD_P = sum(BIAS << (8 * t) for t in range(15)) % P
+
+
 def fold_digits(D):
-    """sum_t D[t] 256^t mod P as the kernel does it (64-bit signed LO / HI, one 128-bit sum, reduce128)"""
-    LO = HI = 0
-    for r in (3, 2, 1, 0):
-        d12 = D[12 + r] if 12 + r < 15 else 0
-        lo = D[r] - D[8 + r] - d12
-        hi = D[4 + r] + D[8 + r]
-        LO = LO * 256 + lo
-        HI = HI * 256 + hi
-    assert abs(LO) < 1 << 62 and abs(HI) < 1 << 62                    # fit the kernel's signed 64-bit registers
-    h1, h0 = HI >> 32, HI & 0xFFFFFFFF
-    U = (LO - h1) + ((h0 + h1) << 32) + P
-    assert 0 <= U < 1 << 66
-    lo, hi = U & M64, U >> 64                                          # reduce128(lo, hi): lo + (hi & 2^32-1)(2^32 - 1) - (hi >> 32)
-    return (lo + (hi & 0xFFFFFFFF) * 0xFFFFFFFF - (hi >> 32)) % P
+    """sum_t D[t] 256^t mod P as the kernel does it: the accumulators start at 2^24, four words of positive 25-bit numbers,
+    one unsigned 128-bit sum with the constant 2P - (bias mod P), then lo + hi (2^32 - 1)"""
+    E = [d + BIAS for d in D]
+    assert all(0 < x < 1 << 25 for x in E)
+    w = [sum(E[4 * q + r] << (8 * r) for r in range(4) if 4 * q + r < 15) for q in range(4)]
+    assert all(x < 1 << 50 for x in w)
+    U = (2 * P - BIAS_MOD_P) + w[0] - w[2] - w[3] + ((w[1] + w[2]) << 32)
+    assert 0 <= U < 1 << 84
+    lo, hi = U & M64, U >> 64
+    assert hi < 1 << 20
+    r = lo + hi * 0xFFFFFFFF                                           # mad_eps: one correction makes it canonical
+    assert r < 2 * P
+    return r - P if r >= P else r
 
 
 def test_signed_digits_represent_the_value_mod_p():
@@ -58,6 +61,6 @@ def test_digit_products_by_diagonal_fold_to_the_inner_product():
                 for la in range(8):
                     for lb in range(8):
                         D[la + lb] += dx[la] * dy[lb]
-            assert all(abs(t) <= 1 << 24 for t in D), k                # |D_t| <= 8 k 2^14 = 2^24 at k = 128: far inside int32
+            assert all(abs(t) < 1 << 24 for t in D), k                 # |D_t| < 8 k 2^14 = 2^24 at k = 128 (a digit -128 meets at most 127s): the biased sums stay in (0, 2^25)
             want = sum(x * y for x, y in zip(a, e)) % P
             assert fold_digits(D) == want, k
