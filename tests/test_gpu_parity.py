@@ -1083,7 +1083,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
     low latency, taken below cuhe_hip_set_ll_rows rows) give the same bits on every source / store variant: zero-padded
     and full forward transforms (all three lengths), window transforms, index-negated inverses with `% p` and a ragged store
     count, the fused x^n+1 reduction, the folded generic reduction's two epilogues, table products, the negacyclic twist
-    and untwist.  One run of each operation per form, compared with each other and (once) with the oracle."""
+    and untwist, the product-on-load inverse of the batched chain.  One run of each operation per form, compared with each other and (once) with the oracle."""
     import oracle_lib as O
     lib, ck = gu.lib, gu.ck
     ALL, NONE = 1 << 30, 0
@@ -1107,6 +1107,15 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                     out[("mul", lvl)] = g.mul_raw(a, b, lvl)
                     out[("mulrelin", lvl)] = g.mul_relin_crt(ca, cb, lvl)
                     out[("ctrt", lvl)] = g.ct_intt(g.ct_ntt(ca, lvl), lvl, False)
+                    # the batched chain: inverse transforms that form the product of their two operands on load
+                    nab = gu.empty_u64(2 * npr, g.ctlen); nbb = gu.empty_u64(2 * npr, g.ctlen)
+                    for i, (x, y) in enumerate(((ca, cb), (cb, cb))):
+                        ck(lib.cuhe_hip_ct_ntt(nab[i * npr:].data_ptr(), gu.to_dev(x).data_ptr(), g.logq(lvl), 0, None))
+                        ck(lib.cuhe_hip_ct_ntt(nbb[i * npr:].data_ptr(), gu.to_dev(y).data_ptr(), g.logq(lvl), 0, None))
+                    ob = gu.empty_u32(2 * npr, q.crtLen)
+                    ck(lib.cuhe_hip_mul_relin_batch(ob.data_ptr(), nab.data_ptr(), nbb.data_ptr(), lvl, 2, 0, None))
+                    out[("mulrelin_batch", lvl)] = gu.host_u32(ob)
+                    assert np.array_equal(out[("mulrelin_batch", lvl)][:npr], out[("mulrelin", lvl)]), (name, lvl, form)
                     if name != "n65536":
                         X = g.ntt(ca, lvl)
                         out[("ntt", lvl)] = X
@@ -1132,7 +1141,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                     for k, v in out.items():
                         assert np.array_equal(v, res[k]), (name, k)
             finally:
-                ck(lib.cuhe_hip_set_ll_rows(40))
+                ck(lib.cuhe_hip_set_ll_rows(24))
                 g.close()
         # the standalone batched forward entry point at all three lengths, odd batch
         for length in (16384, 32768, 65536):
@@ -1144,10 +1153,10 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                 dX = gu.empty_u64(5, length)
                 ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), gu.to_dev(x).data_ptr(), length, 5, length // 2, 0, None))
                 got.append(gu.host_u64(dX))
-            ck(lib.cuhe_hip_set_ll_rows(40))
+            ck(lib.cuhe_hip_set_ll_rows(24))
             assert np.array_equal(got[0], got[1]), length
             assert np.array_equal(got[1][4], O.ntt_ext(x[4], length)), length
     finally:
-        ck(lib.cuhe_hip_set_ll_rows(40))
+        ck(lib.cuhe_hip_set_ll_rows(24))
         if o is not None:
             o.close()
