@@ -1571,9 +1571,8 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
         done = (rem >= 8 || batch < kMacMfmaCts) ? batch : batch - rem;
         CHK(run_mac_mfma(Ws.bt_ntt, Ws.relin, D, k, L, np, (long)k * L, (long)np * L, done, st));
     }
-    if (done < batch) {
-        const int batch_all = batch;
-        const int batch = batch_all - done;                          // (shadows: the VALU kernels below see only the remainder)
+    if (done < batch) {                                               // the VALU kernels take the remaining `rest` ciphertexts
+        const int rest = batch - done;
         u64 *const out_rows = Ws.bt_ntt + (size_t)done * np * L;
         const u64 *const win_rows = Ws.relin + (size_t)done * k * L;
         constexpr int BB = 4;
@@ -1586,17 +1585,17 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
                 const double f = (double)np / slots;
                 if (f >= eff) { eff = f; best = pb; }
             }
-            const dim3 grid((L / CBr) * ((batch + BB - 1) / BB)), block(kMacLdsThreads);       // (tile, group) pairs, see the kernel
+            const dim3 grid((L / CBr) * ((rest + BB - 1) / BB)), block(kMacLdsThreads);        // (tile, group) pairs, see the kernel
 #define MACL(PB_, CB_) do { \
                 if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_relin_mac_lds<PB_, BB, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
                 hipLaunchKernelGGL((k_relin_mac_lds<PB_, BB, CB_>), grid, block, lds, st, out_rows, win_rows, D.ek, k, (long)q.numEvalKey * L, L, np, \
-                                   (long)k * L, (long)np * L, batch); } while (0)
+                                   (long)k * L, (long)np * L, rest); } while (0)
             if (best == 2) MACL(2, CBr); else if (best == 3) MACL(3, CBr); else MACL(4, CBr);
 #undef MACL
         } else {
             constexpr int PB = 2;
-            hipLaunchKernelGGL((k_relin_mac<PB, BB, 1>), dim3((L / 512) * ((np + PB - 1) / PB), 1, (batch + BB - 1) / BB), dim3(256), 0, st,
-                               out_rows, win_rows, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, batch);
+            hipLaunchKernelGGL((k_relin_mac<PB, BB, 1>), dim3((L / 512) * ((np + PB - 1) / PB), 1, (rest + BB - 1) / BB), dim3(256), 0, st,
+                               out_rows, win_rows, D.ek, k, (long)q.numEvalKey * L, L, np, (long)k * L, (long)np * L, rest);
         }
     }
     HIPCHK(hipGetLastError());
