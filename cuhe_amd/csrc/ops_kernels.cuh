@@ -785,6 +785,26 @@ static inline size_t icrt_lds_bytes(int np, int W) {
     const size_t np8 = (size_t)(np + 7) & ~(size_t)7, nb = (size_t)(W + kIcrtKB - 1) / kIcrtKB;
     return (size_t)kIcrtCoef * (np8 * 4 + nb * 24 + kIcrtGroups * 8);
 }
+// four 96-bit multiply-adds  (hi:lo)[j] += t * c_j  with wave-uniform c_j (SGPRs): the multiply-add's own carry-out feeds
+// the add of the top word -- 2 instructions per multiply-add (the compiler's form: multiply, 64-bit add, compare, select,
+// add = 5).  The four chains are interleaved so that three instructions lie between a write of a carry (SGPR pair / VCC)
+// and the VALU read of it (VALUWriteSGPRVALURead, tools/asm_hazard_check.py).
+__device__ __forceinline__ void icrt_mac4(u32 t, u32 c0, u32 c1, u32 c2, u32 c3, u64 (&lo)[4], u32 (&hi)[4]) {
+    u64 sA, sB, sC;
+    asm("v_mad_u64_u32 %[l0], vcc, %[t], %[c0], %[l0]\n\t"
+        "v_mad_u64_u32 %[l1], %[sA], %[t], %[c1], %[l1]\n\t"
+        "v_mad_u64_u32 %[l2], %[sB], %[t], %[c2], %[l2]\n\t"
+        "v_mad_u64_u32 %[l3], %[sC], %[t], %[c3], %[l3]\n\t"
+        "v_addc_co_u32_e32 %[h0], vcc, 0, %[h0], vcc\n\t"
+        "v_addc_co_u32_e64 %[h1], %[sA], 0, %[h1], %[sA]\n\t"
+        "v_addc_co_u32_e64 %[h2], %[sB], 0, %[h2], %[sB]\n\t"
+        "v_addc_co_u32_e64 %[h3], %[sC], 0, %[h3], %[sC]"
+        : [l0] "+v"(lo[0]), [l1] "+v"(lo[1]), [l2] "+v"(lo[2]), [l3] "+v"(lo[3]),
+          [h0] "+v"(hi[0]), [h1] "+v"(hi[1]), [h2] "+v"(hi[2]), [h3] "+v"(hi[3]),
+          [sA] "=&s"(sA), [sB] "=&s"(sB), [sC] "=&s"(sC)
+        : [t] "v"(t), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2), [c3] "s"(c3)
+        : "vcc");
+}
 // phase 3 of the ICRT kernels: wave 0 ripples the block carries and applies the +-M fix-up, then the block stores its slab
 __device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, const long long *bcar, int nb, int W, const IcrtTab &it,
                                             int ci, int g, long base, int nvalid) {
@@ -890,12 +910,7 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
                 const u32 t = tt[(i0 + ii) * CB + ci];
-#pragma unroll
-                for (int j = 0; j < KB; ++j) {
-                    const u64 nl = (u64)t * c[ii][j] + lo[j];
-                    hi[j] += (nl < lo[j]);
-                    lo[j] = nl;
-                }
+                icrt_mac4(t, c[ii][0], c[ii][1], c[ii][2], c[ii][3], lo, hi);
             }
         }
         // the four columns, 32 bits apart, minus q * M: four words and a signed carry (column < 2^71, so the carry fits)
