@@ -99,7 +99,7 @@ struct DevCtx {
     u32 *m_crt = nullptr;
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *ek = nullptr;
-    unsigned char *ekd = nullptr; MacDigGeom ekg{0, 0, 0, 0, 0};      // signed base-256 digits of the keys in MFMA operand order (built on first use)
+    unsigned char *ekd = nullptr; MacDigGeom ekg{0, 0, 0, 0, 0}; bool ekd_unavailable = false;      // signed base-256 digits of the keys in MFMA operand order (built on first use)
     std::vector<Workspace *> spaces;     // every workspace of this device (owned here)
     std::vector<Workspace *> idle;       // workspaces of finished threads, adopted by later ones
     // allocator (cuhe/DeviceManager.cu:98-138)
@@ -799,7 +799,12 @@ int ensure_key_digits(int dev, hipStream_t st) {
     g.lb_bytes = g.nfull * 1024 + g.tail_groups * (g.tail == 32 ? 128 : 256);
     g.npt = (np + 15) / 16;
     const size_t bytes = (size_t)L * g.npt * 8 * g.lb_bytes;
-    HIPCHK(hipMalloc((void **)&D.ekd, bytes));
+    if (D.ekd_unavailable) return CUHE_OK;
+    if (hipMalloc((void **)&D.ekd, bytes) != hipSuccess) {       // no room for a second copy of the keys: the VALU kernel serves
+        (void)hipGetLastError();
+        D.ekd = nullptr; D.ekd_unavailable = true;
+        return CUHE_OK;
+    }
     D.ekg = g;
     hipLaunchKernelGGL(k_ek_digits, dim3((L + 255) / 256, g.npt * 16, g.nfull * 4 + g.tail_groups), dim3(256), 0, st,
                        D.ekd, (const u64 *)D.ek, K, np, L, (long)K * L, g);
@@ -1354,6 +1359,7 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
         DevCtx &D = G_.dev[dev];
         if (D.ek) { hipFree(D.ek); D.ek = nullptr; }
         if (D.ekd) { hipFree(D.ekd); D.ekd = nullptr; }
+        D.ekd_unavailable = false;
         HIPCHK(hipMalloc((void **)&D.ek, (size_t)np * K * L * sizeof(u64)));
         u32 *raw = nullptr, *crt = nullptr; u64 *ntt = nullptr;
         HIPCHK(hipMalloc((void **)&raw, rawBytes));
@@ -1460,6 +1466,7 @@ int cuhe_hip_relin_import(const void *src, size_t bytes) {
         DevCtx &D = G_.dev[dev];
         if (!D.ek) HIPCHK(hipMalloc((void **)&D.ek, h.payload_bytes));
         if (D.ekd) { hipFree(D.ekd); D.ekd = nullptr; }
+        D.ekd_unavailable = false;
         HIPCHK(hipMemcpy(D.ek, payload, h.payload_bytes, hipMemcpyHostToDevice));
     }
     G_.relin_ready = true;
@@ -1567,9 +1574,11 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     int done = 0;
     if (g_mac_mfma_min > 0 && batch >= g_mac_mfma_min && mac_mfma_supported(q.numEvalKey) && (L % 64) == 0) {
         CHK(ensure_key_digits(dev, st));
-        const int rem = batch % kMacMfmaCts;
-        done = (rem >= 8 || batch < kMacMfmaCts) ? batch : batch - rem;
-        CHK(run_mac_mfma(Ws.bt_ntt, Ws.relin, D, k, L, np, (long)k * L, (long)np * L, done, st));
+        if (D.ekd) {
+            const int rem = batch % kMacMfmaCts;
+            done = (rem >= 8 || batch < kMacMfmaCts) ? batch : batch - rem;
+            CHK(run_mac_mfma(Ws.bt_ntt, Ws.relin, D, k, L, np, (long)k * L, (long)np * L, done, st));
+        }
     }
     if (done < batch) {                                               // the VALU kernels take the remaining `rest` ciphertexts
         const int rest = batch - done;
