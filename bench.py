@@ -588,8 +588,11 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
             ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), nab.data_ptr(), nbb.data_ptr(), 0, B, 0, None))
         torch.cuda.synchronize()
         bdt = (time.perf_counter() - t0) / breps / B
+        # algorithmic minimum per ciphertext of a batch: the keys once per call, two ct-domain operands in, one CRT result out
+        alg = key_bytes / B + 2 * 8 * npn * L + 4 * npn * q.modLen
         batched = {"value": round(1.0 / bdt, 2), "unit": "mul+relin/s", "ms_per_ciphertext": round(bdt * 1e3, 4), "batch": B,
                    "key_bytes_per_ciphertext": key_bytes // min(B, 16),
+                   "algorithmic_bytes_per_ciphertext": int(alg), "frac_hbm": round(alg / bdt / 1e9 / HBM_PEAK_GBS, 4),
                    "note": "B independent chains per call on one stream; products formed on load by the inverse transforms; key-switch inner product on the matrix cores (int8 MFMA over signed base-256 digits) in tiles of 16 ciphertexts"}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
