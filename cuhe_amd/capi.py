@@ -10,6 +10,14 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         "cuhe_amd: %s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
         "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+# PyTorch bundles its own HIP runtime under the soname the library links (libamdhip64.so.7).  Whoever loads first decides
+# which copy the process uses; a process that loads this library first and torch afterwards ends up with /opt/rocm's runtime
+# under torch and loses the device ("no ROCm-capable device is detected" at the first call here).  Python callers hand
+# torch tensors to the library anyway, so torch's runtime is loaded first; C++ clients (libcuHE.so) never see torch.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
 lib = C.CDLL(LIB_PATH)
 
 
