@@ -449,6 +449,8 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         HIPCHK(hipStreamWaitEvent(D.s2, D.ev_start, 0));
     }
     const bool ll = (long)batch * L <= (long)g_ll_rows * 32768;      // few rows: the duration of one workgroup is what counts
+    // pass 2 alone keeps its low-latency form up to twice that size (profiles/r02_small_batch_latency.txt: 9.8 vs 11.2 us at 48 rows of 32K)
+    const bool ll2 = (long)batch * L <= 2L * g_ll_rows * 32768;
     int c = 0, last = 0;
     for (int b0 = 0; b0 < batch; b0 += chunk, ++c) {
         const int nb = std::min(chunk, batch - b0);
@@ -479,15 +481,15 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             if (ep && ep->kind) {
                 Epilogue e = *ep;
                 if (e.aux) e.aux += (long)b0 * e.aux_stride;
-                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
-                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, &e)));
-            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll, np_mod, nullptr, tab.twinv)));
-            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
-            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll, np_mod)));
+                if (e.kind == 1) CHK((launch_pass2<LG, kOutModPRevQ>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, &e)));
+                else CHK((launch_pass2<LG, kOutFoldFinal>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, &e)));
+            } else if (nstore == kNcInverse) CHK((launch_pass2<LG, kOutModPNc>(d, slab, tab, dst_stride, nb, L, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod, nullptr, tab.twinv)));
+            else if (nstore == kFoldXn1) CHK((launch_pass2<LG, kOutModPFoldXn1>(d, slab, tab, dst_stride, nb, L / 2, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod)));
+            else CHK((launch_pass2<LG, kOutModP>(d, slab, tab, dst_stride, nb, nstore, D.p, D.pinv, prime0 + b0, q2, ll2, np_mod)));
         } else {
             u64 *d = (u64 *)dst + (long)b0 * dst_stride;
-            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll, np_mod, nullptr, mul_tab)));
-            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll)));
+            if (mul_tab) CHK((launch_pass2<LG, kOutU64Mul>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, prime0 + b0, q2, ll2, np_mod, nullptr, mul_tab)));
+            else CHK((launch_pass2<LG, kOutU64>(d, slab, tab, dst_stride, nb, nstore, nullptr, nullptr, 0, q2, ll2)));
         }
         if (pipe) { HIPCHK(hipEventRecord(D.ev_p2[sl], q2)); last = sl; }
         if (tm && tm->on) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, st); tm->ev.push_back(e); }

@@ -272,7 +272,8 @@ int cuhe_hip_set_ntt_chunk(int chunk);
 int cuhe_hip_set_ntt_overlap(int on);
 /* Transform calls of at most rows * 32768 points in total (`rows` rows of 32K points, half as many of 64K points) take
  * the low-latency kernel pair (4 values per thread, 4x the workgroups: the duration of a lone ciphertext operation is
- * the latency of its small kernels); larger calls the throughput pair (16 values per thread).  Same results.  Default
+ * the latency of its small kernels); larger calls the throughput pair (16 values per thread); pass 2 alone keeps the
+ * low-latency form up to twice that size (the two forms share the slab layout).  Same results.  Default
  * 24 = the measured crossover (profiles/r02_small_batch_latency.txt); 0 = never; a large value = always (the parity
  * tests run both forms).  Environment CUHE_LL_ROWS overrides the default for A/B runs of whole programs. */
 int cuhe_hip_set_ll_rows(int rows);
