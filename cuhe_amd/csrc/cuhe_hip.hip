@@ -1512,7 +1512,9 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 
 // ---- key digits for the inner product on the matrix cores (k_relin_mac_mfma): built on the first batched call that
 // wants them, from the ct-domain keys; as large as the keys themselves.
-static int g_mac_mfma_min = getenv("CUHE_MAC_MFMA_MIN") ? atoi(getenv("CUHE_MAC_MFMA_MIN")) : 8;     // smallest batch that takes the MFMA kernel; 0 = never
+// measured crossover at config 4: 2 and 4 ciphertexts are a little faster on the VALU kernel (0.190 / 0.127 vs 0.197 / 0.134 ms per
+// ciphertext), 6 already on the matrix cores (0.110 vs 0.141: one half-filled tile instead of two VALU groups)
+static int g_mac_mfma_min = getenv("CUHE_MAC_MFMA_MIN") ? atoi(getenv("CUHE_MAC_MFMA_MIN")) : 5;     // smallest batch that takes the MFMA kernel; 0 = never
 int cuhe_hip_set_relin_mfma(int min_batch) {
     if (min_batch < 0) return fail(CUHE_EINVAL, "min_batch %d", min_batch);
     g_mac_mfma_min = min_batch;
@@ -1572,13 +1574,13 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     // PB (primes per thread and pass) is the one of 2, 3, 4 that wastes the fewest of the 8 x PB prime slots per pass.
     // Falls back to the register-blocked kernel (2 primes x 4 ciphertexts per workgroup) when the tile exceeds LDS.
     // Batches of >= g_mac_mfma_min ciphertexts: the products run on the matrix cores in groups of 16 ciphertexts
-    // (k_relin_mac_mfma); a remainder of fewer than 8 ciphertexts and small batches take the VALU kernel below.
+    // (k_relin_mac_mfma); a remainder below that size and small batches take the VALU kernel below.
     int done = 0;
     if (g_mac_mfma_min > 0 && batch >= g_mac_mfma_min && mac_mfma_supported(q.numEvalKey) && (L % 64) == 0) {
         CHK(ensure_key_digits(dev, st));
         if (D.ekd) {
             const int rem = batch % kMacMfmaCts;
-            done = (rem >= 8 || batch < kMacMfmaCts) ? batch : batch - rem;
+            done = (rem >= g_mac_mfma_min || batch < kMacMfmaCts) ? batch : batch - rem;
             CHK(run_mac_mfma(Ws.bt_ntt, Ws.relin, D, k, L, np, (long)k * L, (long)np * L, done, st));
         }
     }

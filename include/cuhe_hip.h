@@ -196,7 +196,7 @@ int cuhe_hip_set_relin_lanes(int n);
    v_mfma_i32_16x16x64_i8, 16 ciphertexts x 16 primes x 64 windows per instruction; exact, so results do not change) for
    batches of at least `min_batch` ciphertexts and parameter sets with at most 128 evaluation keys; the key digits (as
    large as the keys) are laid out on the first such call; a device without room for them keeps the VALU kernel.
-   Default 8; 0 = never (the VALU kernel). */
+   Default 5 (the measured crossover); 0 = never (the VALU kernel). */
 int cuhe_hip_set_relin_mfma(int min_batch);
 /* `batch` independent full multiplications raw -> raw of one level in one call (mulZZX without the host staging,
    CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the

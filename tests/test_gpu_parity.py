@@ -762,7 +762,7 @@ def test_matrix_core_inner_product_equals_valu_kernel(gu, args):
             rows = np.concatenate([_rand_crt(o, npr, 5000 + 100 * lvl + i) for i in range(B)])
             src = gu.to_dev(rows)
             outs = []
-            for mfma in (0, 1):
+            for mfma in (0, 8):                              # 8: the remainder of 21 = 16 + 5 goes to the VALU kernel, 27 = 16 + 11 is padded
                 gu.ck(gu.lib.cuhe_hip_set_relin_mfma(mfma))
                 out = gu.empty_u32(B * npr, q.crtLen)
                 gu.ck(gu.lib.cuhe_hip_relin_batch(out.data_ptr(), src.data_ptr(), lvl, B, 0, None))
@@ -770,10 +770,10 @@ def test_matrix_core_inner_product_equals_valu_kernel(gu, args):
             assert np.array_equal(outs[0], outs[1]), (lvl, B, [i for i in range(B) if not np.array_equal(outs[0][i], outs[1][i])][:8])
             one = g.relin_crt(g.icrt(rows[:npr], lvl), lvl)                     # the single-ciphertext sequence, once
             assert np.array_equal(outs[1][0], one), (lvl, B)
-        gu.ck(gu.lib.cuhe_hip_set_relin_mfma(8))
+        gu.ck(gu.lib.cuhe_hip_set_relin_mfma(5))
         assert gu.lib.cuhe_hip_set_relin_mfma(-1) != 0
     finally:
-        gu.lib.cuhe_hip_set_relin_mfma(8)
+        gu.lib.cuhe_hip_set_relin_mfma(5)
         g.close(); o.close()
 
 
