@@ -67,7 +67,7 @@ struct Workspace {
     size_t slab_bytes[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     size_t n_barrett = 0, n_alias = 0, n_relin = 0;     // rows / elements the buffers below currently hold
     // scratch of the batched multiply + relinearise (cuhe_hip_mul_relin_batch), sized by the largest batch seen
-    u64 *bt_ntt = nullptr; u32 *bt_crt = nullptr, *bt_raw = nullptr; size_t n_bt = 0;
+    u64 *bt_ntt = nullptr; u32 *bt_crt = nullptr; size_t n_bt = 0;
     u64 *mr_ntt = nullptr; u32 *mr_crt = nullptr; size_t n_mr = 0;        // cuhe_hip_mul_raw_batch
     u64 *b_ntt = nullptr;                // Barrett scratch (cuhe/Operations.cu:196-209)
     u32 *b_mq = nullptr, *b_crt = nullptr;  // q (at offset n) and (m - x^n) q
@@ -255,7 +255,7 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 }
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
-    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->bt_raw, w->mr_ntt, w->mr_crt,
+    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->mr_ntt, w->mr_crt,
                     w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
@@ -523,14 +523,15 @@ int need_init(int dev) {
 PrimeTab prime_tab(const DevCtx &D) { return PrimeTab{D.p, D.pinv, D.e64, D.pow32, D.maxW}; }
 
 // ICRT of `batch` ciphertexts of level lvl (np primes, W words)
-int launch_icrt(u32 *dst, const u32 *src, const DevCtx &D, int lvl, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st) {
+int launch_icrt(u32 *dst, const u32 *src, const DevCtx &D, int lvl, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st,
+                IcrtWindows wo = IcrtWindows{nullptr, 0, 0, 0, 0}) {
     const Params &q = G_.prm;
     const IcrtLevel &I = D.icrt[lvl];
     IcrtTab it{I.M, I.mi, I.bi, I.rp};
     const dim3 grid((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), block(kIcrtCoef * kIcrtGroups);
     const size_t lds = icrt_lds_bytes(np, W);
     CHK(icrt_lds_attr(lds));
-    hipLaunchKernelGGL(k_icrt, grid, block, lds, st, dst, src, prime_tab(D), it, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride);
+    hipLaunchKernelGGL(k_icrt, grid, block, lds, st, dst, src, prime_tab(D), it, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride, wo);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -1543,13 +1544,11 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     CHK(workspace(dev, st, &Wp));
     Workspace &Ws = *Wp;
     if (Ws.n_bt < (size_t)batch) {
-        size_t x = 0, y = 0, z = 0;
+        size_t x = 0, y = 0;
         if (Ws.bt_ntt) { HIPCHK(hipFree(Ws.bt_ntt)); Ws.bt_ntt = nullptr; }
         if (Ws.bt_crt) { HIPCHK(hipFree(Ws.bt_crt)); Ws.bt_crt = nullptr; }
-        if (Ws.bt_raw) { HIPCHK(hipFree(Ws.bt_raw)); Ws.bt_raw = nullptr; }
         CHK(ws_grow(&Ws.bt_ntt, &x, (size_t)batch * q.numCrtPrime * L));
         CHK(ws_grow(&Ws.bt_crt, &y, (size_t)batch * q.numCrtPrime * cl));
-        CHK(ws_grow(&Ws.bt_raw, &z, (size_t)batch * q.rawLen * q.wordsCoeff(0)));
         Ws.n_bt = batch;
     }
     CHK(ws_relin(Ws, batch));
@@ -1561,13 +1560,10 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
         CHK(ct_inverse(Ws.bt_crt, (const u64 *)a, rows, 0, np, true, dev, st, (const u64 *)b));
         crt_rows = Ws.bt_crt;
     }
-    // ICRT of every ciphertext
-    if (q.modLen < q.rawLen) HIPCHK(hipMemsetAsync(Ws.bt_raw, 0, (size_t)batch * q.rawLen * W * sizeof(u32), st));
-    CHK(launch_icrt(Ws.bt_raw, crt_rows, D, lvl, np, W, batch, (long)np * cl, (long)q.rawLen * W, st));
-    // 3. windows of every ciphertext and their transforms: batch*k rows
-    hipLaunchKernelGGL(k_extract_windows, dim3((cl + kWinCoef - 1) / kWinCoef, batch), dim3(kWinCoef * kWinGroups), (size_t)W * kWinCoef * 4, st,
-                       Ws.win, Ws.bt_raw, W, q.logRelin, k, cl, cl, (long)q.rawLen * W, (long)k * cl);
-    HIPCHK(hipGetLastError());
+    // ICRT of every ciphertext, 3. straight into the relinearisation windows (batch*k rows): the raw form is never stored
+    if (q.modLen < cl)                                                // coefficients modLen .. crtLen of every window row are zero
+        HIPCHK(hipMemset2DAsync(Ws.win + q.modLen, (size_t)cl * sizeof(u32), 0, (size_t)(cl - q.modLen) * sizeof(u32), (size_t)batch * k, st));
+    CHK(launch_icrt(nullptr, crt_rows, D, lvl, np, W, batch, (long)np * cl, 0L, st, IcrtWindows{Ws.win, (long)k * cl, q.logRelin, k, cl}));
     CHK(ct_forward(Ws.relin, Ws.win, batch * k, dev, st));
     // 4. key-switch inner products: a key value fetched once serves four ciphertexts
     // window tiles of 4 ciphertexts resident in LDS, every key value fetched once per 4 ciphertexts (k_relin_mac_lds);

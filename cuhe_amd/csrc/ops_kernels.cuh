@@ -805,9 +805,13 @@ __device__ __forceinline__ void icrt_mac4(u32 t, u32 c0, u32 c1, u32 c2, u32 c3,
         : [t] "v"(t), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2), [c3] "s"(c3)
         : "vcc");
 }
+// optional second output of k_icrt: the relinearisation windows of the coefficients (what k_extract_windows makes of the
+// raw words), written straight from the result words in LDS -- the batched chain then needs neither the raw rows nor
+// the extraction kernel (151 + 151 MB of traffic per 32 ciphertexts at config 4)
+struct IcrtWindows { u32 *win; long ct_stride; int w, k, clen; };
 // phase 3 of the ICRT kernels: wave 0 ripples the block carries and applies the +-M fix-up, then the block stores its slab
 __device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, const long long *bcar, int nb, int W, const IcrtTab &it,
-                                            int ci, int g, long base, int nvalid) {
+                                            int ci, int g, long base, int nvalid, const IcrtWindows &wo) {
     constexpr int CB = kIcrtCoef, NG = kIcrtGroups;
     u32 *out = reinterpret_cast<u32 *>(blk);         // word k of coefficient c: out[((k / 4) * CB + c) * 4 + k % 4]
     if (g == 0) {
@@ -844,6 +848,17 @@ __device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, c
         }
     }
     __syncthreads();
+    if (wo.win && ci < nvalid) {                      // win[j][coefficient] = bits [w j, w j + w) (cuhe/Base.cu:361-371); a wave: windows g, g + 4, ...
+        u32 *wrow = wo.win + (long)blockIdx.y * wo.ct_stride + base + ci;
+        const u32 mask = (u32)((1u << wo.w) - 1u);
+        for (int j = g; j < wo.k; j += NG) {
+            const int bit = wo.w * j, wi = bit >> 5;
+            u64 sv = out[((wi >> 2) * CB + ci) * 4 + (wi & 3)];
+            if (wi + 1 < W) sv |= (u64)out[(((wi + 1) >> 2) * CB + ci) * 4 + ((wi + 1) & 3)] << 32;
+            wrow[(long)j * wo.clen] = (u32)(sv >> (bit & 31)) & mask;
+        }
+    }
+    if (!dst) return;
     const int slab = nvalid * W, dc = (CB * NG) / W, dk = (CB * NG) % W;       // coalesced: (coefficient, word) advance without a division per element
     int c2 = (int)threadIdx.x / W, k = (int)threadIdx.x % W;
     for (int e = threadIdx.x; e < slab; e += CB * NG) {
@@ -854,9 +869,9 @@ __device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, c
 }
 __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
-            int np, int W, int mlen, int clen, long src_ct_stride, long dst_ct_stride) {
+            int np, int W, int mlen, int clen, long src_ct_stride, long dst_ct_stride, IcrtWindows wo) {
     src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: ciphertext of a batched call (strides in words)
-    dst += (long)blockIdx.y * dst_ct_stride;
+    if (dst) dst += (long)blockIdx.y * dst_ct_stride;
     extern __shared__ __attribute__((aligned(16))) unsigned char shraw[];
     constexpr int CB = kIcrtCoef, NG = kIcrtGroups, KB = kIcrtKB;
     const int np8 = (np + 7) & ~7, W4 = (W + 3) & ~3, nb = W4 / KB;
@@ -928,7 +943,7 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
         bcar[(k0 / KB) * CB + ci] = carry;
     }
     __syncthreads();
-    icrt_finish(dst, blk, bcar, nb, W, it, ci, g, base, nvalid);
+    icrt_finish(dst, blk, bcar, nb, W, it, ci, g, base, nvalid, wo);
 }
 
 }  // namespace cuhe
