@@ -22,6 +22,7 @@
 #include "comm.hpp"
 #include "host_math.hpp"
 #include "ntt_kernels.cuh"
+#include "ntt_onewg.hpp"
 #include "ops_kernels.cuh"
 
 using namespace cuhe;
@@ -84,9 +85,18 @@ struct Workspace {
 };
 struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0; };
 
+// tables of the one-workgroup transforms (ntt_onewg.cuh) of Lh = 2^(13 + index) points
+struct OwTab {
+    u64 *TW1f = nullptr, *TW1i = nullptr, *TW1h = nullptr, *TW2 = nullptr;      // forward, inverse (x Lh^-1), both parities of the zero-padded form, stage 2
+    std::atomic<int> ready{0};
+    OwTab() {}
+    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), ready(o.ready.load()) {}
+    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; ready.store(o.ready.load()); return *this; }
+};
 struct DevCtx {
     bool ready = false;
     NttTab ntt[3];                       // LG 14,15,16
+    OwTab ow[3];                         // sub-transforms of 8K, 16K, 32K points
     // prime tables
     u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
     u64 *pinv = nullptr;
@@ -130,6 +140,7 @@ struct Global {
     bool allocator_on = false;
     size_t cache_cap = (size_t)4 << 30;  // with the pooled allocator off, freed blocks are still kept up to this many bytes
     int ntt_chunk = 0;
+    int onewg = getenv("CUHE_ONEWG") ? atoi(getenv("CUHE_ONEWG")) : 1;   // one-workgroup transforms: 0 never, 1 wherever they exist
     bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
     std::mutex mu;
@@ -351,6 +362,39 @@ int ensure_twist(int dev, int len) {
     return CUHE_OK;
 }
 
+
+// ---- one-workgroup transforms: tables (the index formulas are those of tests/onewg_model.py)
+int ensure_onewg(OwTab &tab, int lgh) {
+    if (tab.ready.load(std::memory_order_acquire)) return CUHE_OK;
+    std::lock_guard<std::mutex> lk(G_.mu);
+    if (tab.ready.load(std::memory_order_relaxed)) return CUHE_OK;
+    const int Lh = 1 << lgh, T = Lh / 32, R = T / 32;
+    const u64 W = host::powP(host::G, 65536 / (2 * Lh));          // w_(2 Lh); w_Lh = W^2 (cuhe/Base.cu:63-70)
+    std::vector<u64> r(2 * (size_t)Lh);
+    r[0] = 1;
+    for (size_t i = 1; i < r.size(); ++i) r[i] = host::mulP(r[i - 1], W);
+    const u64 linv = host::powP((u64)Lh, host::P - 2);
+    std::vector<u64> f(Lh), fi(Lh), fh(2 * (size_t)Lh), t2(T);
+    for (int ka = 0; ka < 32; ++ka)
+        for (int m = 0; m < T; ++m) {
+            const size_t o = (size_t)ka * T + m;
+            f[o] = r[(2L * m * ka) % (2L * Lh)];                 // w_Lh^(m ka)
+            fi[o] = host::mulP(f[o], linv);
+            fh[o] = f[o];
+            fh[Lh + o] = r[((long)m * (2 * ka + 1)) % (2L * Lh)]; // W^(m (2 ka + 1)): the odd outputs of the zero-padded transform
+        }
+    for (int kb = 0; kb < R; ++kb)
+        for (int c = 0; c < 32; ++c) t2[(size_t)kb * 32 + c] = r[(64L * c * kb) % (2L * Lh)];      // w_T^(c kb) = w_Lh^(32 c kb)
+    CHK(upload(&tab.TW1f, f)); CHK(upload(&tab.TW1i, fi)); CHK(upload(&tab.TW1h, fh)); CHK(upload(&tab.TW2, t2));
+    tab.ready.store(1, std::memory_order_release);
+    return CUHE_OK;
+}
+int onewg_launch(int lgh, int mode, int out, bool half, const OwArgs &a, hipStream_t st) {
+    hipError_t e = lgh == 13 ? ow_launch_13(mode, out, half, a, st) : lgh == 14 ? ow_launch_14(mode, out, half, a, st) : ow_launch_15(mode, out, half, a, st);
+    if (e != hipSuccess) return fail(CUHE_EHIP, "one-workgroup transform (2^%d points, source %d, store %d%s): %s", lgh, mode, out, half ? ", half" : "", hipGetErrorString(e));
+    return CUHE_OK;
+}
+
 // hipFuncSetAttribute once per (kernel instantiation, device); host threads may race to be first
 struct AttrOnce {
     std::mutex mu; std::atomic<uint64_t> done{0};
@@ -437,6 +481,36 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
     const int chunk = tab.chunk;
     // Two-stage software pipeline over chunks: pass 1 (VALU/LDS bound) of chunk c+1 runs on stream s1 while
     // pass 2 (load/store heavy, 1 wave/SIMD fits beside pass 1's 2) of chunk c runs on s2.
+    // ---- the one-workgroup form wherever it exists: ONE launch for the whole batch, no slab (ntt_onewg.cuh).  A zero-padded
+    // source (the reference contract) is done as the two half-length transforms of its even and odd outputs.
+    {
+        const bool half = src_is_ext(mode);
+        const int lgh = half ? LG - 1 : LG;
+        if (G_.onewg && lgh <= 15) {
+            int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
+            if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
+                if (ep && ep->kind) { out = ep->kind == 1 ? kOutModPRevQ : kOutFoldFinal; e = *ep; }
+                else if (nstore == kNcInverse) { out = kOutModPNc; nst = L; xt = tab.twinv; }
+                else if (nstore == kFoldXn1) { out = kOutModPFoldXn1; nst = L / 2; }
+                else out = kOutModP;
+            } else { out = mul_tab ? kOutU64Mul : kOutU64; xt = mul_tab; }
+            if (ow_supported(mode, out, half)) {
+                OwTab &ot = D.ow[lgh - 13];
+                CHK(ensure_onewg(ot, lgh));
+                const u64 *tw = mode == kSrcU64NegMul ? mul_tab : mode == kSrcU32Twist ? (const u64 *)tab.tw : nullptr;
+                if (mode == kSrcU64NegMul && !tw) return fail(CUHE_EINVAL, "second operand missing");
+                if (mode == kSrcU32Twist && !tw) return fail(CUHE_EINVAL, "negacyclic twist table missing");
+                if (out == kOutModPNc && !xt) return fail(CUHE_EINVAL, "negacyclic untwist table missing");
+                const bool inv = out_is_inverse(out);
+                OwArgs a{dst, src, half ? ot.TW1h : inv ? ot.TW1i : ot.TW1f, ot.TW2, mode == kSrcWindow ? 0 : src_stride, dst_stride, batch, nst, wa, tw,
+                         D.p, D.pinv, prime0, np_mod, e.aux, e.aux_stride, e.fg, xt};
+                if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+                CHK(onewg_launch(lgh, mode, out, half, a, st));
+                if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+                return CUHE_OK;
+            }
+        }
+    }
     const bool pipe = G_.ntt_overlap && !(tm && tm->on) && batch > chunk;
     hipStream_t q1 = pipe ? D.s1 : st, q2 = pipe ? D.s2 : st;
     const size_t slab_bytes = (size_t)((std::min(chunk, batch) + 7) & ~7) * L * sizeof(u64);
@@ -2001,6 +2075,7 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     G_.ntt_chunk = chunk;
     return CUHE_OK;
 }
+int cuhe_hip_set_onewg(int mode) { if (mode < 0 || mode > 1) return fail(CUHE_EINVAL, "mode %d", mode); G_.onewg = mode; return CUHE_OK; }
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
 int cuhe_hip_set_ll_rows(int rows) { if (rows < 0) return fail(CUHE_EINVAL, "rows %d", rows); g_ll_rows = rows; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {

@@ -1,0 +1,25 @@
+// ntt_onewg.hpp -- host-side entry of the one-workgroup transforms (ntt_onewg.cuh).  The kernels are instantiated in
+// their own translation units (ntt_onewg_inst.hip, compiled once per sub-transform size) so that the sizes build in
+// parallel; cuhe_hip.hip calls them through ow_launch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ntt_kernels.cuh"
+
+namespace cuhe {
+
+struct OwArgs {
+    void *dst; const void *src;
+    const u64 *TW1, *TW2;                 // stage-1 table (HALF: both parities, u64[2][Lh]) and stage-2 table u64[Lh/32]
+    long src_stride, dst_stride; int nbatch, nstore;
+    WindowArgs wa; const u64 *tw;         // kSrcWindow geometry; twist table (kSrcU32Twist) or second operand rows (kSrcU64NegMul)
+    const u32 *primes; const u64 *pinv; int prime0, np_mod;
+    const u32 *aux; long aux_stride; FoldGeom fg; const u64 *xtab;
+};
+// hipErrorInvalidValue: this (sub-transform size, source, epilogue, half) combination is not instantiated
+hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
+hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
+hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
+bool ow_supported(int mode, int out, bool half);
+
+}  // namespace cuhe

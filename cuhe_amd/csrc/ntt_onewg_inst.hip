@@ -1,0 +1,76 @@
+// ntt_onewg_inst.hip -- instantiations + launcher of the one-workgroup transforms for ONE sub-transform size
+// (-DCUHE_OW_LGH=13|14|15; cuhe_amd/build.py compiles the three sizes in parallel).
+#include "ntt_onewg.hpp"
+#include "ntt_onewg.cuh"
+
+#include <atomic>
+#include <mutex>
+
+#ifndef CUHE_OW_LGH
+#error "compile with -DCUHE_OW_LGH=13, 14 or 15"
+#endif
+
+namespace cuhe {
+namespace {
+
+constexpr int kLgh = CUHE_OW_LGH;
+using Geo = OwGeom<(1 << kLgh) / 1024>;
+
+template <int MODE, int OUT, bool HALF>
+hipError_t launch(const OwArgs &a, hipStream_t st) {
+    auto kern = ntt_onewg<kLgh, MODE, OUT, HALF>;
+    // the large-LDS attribute once per (instantiation, device); host threads may race to be first
+    static std::mutex mu; static std::atomic<uint64_t> done{0};
+    int cur = 0;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (cur & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
+            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
+            if (e != hipSuccess) return e;
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    const int nb8 = (a.nbatch + 7) & ~7;
+    const int grid = HALF ? 2 * nb8 : a.nbatch;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
+                       a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#define OW_CASE(MODE, OUT, HALF) if (mode == MODE && out == OUT && half == HALF) return launch<MODE, OUT, HALF>(a, st);
+#define OW_CONCAT2(a, b) a##b
+#define OW_CONCAT(a, b) OW_CONCAT2(a, b)
+hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, const OwArgs &a, hipStream_t st) {
+    // the zero-padded forward transform of 2^(LGH+1) points, one parity per workgroup
+    OW_CASE(kSrcU32Ext, kOutU64, true)
+    OW_CASE(kSrcU32Ext, kOutU64Mul, true)
+    OW_CASE(kSrcWindow, kOutU64, true)
+    // full-length transforms of 2^LGH points: negacyclic forward, inverses with their store epilogues
+    OW_CASE(kSrcU32Twist, kOutU64, false)
+    OW_CASE(kSrcU32Twist, kOutU64Mul, false)
+    OW_CASE(kSrcU64Neg, kOutModP, false)
+    OW_CASE(kSrcU64Neg, kOutModPFoldXn1, false)
+    OW_CASE(kSrcU64Neg, kOutModPRevQ, false)
+    OW_CASE(kSrcU64Neg, kOutFoldFinal, false)
+    OW_CASE(kSrcU64Neg, kOutModPNc, false)
+    OW_CASE(kSrcU64NegMul, kOutModP, false)
+    OW_CASE(kSrcU64NegMul, kOutModPFoldXn1, false)
+    OW_CASE(kSrcU64NegMul, kOutModPNc, false)
+    return hipErrorInvalidValue;
+}
+#if CUHE_OW_LGH == 15
+bool ow_supported(int mode, int out, bool half) {
+    if (half) return (mode == kSrcU32Ext && (out == kOutU64 || out == kOutU64Mul)) || (mode == kSrcWindow && out == kOutU64);
+    if (mode == kSrcU32Twist) return out == kOutU64 || out == kOutU64Mul;
+    if (mode == kSrcU64Neg) return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPRevQ || out == kOutFoldFinal || out == kOutModPNc;
+    if (mode == kSrcU64NegMul) return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPNc;
+    return false;
+}
+#endif
+
+}  // namespace cuhe

@@ -277,6 +277,12 @@ int cuhe_hip_set_ntt_overlap(int on);
  * 24 = the measured crossover (profiles/r02_small_batch_latency.txt); 0 = never; a large value = always (the parity
  * tests run both forms).  Environment CUHE_LL_ROWS overrides the default for A/B runs of whole programs. */
 int cuhe_hip_set_ll_rows(int rows);
+/* One-workgroup transforms (cuhe_amd/csrc/ntt_onewg.cuh): a sub-transform of 8K / 16K / 32K points in the registers of
+ * one workgroup, ONE launch and no slab in HBM; the zero-padded forward transforms of 16K / 32K / 64K points run as their
+ * two half-length halves.  1 (default): wherever that form exists; 0: the two-pass kernels only (the parity tests run
+ * both).  Same results.  Environment CUHE_ONEWG overrides the default for A/B runs of whole programs.  Replaces the
+ * same reference code as the two-pass kernels (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398). */
+int cuhe_hip_set_onewg(int mode);
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,

@@ -41,6 +41,33 @@ def test_checker_fires_on_known_hazards():
     assert findings == [], findings
 
 
+def test_checker_follows_branches_and_loop_back_edges():
+    import asm_hazard_check as H
+    # the carry written at the end of the loop body is read by the first instruction of the next iteration
+    loop = """_Z1kv:
+.LBB0_1:
+	v_addc_co_u32_e64 v1, s[4:5], v1, v2, s[4:5]
+	v_add_u32_e32 v9, v9, v9
+	v_add_u32_e32 v9, v9, v9
+	v_add_co_u32_e64 v0, s[4:5], v0, v3
+	s_cbranch_scc1 .LBB0_1
+"""
+    findings, _, _ = H.check(loop.split("\n"))
+    assert len(findings) == 1 and "v_addc_co_u32_e64" in findings[0], findings
+    # a write just before a taken forward branch reaches the read at its target
+    fwd = """_Z1kv:
+	v_cmp_lt_u64_e64 s[2:3], v[2:3], v[4:5]
+	s_cbranch_execz .LBB0_2
+	v_add_u32_e32 v9, v9, v9
+	v_add_u32_e32 v9, v9, v9
+	v_add_u32_e32 v9, v9, v9
+.LBB0_2:
+	v_cndmask_b32_e64 v6, 0, 1, s[2:3]
+"""
+    findings, _, _ = H.check(fwd.split("\n"))
+    assert len(findings) == 1, findings
+
+
 def test_device_code_has_no_sgpr_hazards():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_hazard_check.py")], capture_output=True, text=True, timeout=900)
     print(r.stdout[-2000:], r.stderr[-2000:])

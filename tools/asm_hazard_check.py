@@ -8,7 +8,8 @@ LLVM pads its own code; it does not look inside or behind an inline-asm statemen
 cuhe_amd/csrc/modp.cuh / ops_kernels.cuh produces its carries in asm.  This script compiles the device code to assembly
 and replays the rule over EVERY instruction of every kernel (not only the asm sites): for each VALU instruction it checks
 that every SGPR it reads was last written by a VALU instruction at least two wait states earlier (an instruction = one
-wait state, s_nop N = N + 1; an SALU write in between clears the hazard: SALU -> VALU is interlocked).
+wait state, s_nop N = N + 1; an SALU write in between clears the hazard: SALU -> VALU is interlocked).  Branches and
+labels are followed: a read at a loop head or behind a taken branch sees the writes of every predecessor.
 Exit code 0 = clean.  usage: tools/asm_hazard_check.py [extra hipcc flags] | --asm file.s
 cuhe_amd/build.py runs it after compiling and refuses to keep a library whose code has findings."""
 import os, re, subprocess, sys, tempfile
@@ -31,58 +32,97 @@ def sregs(tok):
 
 
 def check(lines):
-    findings, asm_sites, valu_sgpr_reads = [], 0, 0
-    age = {}                     # sgpr index -> wait states since a VALU instruction wrote it (absent: no pending VALU write)
-    in_asm, func = False, "?"
+    """Replays the rule over the listing.  Control flow: the state (wait states since the last VALU write, per SGPR) that
+    reaches a label is the most recent over ALL its predecessors -- the fall-through and every branch that names it, loop
+    back-edges included -- found by iterating each function's listing until the states at its labels stop changing."""
+    # split into functions
+    funcs, cur = [], None
     for ln, raw in enumerate(lines, 1):
-        t = raw.strip()
-        if ";;#ASMSTART" in t: in_asm = True; asm_sites += 1; continue
-        if ";;#ASMEND" in t: in_asm = False; continue
         m = re.match(r"^(_Z\w+):", raw)
-        if m: func, age = m.group(1), {}; continue
-        if not t or t[0] in ";." or t.endswith(":") or t.startswith("//"): continue
-        t = t.split(";")[0].strip()
-        ops = t.split(None, 1)
-        op = ops[0]
-        if not re.match(r"^[a-z][a-z0-9_]+$", op): continue
-        args = [a.strip() for a in ops[1].split(",")] if len(ops) > 1 else []
-        if op == "s_nop":
-            n = int(args[0], 0) + 1
-            age = {r: a + n for r, a in age.items()}
-            continue
-        if op.startswith("v_"):
-            ndst = 2 if TWO_DST.match(op) else 1
-            reads, writes = set(), set()
-            for a in args[ndst:]: reads |= sregs(a.split(" ")[0])
-            for a in args[:ndst]: writes |= sregs(a)
-            if reads: valu_sgpr_reads += 1
-            hot = [r for r in reads if age.get(r, 99) < 2]
-            if hot:
-                findings.append("%s line %d%s: '%s' reads s%s %d wait state(s) after a VALU write" %
-                                (func[:50], ln, " (inside asm)" if in_asm else "", t, sorted(hot), min(age[r] for r in hot)))
-            age = {r: a + 1 for r, a in age.items()}
-            for r in writes: age[r] = 0
-        else:
-            # SALU / memory / branch: one wait state; an SALU write to a register ends the VALU-write hazard on it
-            age = {r: a + 1 for r, a in age.items()}
-            if op.startswith("s_") and args:
-                for r in sregs(args[0]): age.pop(r, None)
-                if op.startswith(("s_and", "s_or", "s_xor", "s_andn2", "s_orn2", "s_nand", "s_nor", "s_xnor", "s_not", "s_add", "s_sub", "s_cmp", "s_lshl", "s_lshr", "s_ashr", "s_bfe", "s_mul", "s_min", "s_max", "s_abs", "s_addc", "s_subb", "s_bitcmp", "s_wqm", "s_bcnt", "s_ff", "s_flbit", "s_sext", "s_absdiff", "s_cselect") ):
-                    pass                                     # (SCC is not an SGPR mask: nothing to track)
+        if m: cur = (m.group(1), []); funcs.append(cur); continue
+        if cur is not None: cur[1].append((ln, raw))
+    findings, asm_sites, valu_sgpr_reads = [], 0, 0
+
+    def merge(a, b):                       # most recent write wins, register by register
+        if a is None: return dict(b)
+        out = dict(a)
+        for r, v in b.items(): out[r] = min(out.get(r, 99), v)
+        return out
+
+    for func, body in funcs:
+        incoming = {}                      # label -> state arriving over branches
+        for sweep in range(4):
+            last = sweep == 3
+            found, sites, reads_n = [], 0, 0
+            age, in_asm, dead, changed = {}, False, False, False
+            for ln, raw in body:
+                t = raw.strip()
+                if ";;#ASMSTART" in t: in_asm = True; sites += 1; continue
+                if ";;#ASMEND" in t: in_asm = False; continue
+                m = re.match(r"^(\.?[A-Za-z_][\w.$]*):", t)
+                if m and not t.startswith("//"):
+                    lab = m.group(1)
+                    age = merge(None if dead else age, incoming.get(lab, {})) if (lab in incoming or not dead) else {}
+                    dead = False
+                    continue
+                if not t or t[0] in ";." or t.startswith("//"): continue
+                t = t.split(";")[0].strip()
+                ops = t.split(None, 1)
+                op = ops[0]
+                if not re.match(r"^[a-z][a-z0-9_]+$", op): continue
+                args = [a.strip() for a in ops[1].split(",")] if len(ops) > 1 else []
+                if op == "s_nop":
+                    n = int(args[0], 0) + 1
+                    age = {r: a + n for r, a in age.items()}
+                    continue
+                if op.startswith("v_"):
+                    ndst = 2 if TWO_DST.match(op) else 1
+                    reads, writes = set(), set()
+                    for a in args[ndst:]: reads |= sregs(a.split(" ")[0])
+                    for a in args[:ndst]: writes |= sregs(a)
+                    if reads: reads_n += 1
+                    hot = [r for r in reads if age.get(r, 99) < 2]
+                    if hot:
+                        found.append("%s line %d%s: '%s' reads s%s %d wait state(s) after a VALU write" %
+                                     (func[:50], ln, " (inside asm)" if in_asm else "", t, sorted(hot), min(age[r] for r in hot)))
+                    age = {r: a + 1 for r, a in age.items()}
+                    for r in writes: age[r] = 0
+                    continue
+                # SALU / memory / branch: one wait state; an SALU write to a register ends the VALU-write hazard on it
+                age = {r: a + 1 for r, a in age.items()}
+                if op.startswith("s_") and args and not op.startswith(("s_cbranch", "s_branch")):
+                    for r in sregs(args[0]): age.pop(r, None)
+                if op.startswith(("s_cbranch", "s_branch")) and args:
+                    tgt = args[-1]
+                    new = merge(incoming.get(tgt), age)
+                    if new != incoming.get(tgt): incoming[tgt] = new; changed = True
+                    if op == "s_branch": dead = True           # nothing falls through an unconditional branch
+            if last or not changed:
+                findings += found; asm_sites += sites; valu_sgpr_reads += reads_n
+                break
     return findings, asm_sites, valu_sgpr_reads
 
 
 def main(argv):
     if len(argv) >= 2 and argv[0] == "--asm":
-        lines = open(argv[1]).read().split("\n")
-    else:
+        listings = [open(argv[1]).read().split("\n")]
+    else:                                      # every translation unit of the library (cuhe_amd/build.py: UNITS)
+        sys.path.insert(0, ROOT)
+        from cuhe_amd import build as B
+        listings = []
         with tempfile.TemporaryDirectory() as d:
-            s = os.path.join(d, "dev.s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S"] + argv +
-                                  ["-o", s, os.path.join(ROOT, "cuhe_amd/csrc/cuhe_hip.hip"), "-I" + os.path.join(ROOT, "include")],
-                                  stderr=subprocess.DEVNULL)
-            lines = open(s).read().split("\n")
-    findings, asm_sites, reads = check(lines)
+            procs = []
+            for name, src, extra in B.UNITS:
+                out = os.path.join(d, name + ".s")
+                procs.append((out, subprocess.Popen([B.HIPCC] + B.FLAGS + extra + ["--cuda-device-only", "-S"] + argv + ["-o", out, os.path.join(B.CSRC, src)],
+                                                    stderr=subprocess.DEVNULL)))
+            for out, p in procs:
+                if p.wait() != 0: raise RuntimeError("compilation failed: " + out)
+                listings.append(open(out).read().split("\n"))
+    findings, asm_sites, reads = [], 0, 0
+    for lines in listings:
+        f, a, r = check(lines)
+        findings += f; asm_sites += a; reads += r
     for f in findings[:40]: print(f)
     print("asm sites: %d, VALU instructions reading an SGPR / VCC: %d, findings: %d" % (asm_sites, reads, len(findings)))
     return 1 if findings else 0
