@@ -97,6 +97,7 @@ struct DevCtx {
     bool ready = false;
     NttTab ntt[3];                       // LG 14,15,16
     OwTab ow[3];                         // sub-transforms of 8K, 16K, 32K points
+    int cus = 0;                         // compute units (policy of the one-workgroup transforms)
     // prime tables
     u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
     u64 *pinv = nullptr;
@@ -140,7 +141,11 @@ struct Global {
     bool allocator_on = false;
     size_t cache_cap = (size_t)4 << 30;  // with the pooled allocator off, freed blocks are still kept up to this many bytes
     int ntt_chunk = 0;
-    int onewg = getenv("CUHE_ONEWG") ? atoi(getenv("CUHE_ONEWG")) : 1;   // one-workgroup transforms: 0 never, 1 wherever they exist
+    // one-workgroup transforms: 0 never; 1 where they exist and the call fills the chip; 2 wherever they exist (tests)
+    int onewg = getenv("CUHE_ONEWG") ? atoi(getenv("CUHE_ONEWG")) : 1;
+    // zero-padded rows of 64K points (32K-point halves, ONE workgroup per CU): 0 two-pass kernels (default: same speed,
+    // profiles/r03_onewg_ab.txt), 1 one workgroup per half, 2 persistent workgroups with LDS-DMA prefetch of the samples
+    int onewg64 = getenv("CUHE_ONEWG64") ? atoi(getenv("CUHE_ONEWG64")) : 0;
     bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
     std::mutex mu;
@@ -333,6 +338,9 @@ int ensure_ntt(int dev, int len, int batch_hint) {
     tab.chunk = (chunk + 7) & ~7;
     DevCtx &D = G_.dev[dev];
     if (!D.s1) {
+        int cur = 0;
+        HIPCHK(hipGetDevice(&cur));
+        HIPCHK(hipDeviceGetAttribute(&D.cus, hipDeviceAttributeMultiprocessorCount, cur));
         HIPCHK(hipStreamCreateWithFlags(&D.s1, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&D.s2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&D.ev_start, hipEventDisableTiming));
@@ -486,7 +494,12 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
     {
         const bool half = src_is_ext(mode);
         const int lgh = half ? LG - 1 : LG;
-        if (G_.onewg && lgh <= 15) {
+        // worth it once the call's workgroups (1 / 2 / 4 fit a CU at 32K / 16K / 8K points) fill the chip; below that the
+        // two-pass kernels spread a row over 8 - 16 workgroups and finish sooner
+        const long wgs = (long)batch * (half ? 2 : 1);
+        const bool fills = G_.onewg == 2 || (lgh >= 13 && lgh <= 15 && wgs >= (long)D.cus * (1 << (15 - lgh)));
+        const bool rows64 = half && lgh == 15;
+        if (G_.onewg && lgh <= 15 && fills && (!rows64 || G_.onewg64)) {
             int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
             if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
                 if (ep && ep->kind) { out = ep->kind == 1 ? kOutModPRevQ : kOutFoldFinal; e = *ep; }
@@ -505,7 +518,15 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 OwArgs a{dst, src, half ? ot.TW1h : inv ? ot.TW1i : ot.TW1f, ot.TW2, mode == kSrcWindow ? 0 : src_stride, dst_stride, batch, nst, wa, tw,
                          D.p, D.pinv, prime0, np_mod, e.aux, e.aux_stride, e.fg, xt};
                 if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-                CHK(onewg_launch(lgh, mode, out, half, a, st));
+                // 64K-point rows: one workgroup per CU walks over its share of the halves, the next half's samples arriving by
+                // LDS-DMA beside stage 3 of the current one (16-byte aligned rows, at least two halves per workgroup)
+                const int grid = D.cus & ~15;
+                const bool stream = G_.onewg64 == 2 && rows64 && mode == kSrcU32Ext && grid >= 16 && wgs >= 2L * grid &&
+                                    ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
+                if (stream) {
+                    hipError_t he = ow_launch_stream(out, a, grid, st);
+                    if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform: %s", hipGetErrorString(he));
+                } else CHK(onewg_launch(lgh, mode, out, half, a, st));
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 return CUHE_OK;
             }
@@ -2075,7 +2096,11 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     G_.ntt_chunk = chunk;
     return CUHE_OK;
 }
-int cuhe_hip_set_onewg(int mode) { if (mode < 0 || mode > 1) return fail(CUHE_EINVAL, "mode %d", mode); G_.onewg = mode; return CUHE_OK; }
+int cuhe_hip_set_onewg(int mode, int rows64k) {
+    if (mode < 0 || mode > 2 || rows64k < 0 || rows64k > 2) return fail(CUHE_EINVAL, "mode %d, rows64k %d", mode, rows64k);
+    G_.onewg = mode; G_.onewg64 = rows64k;
+    return CUHE_OK;
+}
 int cuhe_hip_set_ntt_overlap(int on) { G_.ntt_overlap = on != 0; return CUHE_OK; }
 int cuhe_hip_set_ll_rows(int rows) { if (rows < 0) return fail(CUHE_EINVAL, "rows %d", rows); g_ll_rows = rows; return CUHE_OK; }
 int cuhe_hip_ntt_fwd_batched(uint64_t *dst, const uint32_t *src, int len, int batch, long src_stride, int dev, void *st) {

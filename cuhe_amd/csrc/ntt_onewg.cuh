@@ -8,8 +8,7 @@
 // cuhe/Operations.cu:306-398).  The zero-padded forward transform of the reference contract (u32[L/2] -> u64[L],
 // cuhe/Base.cu:309-437) is done as its two decimation-in-frequency halves: the outputs of parity h are the L/2-point
 // transform of x[j] W^(j h), W = w_L -- W^(a T) = 2^(3a) is a shift of the samples, W^m joins the stage-1 twiddle table --
-// one workgroup per half (HALF mode), both halves of a transform on one XCD so that their interleaved 8-byte stores
-// meet in its L2.
+// one workgroup per half (HALF mode), both halves of a transform on one XCD.
 //
 // Dataflow (tests/onewg_model.py is the executable statement of the index formulas; tests/test_onewg_model.py pins it to
 // the oracle):
@@ -20,6 +19,11 @@
 //   stage 3  Y[t3 + T kc] = DFT32_c(z), stored through the same epilogues as pass 2 (ntt_kernels.cuh: pass2_store)
 // Each exchange moves half of every thread's values at a time (the LDS holds half a transform: 1 / 2 / 4 workgroups
 // per CU at 32K / 16K / 8K points); rows are padded to odd strides (R + 1, 33 u64): conflict-free on both sides.
+//
+// Two kernels share the stages: ntt_onewg (one workgroup per sub-transform: 2 / 4 of them overlap on a CU at 16K / 8K
+// points) and ntt_onewg_stream (32K-point halves of the 64K-point zero-padded transform, where only ONE workgroup fits a
+// CU: a persistent workgroup walks over its share of the batch and the u32 samples of the NEXT half arrive in the idle
+// exchange buffer by LDS-DMA while stage 3 of the current one computes and stores).
 #pragma once
 #include "ntt_kernels.cuh"
 
@@ -29,7 +33,7 @@ template <int R>
 struct OwGeom {
     static constexpr int T = 32 * R, Lh = 32 * T, NP = 32 / R;
     static constexpr int X1W = 16 * 32 * (R + 1), X2W = (R / 2) * 32 * 33;
-    static constexpr int XW = X1W > X2W ? X1W : X2W;              // exchange buffer (u64 words)
+    static constexpr int XW = R == 32 ? 32 * 545 : (X1W > X2W ? X1W : X2W);      // exchange buffer (u64 words); R = 32: the balanced layouts below
     static constexpr size_t bytes = (size_t)(XW + T) * sizeof(u64);   // + the stage-2 twiddle table
 };
 
@@ -54,17 +58,184 @@ struct HalfShift {                                       // x[a] *= 2^(3a): the 
     }
 };
 
+// the 32-point transform of stage 1 and its twiddle products.  The table values arrive in batches that are in flight during
+// the butterflies (a first batch of 4: more would spill) / during the products of the previous batch (hipcc places a
+// load next to its use: an L2 round trip per value, which one workgroup per CU has nothing to hide behind).
+template <int T>
+__device__ __forceinline__ void ow_dft_twiddle(u64 (&x)[32], const u64 *__restrict__ t1, bool row0) {
+    u64 w0[4], wa[8], wb[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = t1[i * T];
+    __builtin_amdgcn_sched_barrier(0);
+    dft_regs<32, false>(x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wa[i] = t1[(4 + i) * T];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ka = 0; ka < 4; ++ka)
+        if (ka != 0 || row0) x[bitrev<32>(ka)] = mulp(x[bitrev<32>(ka)], w0[ka]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wb[i] = t1[(12 + i) * T];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ka = 4; ka < 12; ++ka) x[bitrev<32>(ka)] = mulp(x[bitrev<32>(ka)], wa[ka - 4]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wa[i] = t1[(20 + i) * T];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ka = 12; ka < 20; ++ka) x[bitrev<32>(ka)] = mulp(x[bitrev<32>(ka)], wb[ka - 12]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[i] = t1[(28 + i) * T];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ka = 20; ka < 28; ++ka) x[bitrev<32>(ka)] = mulp(x[bitrev<32>(ka)], wa[ka - 20]);
+#pragma unroll
+    for (int ka = 28; ka < 32; ++ka) x[bitrev<32>(ka)] = mulp(x[bitrev<32>(ka)], w0[ka - 28]);
+}
+
+// ---- stage 1 after the samples are in x: 32-point transform, stage-1 twiddles (t1 = table + m; row0: row ka = 0 of the
+// table is not all ones), exchange 1.
+template <int R>
+__device__ __forceinline__ void ow_stage1_x1(u64 (&x)[32], u64 (&y)[32], u64 *buf, const u64 *__restrict__ t1, bool row0, int t) {
+    using G = OwGeom<R>;
+    constexpr int T = G::T, NP = G::NP;
+    ow_dft_twiddle<T>(x, t1, row0);
+    const int c = t & 31, q = t >> 5;                     // writer: (b, c) = (q, c); reader: (kq, c) = (q, c)
+    {
+        u64 *wr = buf + c * (R + 1) + q;
+#pragma unroll
+        for (int kl = 0; kl < 16; ++kl) wr[kl * 32 * (R + 1)] = x[bitrev<32>(kl)];
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if (hh == 1) {
+            u64 *wr = buf + c * (R + 1) + q;
+#pragma unroll
+            for (int kl = 0; kl < 16; ++kl) wr[kl * 32 * (R + 1)] = x[bitrev<32>(16 + kl)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            bool act;
+            if constexpr (R == 32) act = (q >> 4) == hh;              // whole waves
+            else act = ((R * i) >> 4) == hh;                          // known at compile time: ka = q + R i, q < R <= 16
+            if (act) {
+                const u64 *rd = buf + (((q + R * i) & 15) * 32 + c) * (R + 1);
+#pragma unroll
+                for (int b = 0; b < R; ++b) y[i * R + b] = rd[b];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- stage 2 (NP transforms of R points, times w_T^(c kb)), exchange 2 (last_sync: a barrier after the last reads,
+// for a caller that re-uses the buffer); the caller finishes with stage 3: dft_regs<32>(z), z[bitrev32(kc)] = Y[t + T kc]
+template <int R>
+__device__ __forceinline__ void ow_stage2_x2(u64 (&y)[32], u64 (&z)[32], u64 *buf, const u64 *tw2, int t, bool last_sync) {
+    using G = OwGeom<R>;
+    constexpr int NP = G::NP;
+    const int c = t & 31, q = t >> 5;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        u64 (&sub)[R] = *reinterpret_cast<u64(*)[R]>(&y[i * R]);
+        dft_regs<R, false>(sub);
+#pragma unroll
+        for (int kb = 1; kb < R; ++kb) sub[bitrev<R>(kb)] = mulp(sub[bitrev<R>(kb)], tw2[32 * kb + c]);
+    }
+    const int ka3 = t & 31, kb3 = t >> 5;                 // reader t3 = ka + 32 kb
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            u64 *w = buf + (q + R * i) * 33 + c;
+#pragma unroll
+            for (int kl = 0; kl < R / 2; ++kl) w[kl * 32 * 33] = y[i * R + bitrev<R>(hh * (R / 2) + kl)];
+        }
+        __syncthreads();
+        if ((kb3 / (R / 2)) == hh) {                      // whole waves: t3 < T/2 or >= T/2
+            const u64 *rd = buf + ((kb3 - hh * (R / 2)) * 32 + ka3) * 33;
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) z[cc] = rd[cc];
+        }
+        if (hh == 0 || last_sync) __syncthreads();
+    }
+}
+
+// ---- R = 32 (32K points, one workgroup of 1024 threads per CU): exchanges whose READ side is unconditional and balanced
+// (tests/onewg_model.py: simulate32).  Stage-2 thread t2 = kq + 32 c.
+//   X1, half h: the waves with b in [16 h, 16 h + 16) (t = 32 b + c) store all 32 A[ka] -> buf[c 545 + ka 17 + (b - 16 h)];
+//               every reader (kq, c) takes its 16 values b
+//   X2, half h: the waves with c in [16 h, 16 h + 16) (t2 = kq + 32 c) store all 32 B[kb] -> buf[kb 544 + ka 17 + (c - 16 h)];
+//               every reader (ka, kb) takes its 16 values c
+// Every thread's y / z are assigned on every path, which also keeps them out of the loop-carried state of the persistent kernel.
+__device__ __forceinline__ void ow32_stage1_x1(u64 (&x)[32], u64 (&y)[32], u64 *buf, const u64 *__restrict__ t1, bool row0, int t) {
+    ow_dft_twiddle<1024>(x, t1, row0);
+    const int lo = t & 31, hi = t >> 5;                   // writer (b, c) = (hi, lo); reader (kq, c) = (lo, hi)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if ((hi >> 4) == hh) {                            // whole waves
+            u64 *wr = buf + lo * 545 + (hi & 15);
+#pragma unroll
+            for (int ka = 0; ka < 32; ++ka) wr[ka * 17] = x[bitrev<32>(ka)];
+        }
+        __syncthreads();
+        const u64 *rd = buf + hi * 545 + lo * 17;
+#pragma unroll
+        for (int bl = 0; bl < 16; ++bl) y[16 * hh + bl] = rd[bl];
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void ow32_stage2_x2(u64 (&y)[32], u64 (&z)[32], u64 *buf, const u64 *tw2, int t, bool last_sync) {
+    const int lo = t & 31, hi = t >> 5;                   // stage 2: (kq, c) = (lo, hi); stage 3: (ka, kb) = (lo, hi)
+    dft_regs<32, false>(y);
+#pragma unroll
+    for (int kb = 1; kb < 32; ++kb) y[bitrev<32>(kb)] = mulp(y[bitrev<32>(kb)], tw2[32 * kb + hi]);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if ((hi >> 4) == hh) {                            // whole waves
+            u64 *wr = buf + lo * 17 + (hi & 15);
+#pragma unroll
+            for (int kb = 0; kb < 32; ++kb) wr[kb * 544] = y[bitrev<32>(kb)];
+        }
+        __syncthreads();
+        const u64 *rd = buf + hi * 544 + lo * 17;
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl) z[16 * hh + cl] = rd[cl];
+        if (hh == 0 || last_sync) __syncthreads();
+    }
+}
+
+// the outputs of parity h of the zero-padded transform: Y[k] -> X[2 k + h]
+template <int R, int OUT>
+__device__ __forceinline__ void ow_store_half(const u64 (&z)[32], void *dst_, long dst_stride, int batch, int h, int t,
+                                              const u64 *__restrict__ xtab, int prime0, int np_mod) {
+    constexpr int T = OwGeom<R>::T;
+    constexpr long L = 2L * OwGeom<R>::Lh;
+    static_assert(OUT == kOutU64 || OUT == kOutU64Mul, "HALF mode stores u64 rows");
+    u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + h;
+    if constexpr (OUT == kOutU64Mul) {
+        const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
+        const u64 *tab = xtab + (long)pidx * L + h;
+#pragma unroll
+        for (int kc = 0; kc < 32; ++kc) { const long o = 2L * (t + T * kc); dst[o] = mulp(z[bitrev<32>(kc)], tab[o]); }
+    } else {
+#pragma unroll
+        for (int kc = 0; kc < 32; ++kc) dst[2L * (t + T * kc)] = z[bitrev<32>(kc)];
+    }
+}
+
 // LGH: log2 of the sub-transform; HALF: the transform has 2^(LGH+1) points with a zero upper input half and this
 // workgroup produces the outputs of one parity.  TW1: HALF ? u64[2][Lh] (parity h at + h Lh) : u64[Lh].
 template <int LGH, int MODE, int OUT, bool HALF>
-__global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T)
+__global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
 void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
                long src_stride, long dst_stride, int nbatch, int nstore, WindowArgs wa, const u64 *__restrict__ tw,
                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
                const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab) {
     constexpr int R = (1 << LGH) / 1024;
     using G = OwGeom<R>;
-    constexpr int T = G::T, Lh = G::Lh, NP = G::NP;
+    constexpr int T = G::T, Lh = G::Lh;
     constexpr int LGF = HALF ? LGH + 1 : LGH;             // log2 of the transform the caller sees
     constexpr bool INV = out_is_inverse(OUT);
     static_assert(!HALF || (src_is_ext(MODE) && !INV), "HALF mode is the zero-padded forward transform");
@@ -83,83 +254,20 @@ void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64
     const int t = threadIdx.x;
     tw2[t] = TW2[t];
 
-    // ---- stage 1: thread m = t
-    u64 x[32];
+    u64 x[32], y[32], z[32];
 #pragma unroll
     for (int a = 0; a < 32; ++a) x[a] = load_sample<LGF, MODE>(src_, src_stride, batch, a * T + t, wa, tw);
     if constexpr (HALF) { if (h) HalfShift<0>::run(x); }
-    dft_regs<32, false>(x);
-    {
-        const u64 *t1 = TW1 + (HALF ? (long)h * Lh : 0) + t;
-        const bool row0 = INV || (HALF && h);              // row ka = 0 of the table is not all ones
-#pragma unroll
-        for (int ka = 0; ka < 32; ++ka)
-            if (ka != 0 || row0) x[bitrev<32>(ka)] = mulp(x[bitrev<32>(ka)], t1[ka * T]);
+    if constexpr (R == 32) {
+        ow32_stage1_x1(x, y, buf, TW1 + (HALF ? (long)h * Lh : 0) + t, INV || (HALF && h), t);
+        ow32_stage2_x2(y, z, buf, tw2, t, false);
+    } else {
+        ow_stage1_x1<R>(x, y, buf, TW1 + (HALF ? (long)h * Lh : 0) + t, INV || (HALF && h), t);
+        ow_stage2_x2<R>(y, z, buf, tw2, t, false);
     }
-    // ---- exchange 1
-    const int c = t & 31, q = t >> 5;                     // writer: (b, c) = (q, c); reader: (kq, c) = (q, c)
-    u64 y[32];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        {
-            u64 *w = buf + c * (R + 1) + q;
-#pragma unroll
-            for (int kl = 0; kl < 16; ++kl) w[kl * 32 * (R + 1)] = x[bitrev<32>(16 * hh + kl)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int ka = q + R * i;
-            if ((ka >> 4) == hh) {                        // R = 32: wave-uniform; R < 32: known at compile time (i)
-                const u64 *rd = buf + ((ka & 15) * 32 + c) * (R + 1);
-#pragma unroll
-                for (int b = 0; b < R; ++b) y[i * R + b] = rd[b];
-            }
-        }
-        __syncthreads();
-    }
-    // ---- stage 2: NP transforms of R points, times w_T^(c kb)
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        u64 (&sub)[R] = *reinterpret_cast<u64(*)[R]>(&y[i * R]);
-        dft_regs<R, false>(sub);
-#pragma unroll
-        for (int kb = 1; kb < R; ++kb) sub[bitrev<R>(kb)] = mulp(sub[bitrev<R>(kb)], tw2[32 * kb + c]);
-    }
-    // ---- exchange 2
-    const int ka3 = t & 31, kb3 = t >> 5;                 // reader t3 = ka + 32 kb
-    u64 z[32];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            u64 *w = buf + (q + R * i) * 33 + c;
-#pragma unroll
-            for (int kl = 0; kl < R / 2; ++kl) w[kl * 32 * 33] = y[i * R + bitrev<R>(hh * (R / 2) + kl)];
-        }
-        __syncthreads();
-        if ((kb3 / (R / 2)) == hh) {                      // whole waves: t3 < T/2 or >= T/2
-            const u64 *rd = buf + ((kb3 - hh * (R / 2)) * 32 + ka3) * 33;
-#pragma unroll
-            for (int cc = 0; cc < 32; ++cc) z[cc] = rd[cc];
-        }
-        if (hh == 0) __syncthreads();
-    }
-    // ---- stage 3
-    dft_regs<32, false>(z);                               // z[bitrev32(kc)] = Y[t3 + T kc]
+    dft_regs<32, false>(z);
     if constexpr (HALF) {
-        constexpr long L = 2L * Lh;
-        u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + h;
-        if constexpr (OUT == kOutU64Mul) {
-            const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
-            const u64 *tab = xtab + (long)pidx * L + h;
-#pragma unroll
-            for (int kc = 0; kc < 32; ++kc) { const long o = 2L * (t + T * kc); dst[o] = mulp(z[bitrev<32>(kc)], tab[o]); }
-        } else {
-            static_assert(OUT == kOutU64 || OUT == kOutU64Mul, "HALF mode stores u64 rows");
-#pragma unroll
-            for (int kc = 0; kc < 32; ++kc) dst[2L * (t + T * kc)] = z[bitrev<32>(kc)];
-        }
+        ow_store_half<R, OUT>(z, dst_, dst_stride, batch, h, t, xtab, prime0, np_mod);
     } else {
         // the pass-2 epilogues take the four outputs X[k1 + N1 (b + 16 cc)], N1 = Lh / 64 = T / 2:  t3 = k1 + N1 hi,
         // kc = b' + 8 cc  <=>  b = hi + 2 b'
@@ -174,6 +282,76 @@ void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64
             pass2_store<LGH, OUT>(y4, hi + 2 * bp, k1, batch, A);
         }
     }
+}
+
+// ---- persistent form for the 32K-point halves of the 64K-point zero-padded forward transform (u32 rows).
+// Work item i = 2 * transform + parity, in the order of ntt_onewg's blocks; workgroup g takes items g, g + grid, ...
+// The u32 samples of an item (128 KB) arrive by LDS-DMA in the exchange buffer, which is idle from the last read of
+// exchange 2 to the first write of exchange 1 of the next item: the transfer runs beside stage 3 and its stores.
+__device__ __forceinline__ void glds16(const void *gsrc, u32 lds_byte_addr) {     // 64 lanes x 16 B -> LDS [addr, addr + 1 KB), lane-linear
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+// H: the parity this workgroup produces.  The grid is a multiple of 16 workgroups, so that the parity (item >> 3) & 1 is the
+// same for every item of a workgroup and the odd half's sample shifts sit on a straight-line path.
+template <int OUT, int H>
+__device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, u64 *buf, const u64 *tw2,
+                                               long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod) {
+    constexpr int R = 32;
+    using G = OwGeom<R>;
+    constexpr int T = G::T, Lh = G::Lh;
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int nitems = 2 * ((nbatch + 7) & ~7);
+    const u32 lds_base = (u32)(uintptr_t)buf;              // LDS byte address of the buffer (generic -> local: low 32 bits)
+    // items of a padding transform (batch rounded up to 8) are computed on the last real row and not stored: no divergent
+    // control flow around the barriers
+    auto fetch = [&](int i) {                              // samples of item i -> buf (as u32[Lh]); wave w moves bytes [8 KB w, 8 KB (w+1))
+        const int b = min((i >> 4) * 8 + (i & 7), nbatch - 1);
+        const char *row = (const char *)(src + (long)b * src_stride) + lane * 16;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const u32 off = (u32)(wave * 8 + p) * 1024u;
+            glds16(row + off, lds_base + off);
+        }
+    };
+    if ((int)blockIdx.x < nitems) fetch(blockIdx.x);
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int batch = (item >> 4) * 8 + (item & 7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every wave's part of the samples has landed
+        // an offset the compiler cannot see through, new in every iteration: otherwise the ~100 loop-invariant table and
+        // LDS addresses of the body are hoisted out of the loop and live across it (600+ bytes of spills per lane)
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        u64 *lb = buf + opaque;
+        u64 x[32], y[32], z[32];
+        {
+            const u32 *in = (const u32 *)lb + t;
+#pragma unroll
+            for (int a = 0; a < 32; ++a) x[a] = in[a * T];
+        }
+        __syncthreads();                                   // samples are in registers: the buffer is free for exchange 1
+        if constexpr (H) HalfShift<0>::run(x);
+        ow32_stage1_x1(x, y, lb, TW1 + (long)H * Lh + t + opaque, H != 0, t);
+        ow32_stage2_x2(y, z, lb, tw2 + opaque, t, true);
+        if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);      // the buffer is idle until exchange 1 of the next item
+        dft_regs<32, false>(z);
+        if (batch < nbatch) ow_store_half<R, OUT>(z, dst_, dst_stride, batch, H, t, xtab, prime0, np_mod);
+    }
+}
+template <int OUT>
+__global__ __launch_bounds__(1024, 4)
+void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
+                      long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod) {
+    using G = OwGeom<32>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 *buf = lds;
+    u64 *tw2 = lds + G::XW;
+    tw2[threadIdx.x] = TW2[threadIdx.x];
+    if ((blockIdx.x >> 3) & 1) ow_stream_loop<OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod);
+    else ow_stream_loop<OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod);
 }
 
 }  // namespace cuhe

@@ -20,6 +20,7 @@ struct OwArgs {
 hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
+hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, hipStream_t st);      // kSrcU32Ext rows of 64K-point transforms
 bool ow_supported(int mode, int out, bool half);
 
 }  // namespace cuhe

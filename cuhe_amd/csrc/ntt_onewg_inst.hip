@@ -64,6 +64,33 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
     return hipErrorInvalidValue;
 }
 #if CUHE_OW_LGH == 15
+// persistent form of the 32K-point halves of the 64K-point zero-padded forward transform (ntt_onewg_stream): `grid`
+// workgroups (a multiple of 16, at most one per CU) walk over the 2 * batch halves
+hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, hipStream_t st) {
+    if (out != kOutU64 && out != kOutU64Mul) return hipErrorInvalidValue;
+    if (grid < 16 || (grid & 15)) return hipErrorInvalidValue;
+    auto k0 = ntt_onewg_stream<kOutU64>;
+    auto k1 = ntt_onewg_stream<kOutU64Mul>;
+    static std::mutex mu; static std::atomic<uint64_t> done{0};
+    int cur = 0;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (cur & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
+            e = hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
+            if (e != hipSuccess) return e;
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    if (out == kOutU64)
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod);
+    else
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod);
+    return hipGetLastError();
+}
 bool ow_supported(int mode, int out, bool half) {
     if (half) return (mode == kSrcU32Ext && (out == kOutU64 || out == kOutU64Mul)) || (mode == kSrcWindow && out == kOutU64);
     if (mode == kSrcU32Twist) return out == kOutU64 || out == kOutU64Mul;

@@ -279,10 +279,15 @@ int cuhe_hip_set_ntt_overlap(int on);
 int cuhe_hip_set_ll_rows(int rows);
 /* One-workgroup transforms (cuhe_amd/csrc/ntt_onewg.cuh): a sub-transform of 8K / 16K / 32K points in the registers of
  * one workgroup, ONE launch and no slab in HBM; the zero-padded forward transforms of 16K / 32K / 64K points run as their
- * two half-length halves.  1 (default): wherever that form exists; 0: the two-pass kernels only (the parity tests run
- * both).  Same results.  Environment CUHE_ONEWG overrides the default for A/B runs of whole programs.  Replaces the
- * same reference code as the two-pass kernels (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398). */
-int cuhe_hip_set_onewg(int mode);
+ * two half-length halves.  mode 1 (default): wherever that form exists and the call has enough rows to fill the chip with
+ * its workgroups (1 / 2 / 4 per CU at 32K / 16K / 8K points; below that the two-pass kernels finish sooner); 2: wherever
+ * it exists, whatever the row count (the parity tests run every form); 0: the two-pass kernels only.
+ * rows64k selects the form of zero-padded rows of 64K points, whose 32K-point halves leave room for ONE workgroup per
+ * CU: 0 (default) the two-pass kernels (equal speed, profiles/r03_onewg_ab.txt), 1 one workgroup per half, 2 persistent
+ * workgroups (one per CU, the next half's samples prefetched into LDS by DMA).  Same results in every form.
+ * Environment CUHE_ONEWG / CUHE_ONEWG64 override the defaults for A/B runs of whole programs.  Replaces the same
+ * reference code as the two-pass kernels (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398). */
+int cuhe_hip_set_onewg(int mode, int rows64k);
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,

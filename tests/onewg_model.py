@@ -15,6 +15,14 @@ Each exchange moves HALF of every thread's 32 values at a time (the LDS holds ha
   X1, half h:  the writers' A[ka], ka in [16 h, 16 h + 16)  ->  buf[((ka - 16 h) * 32 + c) * (R + 1) + b]
   X2, half h:  the writers' B[.][kb], kb in [R/2 h, R/2 (h+1))  ->  buf[((kb - R/2 h) * 32 + ka) * 33 + c]
 
+R = 32 (32K points, ONE workgroup per CU) uses exchanges whose READ side is unconditional and balanced (simulate32):
+  stage-2 thread t2 = kq + 32 c (kq in the lane bits);
+  X1, half h:  writers with b in [16 h, 16 h + 16) (whole waves: t = 32 b + c) store all 32 A[ka]
+               ->  buf[c * 545 + ka * 17 + (b - 16 h)],  every reader (kq, c) takes its 16 values b
+  X2, half h:  writers with c in [16 h, 16 h + 16) (whole waves: t2 = kq + 32 c) store all 32 B[kb]
+               ->  buf[kb * 544 + ka * 17 + (c - 16 h)],  every reader (ka, kb) takes its 16 values c
+  (odd strides 17 / 545 u64: conflict-free for the lanes along c, ka)
+
 HALF mode (the reference's zero-padded forward transform of 2 Lh points, cuhe/Base.cu:309-437): the outputs of parity h
 are the Lh-point transform of x[j] W^(j h), W = w_(2 Lh); W^(a T) = 2^(3 a) is a shift applied to the samples, W^m joins
 the stage-1 twiddle, and Y[k] lands at X[2 k + h]."""
@@ -118,6 +126,74 @@ def simulate(R, u, half=False, h=0):
             for c in range(32):
                 z[t3][c] = buf[x2_addr(kb - lo, ka, c)]
     # ---- stage 3
+    Y = [None] * Lh
+    for t3 in range(T):
+        d = dft(z[t3], w32)
+        for kc in range(32):
+            Y[t3 + T * kc] = d[kc]
+    return Y
+
+
+def x1_addr32(c, ka, b_l):
+    return c * 545 + ka * 17 + b_l
+
+
+def x2_addr32(kb, ka, c_l):
+    return kb * 544 + ka * 17 + c_l
+
+
+LDS_WORDS32 = 32 * 545
+
+
+def simulate32(u, half=False, h=0):
+    """R = 32 with the balanced exchanges (see the module docstring); same contract as simulate(32, ...)."""
+    R, T, Lh = 32, 1024, 32768
+    w, W = root(Lh), root(2 * Lh)
+    w32 = pow(2, 6, P)
+    tw1 = lambda ka, m: pow(W, m * (2 * ka + 1), P) if (half and h) else pow(w, m * ka, P)
+    tw2 = lambda kb, c: pow(w, 32 * c * kb, P)
+    A = []
+    for m in range(T):
+        x = [u[a * T + m] for a in range(32)]
+        if half and h:
+            x = [x[a] * pow(2, 3 * a, P) % P for a in range(32)]
+        a_ = dft(x, w32)
+        A.append([a_[ka] * tw1(ka, m) % P for ka in range(32)])
+    y = [[None] * 32 for _ in range(T)]
+    for hh in range(2):
+        buf = [None] * LDS_WORDS32
+        for m in range(T):
+            b, c = m // 32, m % 32
+            if b // 16 != hh:
+                continue
+            for ka in range(32):
+                ad = x1_addr32(c, ka, b - 16 * hh)
+                assert buf[ad] is None
+                buf[ad] = A[m][ka]
+        for t2 in range(T):
+            kq, c = t2 % 32, t2 // 32
+            for bl in range(16):
+                y[t2][16 * hh + bl] = buf[x1_addr32(c, kq, bl)]
+    Bv = []
+    for t2 in range(T):
+        c = t2 // 32
+        d = dft(y[t2], w32)
+        Bv.append([d[kb] * tw2(kb, c) % P for kb in range(32)])
+    z = [[None] * 32 for _ in range(T)]
+    for hh in range(2):
+        buf = [None] * LDS_WORDS32
+        for t2 in range(T):
+            kq, c = t2 % 32, t2 // 32
+            if c // 16 != hh:
+                continue
+            for kb in range(32):
+                ad = x2_addr32(kb, kq, c - 16 * hh)
+                assert buf[ad] is None
+                buf[ad] = Bv[t2][kb]
+        for t3 in range(T):
+            ka, kb = t3 % 32, t3 // 32
+            for cl in range(16):
+                z[t3][16 * hh + cl] = buf[x2_addr32(kb, ka, cl)]
     Y = [None] * Lh
     for t3 in range(T):
         d = dft(z[t3], w32)

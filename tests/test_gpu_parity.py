@@ -1079,8 +1079,10 @@ def test_sharded_multiply_through_the_c_abi(gu):
                                        ("pow2_16384", (3, 2, 16, 50, 25, 16384)), ("pow2_32768", (3, 2, 16, 48, 24, 32768)),
                                        ("c3_65536", (9, 2, 16, 576, 24, 65536)), ("n65536", (3, 2, 16, 46, 23, 131072))])
 def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
-    """Both forms of the transform kernels (16 values per thread: throughput; 4 values per thread, radix-4 through LDS:
-    low latency, taken below cuhe_hip_set_ll_rows rows) give the same bits on every source / store variant: zero-padded
+    """Every form of the transform kernels (two passes with 16 values per thread: throughput; 4 values per thread, radix-4
+    through LDS: low latency, taken below cuhe_hip_set_ll_rows rows; ONE workgroup per 8K / 16K / 32K-point sub-transform,
+    cuhe_hip_set_onewg, forced here whatever the row count; its persistent form on a large batch of 64K-point rows)
+    gives the same bits on every source / store variant: zero-padded
     and full forward transforms (all three lengths), window transforms, index-negated inverses with `% p` and a ragged store
     count, the fused x^n+1 reduction, the folded generic reduction's two epilogues, table products, the negacyclic twist
     and untwist, the product-on-load inverse of the batched chain.  One run of each operation per form, compared with each other and (once) with the oracle."""
@@ -1090,9 +1092,10 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
     o = O.Ctx(*args) if name != "n65536" else None
     res = {}
     try:
-        for form in (NONE, ALL):
+        for form, onewg in ((NONE, 0), (ALL, 0), (NONE, 2)):
             g = gu.GpuCtx(*args)
             ck(lib.cuhe_hip_set_ll_rows(form))
+            ck(lib.cuhe_hip_set_onewg(onewg, 1))
             try:
                 q = g.prm
                 K, W0, M0 = q.numEvalKey, g.words(0), g.coeff_modulus(0)
@@ -1131,7 +1134,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                         ck(lib.cuhe_hip_ntt_inv_batched(d.data_ptr(), gu.to_dev(X[:3] if npr >= 3 else np.repeat(X[:1], 3, 0)).data_ptr(),
                                                         q.nttLen, 3, q.nttLen, nst, 0 if npr < 4 else 1, 0, None))
                         out[("ragged", lvl)] = gu.host_u32(d)
-                if form == NONE:
+                if form == NONE and onewg == 0:
                     res = out
                     if o is not None:
                         a0 = O.random_raw(q.rawLen, q.modLen, W0, M0, 0xA900)[0]
@@ -1142,21 +1145,42 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                         assert np.array_equal(v, res[k]), (name, k)
             finally:
                 ck(lib.cuhe_hip_set_ll_rows(24))
+                ck(lib.cuhe_hip_set_onewg(1, 0))
                 g.close()
         # the standalone batched forward entry point at all three lengths, odd batch
         for length in (16384, 32768, 65536):
             x = np.stack([O.splitmix_u32_below(length // 2, 0xFFFFFFFF, 900 + b) for b in range(5)])
             ck(lib.cuhe_hip_ntt_prepare(length, 0))
             got = []
-            for form in (NONE, ALL):
+            for form, onewg in ((NONE, 0), (ALL, 0), (NONE, 2)):
                 ck(lib.cuhe_hip_set_ll_rows(form))
+                ck(lib.cuhe_hip_set_onewg(onewg, 1))
                 dX = gu.empty_u64(5, length)
                 ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), gu.to_dev(x).data_ptr(), length, 5, length // 2, 0, None))
                 got.append(gu.host_u64(dX))
             ck(lib.cuhe_hip_set_ll_rows(24))
-            assert np.array_equal(got[0], got[1]), length
+            ck(lib.cuhe_hip_set_onewg(1, 0))
+            assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]), length
             assert np.array_equal(got[1][4], O.ntt_ext(x[4], length)), length
+        if name == "toy1155":
+            # the persistent form of the 64K-point rows needs a batch that gives every workgroup two halves; 301 rows: a
+            # last group of 8 with padding items.  Against the two-pass kernels on every row, against the oracle on three.
+            length, batch = 65536, 301
+            x = np.stack([O.splitmix_u32_below(length // 2, 0xFFFFFFFF, 7000 + b) for b in range(batch)])
+            dx = gu.to_dev(x)
+            got = []
+            for onewg, r64 in ((0, 0), (1, 2), (1, 1)):
+                ck(lib.cuhe_hip_set_onewg(onewg, r64))
+                dX = gu.empty_u64(batch, length)
+                for _ in range(2):                                      # twice: the second call re-uses the tables
+                    ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), dx.data_ptr(), length, batch, length // 2, 0, None))
+                got.append(gu.host_u64(dX))
+            ck(lib.cuhe_hip_set_onewg(1, 0))
+            assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+            for b in (0, 150, 300):
+                assert np.array_equal(got[1][b], O.ntt_ext(x[b], length)), b
     finally:
         ck(lib.cuhe_hip_set_ll_rows(24))
+        ck(lib.cuhe_hip_set_onewg(1, 0))
         if o is not None:
             o.close()

@@ -29,8 +29,19 @@ def test_full_mode_equals_cyclic_transform_of_full_input():
     assert all(int(want[2 * k]) == got[k] for k in range(Lh))
 
 
+def test_32k_balanced_exchanges_equal_zero_padded_transform():
+    Lh = 32768
+    x = O.splitmix_u32_below(Lh, (1 << 32) - 1, 5)
+    want = O.ntt_ext(x, 2 * Lh)
+    u = [int(v) for v in x]
+    for h in (0, 1):
+        got = M.simulate32(u, half=True, h=h)
+        assert all(int(want[2 * k + h]) == got[k] for k in range(Lh)), "half %d" % h
+    assert (M.LDS_WORDS32 + 1024) * 8 <= 160 * 1024
+
+
 def test_lds_budget():
     # bytes of the exchange buffer + the stage-2 twiddle table: 4 / 2 / 1 workgroups per CU inside 160 KiB
-    for R, per_cu in ((8, 4), (16, 2), (32, 1)):
+    for R, per_cu in ((8, 4), (16, 2)):
         bytes_ = (M.lds_words(R) + 32 * R) * 8
         assert bytes_ * per_cu <= 160 * 1024, (R, bytes_)

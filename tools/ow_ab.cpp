@@ -19,27 +19,30 @@ static uint64_t sm(uint64_t &s) { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z 
 int main(int argc, char **argv) {
     const int big = argc > 1 ? atoi(argv[1]) : 4096;          // transforms per timed call at 64K points
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
-    for (int len : {16384, 32768, 65536}) {
+    // equality against the two-pass kernels: every length at a small odd batch (mode 3: one-workgroup form whatever the row
+    // count), and 64K points at a batch that takes the persistent form (mode 1; 301 rows: padding items in the last group of 8)
+    struct Case { int len, batch, mode, r64; };
+    for (Case cs : {Case{16384, 37, 2, 0}, Case{32768, 37, 2, 0}, Case{65536, 37, 2, 1}, Case{65536, 301, 1, 2}, Case{65536, 301, 1, 1}, Case{32768, 600, 1, 0}, Case{16384, 1100, 1, 0}}) {
+        const int len = cs.len, batch = cs.batch;
         CK(cuhe_hip_ntt_prepare(len, 0));
-        const int batch = 37;
         std::vector<uint32_t> h((size_t)batch * len / 2);
-        uint64_t s = len;
+        uint64_t s = len + batch;
         for (auto &v : h) v = (uint32_t)sm(s);
         h[0] = 0xffffffffu; h[1] = 0; h[2] = 1;
         uint32_t *dx; uint64_t *dA, *dB;
         HK(hipMalloc(&dx, h.size() * 4)); HK(hipMalloc(&dA, (size_t)batch * len * 8)); HK(hipMalloc(&dB, (size_t)batch * len * 8));
         HK(hipMemcpy(dx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         HK(hipMemset(dA, 0xAA, (size_t)batch * len * 8)); HK(hipMemset(dB, 0x55, (size_t)batch * len * 8));
-        CK(cuhe_hip_set_onewg(0));
+        CK(cuhe_hip_set_onewg(0, 0));
         CK(cuhe_hip_ntt_fwd_batched(dA, dx, len, batch, len / 2, 0, nullptr));
-        CK(cuhe_hip_set_onewg(1));
-        CK(cuhe_hip_ntt_fwd_batched(dB, dx, len, batch, len / 2, 0, nullptr));
+        CK(cuhe_hip_set_onewg(cs.mode, cs.r64));
+        for (int rep = 0; rep < 2; ++rep) CK(cuhe_hip_ntt_fwd_batched(dB, dx, len, batch, len / 2, 0, nullptr));
         HK(hipDeviceSynchronize());
         std::vector<uint64_t> a((size_t)batch * len), b((size_t)batch * len);
         HK(hipMemcpy(a.data(), dA, a.size() * 8, hipMemcpyDeviceToHost)); HK(hipMemcpy(b.data(), dB, b.size() * 8, hipMemcpyDeviceToHost));
         size_t bad = 0, first = 0;
         for (size_t i = 0; i < a.size(); ++i) if (a[i] != b[i]) { if (!bad) first = i; ++bad; }
-        printf("len %d batch %d: %zu mismatches%s\n", len, batch, bad, bad ? "" : "  (bit-identical)");
+        printf("len %d batch %d mode %d/%d: %zu mismatches%s\n", len, batch, cs.mode, cs.r64, bad, bad ? "" : "  (bit-identical)");
         if (bad) printf("   first at row %zu index %zu: two-pass %016llx one-wg %016llx\n", first / len, first % len, (unsigned long long)a[first], (unsigned long long)b[first]);
         hipFree(dx); hipFree(dA); hipFree(dB);
     }
@@ -51,14 +54,15 @@ int main(int argc, char **argv) {
         uint64_t s = 77 + len;
         for (auto &v : h) v = (uint32_t)sm(s);
         HK(hipMemcpy(dx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-        for (int mode : {0, 1, 0, 1}) {
-            CK(cuhe_hip_set_onewg(mode));
+        for (int mode : {0, 2, 1, 0, 2, 1}) {
+            if (len != 65536 && mode == 2) continue;              // (modes 1 and 2 differ at 64K points only)
+            CK(cuhe_hip_set_onewg(mode ? 1 : 0, mode == 2 ? 1 : mode == 1 ? 2 : 0));
             float p1 = 0, p2 = 0, tot = 0;
             CK(cuhe_hip_time_ntt_fwd(dA, dx, len, batch, 2, 0, nullptr, &p1, &p2, &tot));       // warm
             CK(cuhe_hip_time_ntt_fwd(dA, dx, len, batch, iters, 0, nullptr, &p1, &p2, &tot));
             const double per = tot / iters * 1e-3 / batch;
             printf("len %d batch %d %s: %.4f ms per call, %.3f M transforms/s, HBM-roofline frac %.4f  (passes %.4f + %.4f ms)\n", len, batch,
-                   mode ? "one-wg " : "two-pass", tot / iters, 1e-6 / per, 10.0 * len / per / 8e12, p1 / iters, p2 / iters);
+                   mode == 0 ? "two-pass" : mode == 2 ? "one-wg  " : len == 65536 ? "one-wg persistent" : "one-wg  ", tot / iters, 1e-6 / per, 10.0 * len / per / 8e12, p1 / iters, p2 / iters);
         }
         hipFree(dx); hipFree(dA);
     }
