@@ -88,11 +88,10 @@ struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = 
 // tables of the one-workgroup transforms (ntt_onewg.cuh) of Lh = 2^(13 + index) points
 struct OwTab {
     u64 *TW1f = nullptr, *TW1i = nullptr, *TW1h = nullptr, *TW2 = nullptr;      // forward, inverse (x Lh^-1), both parities of the zero-padded form, stage 2
-    u64 *TW1q = nullptr;                                                        // 16K points only: the four quarters of the 64K-point zero-padded form
     std::atomic<int> ready{0};
     OwTab() {}
-    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), TW1q(o.TW1q), ready(o.ready.load()) {}
-    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; TW1q = o.TW1q; ready.store(o.ready.load()); return *this; }
+    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), ready(o.ready.load()) {}
+    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; ready.store(o.ready.load()); return *this; }
 };
 struct DevCtx {
     bool ready = false;
@@ -395,15 +394,6 @@ int ensure_onewg(OwTab &tab, int lgh) {
     for (int kb = 0; kb < R; ++kb)
         for (int c = 0; c < 32; ++c) t2[(size_t)kb * 32 + c] = r[(64L * c * kb) % (2L * Lh)];      // w_T^(c kb) = w_Lh^(32 c kb)
     CHK(upload(&tab.TW1f, f)); CHK(upload(&tab.TW1i, fi)); CHK(upload(&tab.TW1h, fh)); CHK(upload(&tab.TW2, t2));
-    if (lgh == 14) {                                   // quarters of the 64K-point zero-padded transform: W^(m (r + 4 ka)), W = w_64K
-        std::vector<u64> g(65536), fq(4 * (size_t)Lh);
-        g[0] = 1;
-        for (size_t i = 1; i < g.size(); ++i) g[i] = host::mulP(g[i - 1], host::G);
-        for (int rq = 0; rq < 4; ++rq)
-            for (int ka = 0; ka < 32; ++ka)
-                for (int m = 0; m < T; ++m) fq[(size_t)rq * Lh + (size_t)ka * T + m] = g[((long)m * (rq + 4 * ka)) % 65536];
-        CHK(upload(&tab.TW1q, fq));
-    }
     tab.ready.store(1, std::memory_order_release);
     return CUHE_OK;
 }
@@ -509,19 +499,6 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         const long wgs = (long)batch * (half ? 2 : 1);
         const bool fills = G_.onewg == 2 || (lgh >= 13 && lgh <= 15 && wgs >= (long)D.cus * (1 << (15 - lgh)));
         const bool rows64 = half && lgh == 15;
-        if (rows64 && G_.onewg && G_.onewg64 == 3 && (G_.onewg == 2 || 4L * batch >= 2L * D.cus)) {
-            // QUARTER form: four 16K-point sub-transforms per row, two workgroups per CU
-            const int out = mul_tab ? kOutU64Mul : kOutU64;
-            OwTab &ot = D.ow[1];
-            CHK(ensure_onewg(ot, 14));
-            OwArgs a{dst, src, ot.TW1q, ot.TW2, mode == kSrcWindow ? 0 : src_stride, dst_stride, batch, nstore, wa, nullptr,
-                     D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, mul_tab};
-            if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            hipError_t he = ow_launch_quarter(mode, out, a, host::powP(host::G, 512), st);
-            if (he != hipSuccess) return fail(CUHE_EHIP, "one-workgroup transform, quarter form: %s", hipGetErrorString(he));
-            if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            return CUHE_OK;
-        }
         if (G_.onewg && lgh <= 15 && fills && (!rows64 || G_.onewg64)) {
             int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
             if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
@@ -2120,7 +2097,7 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     return CUHE_OK;
 }
 int cuhe_hip_set_onewg(int mode, int rows64k) {
-    if (mode < 0 || mode > 2 || rows64k < 0 || rows64k > 3) return fail(CUHE_EINVAL, "mode %d, rows64k %d", mode, rows64k);
+    if (mode < 0 || mode > 2 || rows64k < 0 || rows64k > 2) return fail(CUHE_EINVAL, "mode %d, rows64k %d", mode, rows64k);
     G_.onewg = mode; G_.onewg64 = rows64k;
     return CUHE_OK;
 }

@@ -284,80 +284,6 @@ void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64
     }
 }
 
-// ---- QUARTER form: the zero-padded forward transform of 64K points as FOUR sub-transforms of 16K points (two workgroups
-// per CU instead of the one a 32K-point half leaves room for).  X[4 k + r] is the 16K-point transform of
-//   u_r[j] = (x[j] + i^r x[j + 16K]) W^(r j),  W = w_64K, i = 2^48;   j = a 512 + m:
-// W^(r a 512) = w_128^(r a) is a shift for even r a and a shift times the constant w_128 for odd r a (w_128^2 = 8), and
-// W^(r m) joins the stage-1 table, TW1q[r][ka 512 + m] = W^(m (r + 4 ka))  (tests/onewg_model.py: simulate(quarter = r)).
-template <int K>
-__device__ __forceinline__ u64 mulpow2(u64 v) {           // v * 2^K, K in [0, 192)
-    if constexpr (K >= 96) return negp(shlp<K - 96>(v));
-    else return shlp<K>(v);
-}
-template <int RQ>
-__device__ __forceinline__ u64 quarter_combine(u32 x0, u32 x1) {        // x0 + i^RQ x1, canonical
-    if constexpr (RQ == 0) return (u64)x0 + x1;
-    else if constexpr (RQ == 1) return addp((u64)x0, shlp32<48>(x1));
-    else if constexpr (RQ == 2) return subp((u64)x0, (u64)x1);
-    else return subp((u64)x0, shlp32<48>(x1));
-}
-template <int RQ, int A>
-struct QuarterTwist {                                     // x[a] *= w_128^(RQ a)
-    static __device__ __forceinline__ void run(u64 (&x)[32], u64 c128) {
-        constexpr int e = RQ * A;                         // < 128
-        u64 v = mulpow2<(3 * (e / 2)) % 192>(x[A]);
-        if constexpr (e % 2) v = mulp(v, c128);
-        x[A] = v;
-        if constexpr (A + 1 < 32) QuarterTwist<RQ, A + 1>::run(x, c128);
-    }
-};
-template <int RQ, int MODE, int OUT>
-__device__ __forceinline__ void ow_quarter_body(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1q, u64 *buf, const u64 *tw2,
-                                                long src_stride, long dst_stride, int batch, WindowArgs wa, u64 c128,
-                                                const u64 *__restrict__ xtab, int prime0, int np_mod) {
-    constexpr int R = 16, T = 512, Lh = 16384;
-    const int t = threadIdx.x;
-    u64 x[32], y[32], z[32];
-#pragma unroll
-    for (int a = 0; a < 32; ++a) {
-        const u32 x0 = (u32)load_sample<16, MODE>(src_, src_stride, batch, a * T + t, wa, nullptr);
-        const u32 x1 = (u32)load_sample<16, MODE>(src_, src_stride, batch, (a + 32) * T + t, wa, nullptr);
-        x[a] = quarter_combine<RQ>(x0, x1);
-    }
-    if constexpr (RQ != 0) QuarterTwist<RQ, 0>::run(x, c128);
-    ow_stage1_x1<R>(x, y, buf, TW1q + (long)RQ * Lh + t, RQ != 0, t);
-    ow_stage2_x2<R>(y, z, buf, tw2, t, false);
-    dft_regs<32, false>(z);
-    static_assert(OUT == kOutU64 || OUT == kOutU64Mul, "QUARTER form stores u64 rows");
-    u64 *dst = (u64 *)dst_ + (long)batch * dst_stride + RQ;
-    if constexpr (OUT == kOutU64Mul) {
-        const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
-        const u64 *tab = xtab + (long)pidx * 65536 + RQ;
-#pragma unroll
-        for (int kc = 0; kc < 32; ++kc) { const long o = 4L * (t + T * kc); dst[o] = mulp(z[bitrev<32>(kc)], tab[o]); }
-    } else {
-#pragma unroll
-        for (int kc = 0; kc < 32; ++kc) dst[4L * (t + T * kc)] = z[bitrev<32>(kc)];
-    }
-}
-// blocks g, g + 8, g + 16, g + 24: the four quarters of one transform, same XCD
-template <int MODE, int OUT>
-__global__ __launch_bounds__(512, 4)
-void ntt_onewg_quarter(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1q, const u64 *__restrict__ TW2,
-                       long src_stride, long dst_stride, int nbatch, WindowArgs wa, u64 c128, const u64 *__restrict__ xtab, int prime0, int np_mod) {
-    using G = OwGeom<16>;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64 *buf = lds, *tw2 = lds + G::XW;
-    const int g = blockIdx.x, q = g >> 3, r = q & 3;
-    const int batch = (q >> 2) * 8 + (g & 7);
-    if (batch >= nbatch) return;
-    tw2[threadIdx.x] = TW2[threadIdx.x];
-    if (r == 0) ow_quarter_body<0, MODE, OUT>(dst_, src_, TW1q, buf, tw2, src_stride, dst_stride, batch, wa, c128, xtab, prime0, np_mod);
-    else if (r == 1) ow_quarter_body<1, MODE, OUT>(dst_, src_, TW1q, buf, tw2, src_stride, dst_stride, batch, wa, c128, xtab, prime0, np_mod);
-    else if (r == 2) ow_quarter_body<2, MODE, OUT>(dst_, src_, TW1q, buf, tw2, src_stride, dst_stride, batch, wa, c128, xtab, prime0, np_mod);
-    else ow_quarter_body<3, MODE, OUT>(dst_, src_, TW1q, buf, tw2, src_stride, dst_stride, batch, wa, c128, xtab, prime0, np_mod);
-}
-
 // ---- persistent form for the 32K-point halves of the 64K-point zero-padded forward transform (u32 rows).
 // Work item i = 2 * transform + parity, in the order of ntt_onewg's blocks; workgroup g takes items g, g + grid, ...
 // The u32 samples of an item (128 KB) arrive by LDS-DMA in the exchange buffer, which is idle from the last read of

@@ -21,8 +21,6 @@ hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream
 hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, hipStream_t st);      // kSrcU32Ext rows of 64K-point transforms
-// a.TW1 = u64[4][16384] (the quarter tables), c128 = w_128; kSrcU32Ext / kSrcWindow rows of 64K-point transforms
-hipError_t ow_launch_quarter(int mode, int out, const OwArgs &a, u64 c128, hipStream_t st);
 bool ow_supported(int mode, int out, bool half);
 
 }  // namespace cuhe

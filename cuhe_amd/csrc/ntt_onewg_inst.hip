@@ -63,36 +63,6 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
     OW_CASE(kSrcU64NegMul, kOutModPNc, false)
     return hipErrorInvalidValue;
 }
-#if CUHE_OW_LGH == 14
-// QUARTER form of the 64K-point zero-padded forward transform: four 16K-point sub-transforms per row (ntt_onewg_quarter)
-template <int MODE, int OUT>
-static hipError_t launch_quarter(const OwArgs &a, u64 c128, hipStream_t st) {
-    auto kern = ntt_onewg_quarter<MODE, OUT>;
-    static std::mutex mu; static std::atomic<uint64_t> done{0};
-    int cur = 0;
-    hipError_t e = hipGetDevice(&cur);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (cur & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!(done.load(std::memory_order_relaxed) & bit)) {
-            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
-            if (e != hipSuccess) return e;
-            done.fetch_or(bit, std::memory_order_release);
-        }
-    }
-    const int nb8 = (a.nbatch + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(4 * nb8), dim3(Geo::T), Geo::bytes, st, a.dst, a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.wa, c128,
-                       a.xtab, a.prime0, a.np_mod);
-    return hipGetLastError();
-}
-hipError_t ow_launch_quarter(int mode, int out, const OwArgs &a, u64 c128, hipStream_t st) {
-    if (mode == kSrcU32Ext && out == kOutU64) return launch_quarter<kSrcU32Ext, kOutU64>(a, c128, st);
-    if (mode == kSrcU32Ext && out == kOutU64Mul) return launch_quarter<kSrcU32Ext, kOutU64Mul>(a, c128, st);
-    if (mode == kSrcWindow && out == kOutU64) return launch_quarter<kSrcWindow, kOutU64>(a, c128, st);
-    return hipErrorInvalidValue;
-}
-#endif
 #if CUHE_OW_LGH == 15
 // persistent form of the 32K-point halves of the 64K-point zero-padded forward transform (ntt_onewg_stream): `grid`
 // workgroups (a multiple of 16, at most one per CU) walk over the 2 * batch halves

@@ -58,13 +58,9 @@ def lds_words(R):
     return max(16 * 32 * (R + 1), (R // 2) * 32 * 33)
 
 
-def simulate(R, u, half=False, h=0, quarter=None):
+def simulate(R, u, half=False, h=0):
     """u: list of Lh samples (already index-mapped: u[j] = sample j of the sub-transform, before any twist).
-    Returns Y[0..Lh): the Lh-point transform (HALF: the parity-h outputs of the 2 Lh-point transform of u).
-    quarter = r (0..3): u holds the 2 Lh non-zero samples of a zero-padded transform of 4 Lh points and Y[k] = X[4 k + r]:
-    the samples are first combined in pairs, u'[j] = (u[j] + i^r u[j + Lh]) W4^(r j), W4 = w_(4 Lh), i = 2^48; the factor
-    W4^(r a T) = w_128^(r a) (T = 512) is a shift for even r a and a shift times the constant w_128 for odd r a, and
-    W4^(r m) joins the stage-1 table: TW1[ka T + m] = W4^(m (r + 4 ka))."""
+    Returns Y[0..Lh): the Lh-point transform (HALF: the parity-h outputs of the 2 Lh-point transform of u)."""
     T = 32 * R
     Lh = 32 * T
     NP = 32 // R
@@ -73,28 +69,12 @@ def simulate(R, u, half=False, h=0, quarter=None):
     w32 = pow(2, 6, P)
     wR = pow(2, 192 // R, P)
     assert pow(w, T, P) == w32 and pow(w, 1024, P) == wR
-    if quarter is not None:
-        W4 = root(4 * Lh)
-        assert R == 16 and pow(W4, 2 * T, P) == 8
-        c128 = pow(W4, T, P)                                  # w_128
-        tw1 = lambda ka, m: pow(W4, m * (quarter + 4 * ka), P)
-    else:
-        tw1 = lambda ka, m: pow(W, m * (2 * ka + 1), P) if (half and h) else pow(w, m * ka, P)
+    tw1 = lambda ka, m: pow(W, m * (2 * ka + 1), P) if (half and h) else pow(w, m * ka, P)
     tw2 = lambda kb, c: pow(w, 32 * c * kb, P)
     # ---- stage 1
     A = []
     for m in range(T):
-        if quarter is not None:
-            x = []
-            for a in range(32):
-                v = (u[a * T + m] + pow(2, 48 * quarter, P) * u[(a + 32) * T + m]) % P
-                e = quarter * a                               # w_128^e = 2^(3 (e // 2)) * w_128^(e % 2)
-                v = v * pow(2, 3 * (e // 2), P) % P
-                if e % 2:
-                    v = v * c128 % P
-                x.append(v)
-        else:
-            x = [u[a * T + m] for a in range(32)]
+        x = [u[a * T + m] for a in range(32)]
         if half and h:
             x = [x[a] * pow(2, 3 * a, P) % P for a in range(32)]
         a_ = dft(x, w32)

@@ -29,15 +29,6 @@ def test_full_mode_equals_cyclic_transform_of_full_input():
     assert all(int(want[2 * k]) == got[k] for k in range(Lh))
 
 
-def test_quarter_mode_equals_zero_padded_transform_of_64k_points():
-    x = O.splitmix_u32_below(32768, (1 << 32) - 1, 41)
-    want = O.ntt_ext(x, 65536)
-    u = [int(v) for v in x]
-    for r in range(4):
-        got = M.simulate(16, u, quarter=r)
-        assert all(int(want[4 * k + r]) == got[k] for k in range(16384)), "quarter %d" % r
-
-
 def test_32k_balanced_exchanges_equal_zero_padded_transform():
     Lh = 32768
     x = O.splitmix_u32_below(Lh, (1 << 32) - 1, 5)
