@@ -368,7 +368,12 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
         K, W = q.numEvalKey, lib.cuhe_hip_words_coeff(0)
         ek = np.random.default_rng(7).integers(0, 1 << 32, (K, q.rawLen, W), dtype=np.uint32)
         ek[:, :, W - 1] &= 0x7FFF
-        ck(lib.cuhe_hip_init_relin(ek.ctypes.data_as(C.c_void_p)))
+        # each rank keeps the evaluation keys of ITS primes only (keys partitioned with the primes)
+        kf, kc = C.c_int(), C.c_int()
+        ck(lib.cuhe_hip_key_range(world, rank, C.byref(kf), C.byref(kc)))
+        ck(lib.cuhe_hip_init_relin_range(ek.ctypes.data_as(C.c_void_p), kf.value, kc.value))
+        lib_ct_len = lib.cuhe_hip_ct_len()
+        key_bytes = kc.value * K * lib_ct_len * 8
         hb = HipBackend()
         sh = ShardedMulRelin(hb, 0, rank, world)
         gen = torch.Generator(device=dev); gen.manual_seed(5)
@@ -385,17 +390,17 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
         lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
         return {"error": "set-up failed on at least one rank" + (": " + err if err else "")}
     # in-library communicator: rank 0 makes the id, torch.distributed carries the 128 bytes
-    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-    ok = 1
+    # (byte 128 carries rank 0's verdict: if it could not make the id NOBODY calls comm_init -- the others would block in it)
+    idt = torch.zeros(129, dtype=torch.uint8, device=dev)
     if rank == 0:
         uid = (C.c_uint8 * 128)()
-        if lib.cuhe_hip_comm_unique_id(uid) == 0:
-            idt = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
-        else:
-            ok = 0
+        made = lib.cuhe_hip_comm_unique_id(uid) == 0
+        idt = torch.tensor(list(uid) + [1 if made else 0], dtype=torch.uint8, device=dev)
     dist.broadcast(idt, 0)
+    host_id = [int(v) for v in idt.cpu().tolist()]
+    ok = host_id[128]
     if ok:
-        uid = (C.c_uint8 * 128)(*[int(v) for v in idt.cpu().tolist()])
+        uid = (C.c_uint8 * 128)(*host_id[:128])
         ok = 1 if lib.cuhe_hip_comm_init(world, rank, uid) == 0 else 0
     comm_err = None if ok else lib.cuhe_hip_last_error().decode()[:200]
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
@@ -424,9 +429,30 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # the part every participant repeats (ICRT of the gathered rows, window extraction, the k window transforms): timed as
+    # ICRT + the key switch onto ONE prime; its share of the call is the serial fraction that bounds the speed-up
+    rows_all = torch.randint(0, 1 << (q.logCrtPrime - 1), (q.numCrtPrime, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+    raw = torch.zeros((q.rawLen, W), dtype=torch.int32, device=dev)
+    acc1 = torch.empty((1, lib.cuhe_hip_ct_len()), dtype=torch.int64, device=dev)
+    def replicated():
+        ck(lib.cuhe_hip_icrt(raw.data_ptr(), rows_all.data_ptr(), lib.cuhe_hip_log_coeff(0), 0, None))
+        ck(lib.cuhe_hip_relin_range(acc1.data_ptr(), raw.data_ptr(), 0, sh.first, 1, 0, None))
+    for _ in range(3):
+        replicated()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        replicated()
+    torch.cuda.synchronize()
+    t_rep = (time.perf_counter() - t0) / reps
     lib.cuhe_hip_comm_destroy()
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s (one ciphertext, primes sharded)", "ms": round(dt * 1e3, 3),
+            "key_bytes_per_rank": key_bytes, "key_primes_per_rank": kc.value,
+            "replicated_ms": round(t_rep * 1e3, 3), "serial_fraction": round(t_rep / dt, 3),
+            "serial_note": "ICRT + window extraction + the k window transforms are repeated on every rank (exchanging the transformed windows instead "
+                           "would move k*n*8 = %d B per multiply against %d B of CRT rows); the key-switch inner product, both inverse transforms and the "
+                           "key memory divide by the number of ranks" % (K * lib_ct_len * 8, q.numCrtPrime * q.crtLen * 4),
             "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "ring_degree": q.modLen,
             "exchange": "RCCL group of broadcasts inside cuhe_hip_mul_relin_sharded, on the compute stream" if in_library
                         else "torch.distributed all-gather around the C-ABI stages (in-library communicator unavailable: %s)" % comm_err,

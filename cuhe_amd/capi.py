@@ -124,6 +124,9 @@ SIGNATURES = {
     "cuhe_hip_crt_range": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "cuhe_hip_ntt_fwd_batched": (i32, [vp, vp, i32, i32, lng, i32, vp]),
     "cuhe_hip_ntt_inv_batched": (i32, [vp, vp, i32, i32, lng, i32, i32, i32, vp]),
+    "cuhe_hip_init_relin_range": (i32, [vp, i32, i32]),
+    "cuhe_hip_key_range": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "cuhe_hip_init_relin_sharded": (i32, [vp]),
     "cuhe_hip_shard_bounds": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
     "cuhe_hip_comm_unique_id": (i32, [vp]),
     "cuhe_hip_comm_init": (i32, [i32, i32, vp]),

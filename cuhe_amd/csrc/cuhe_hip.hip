@@ -110,6 +110,7 @@ struct DevCtx {
     u32 *m_crt = nullptr;
     // relinearisation (cuhe/Relinearization.cu:37-38) -- keys resident in HBM
     u64 *ek = nullptr;
+    int ek_first = 0, ek_count = 0;      // CRT primes whose keys this device holds: row 0 of `ek` is prime ek_first (cuhe_hip_init_relin_range)
     unsigned char *ekd = nullptr; MacDigGeom ekg{0, 0, 0, 0, 0}; bool ekd_unavailable = false;      // signed base-256 digits of the keys in MFMA operand order (built on first use)
     std::vector<Workspace *> spaces;     // every workspace of this device (owned here)
     std::vector<Workspace *> idle;       // workspaces of finished threads, adopted by later ones
@@ -883,8 +884,14 @@ void shl_dispatch(int l, uint64_t *z, const uint64_t *x, size_t n, hipStream_t s
 
 // ---- key-switch inner product on the matrix cores: key digits, launch
 bool mac_mfma_supported(int K) { return K >= 1 && K <= 128; }          // at most two K steps are instantiated
+int need_all_keys(const DevCtx &D) {
+    if (D.ek_first != 0 || D.ek_count != G_.prm.numCrtPrime)
+        return fail(CUHE_EINVAL, "this device holds the keys of primes [%d, %d) only (cuhe_hip_init_relin_range): the call needs all %d", D.ek_first, D.ek_first + D.ek_count, G_.prm.numCrtPrime);
+    return CUHE_OK;
+}
 int ensure_key_digits(int dev, hipStream_t st) {
     DevCtx &D = G_.dev[dev];
+    CHK(need_all_keys(D));
     std::lock_guard<std::mutex> lk(G_.mu);
     if (D.ekd) return CUHE_OK;
     const Params &q = G_.prm;
@@ -1446,30 +1453,34 @@ int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void 
 }
 
 // ---------------------------------------------------------------- relinearisation
-int cuhe_hip_init_relin(const uint32_t *ek_host) {
+// keys of the primes [first[dev], first[dev] + count[dev]) on every device (count < 0: all primes)
+static int init_relin_impl(const uint32_t *ek_host, const int *first, const int *count) {
     if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
     const Params &q = G_.prm;
     const int K = q.numEvalKey, np = q.numCrtPrime, L = ct_len(), W0 = q.wordsCoeff(0);     // keys live in the ct domain
     if (K <= 0) return fail(CUHE_EINVAL, "numEvalKey = 0");
     const size_t rawBytes = (size_t)q.rawLen * W0 * 4;
     for (int dev = 0; dev < G_.ndev; ++dev) {
+        const int p0 = first ? first[dev] : 0, pc = count ? count[dev] : np;
+        if (p0 < 0 || pc < 1 || p0 + pc > np) return fail(CUHE_EINVAL, "key range [%d, %d) of %d primes", p0, p0 + pc, np);
         CHK(set_dev(dev));
         DevCtx &D = G_.dev[dev];
         if (D.ek) { hipFree(D.ek); D.ek = nullptr; }
         if (D.ekd) { hipFree(D.ekd); D.ekd = nullptr; }
         D.ekd_unavailable = false;
-        HIPCHK(hipMalloc((void **)&D.ek, (size_t)np * K * L * sizeof(u64)));
+        HIPCHK(hipMalloc((void **)&D.ek, (size_t)pc * K * L * sizeof(u64)));
+        D.ek_first = p0; D.ek_count = pc;
         u32 *raw = nullptr, *crt = nullptr; u64 *ntt = nullptr;
         HIPCHK(hipMalloc((void **)&raw, rawBytes));
         HIPCHK(hipMalloc((void **)&crt, (size_t)np * q.crtLen * 4));
-        HIPCHK(hipMalloc((void **)&ntt, (size_t)np * L * 8));
+        HIPCHK(hipMalloc((void **)&ntt, (size_t)pc * L * 8));
         for (int j = 0; j < K; ++j) {                              // cuhe/Relinearization.cu:49-56
             HIPCHK(hipMemcpy(raw, ek_host + (size_t)j * q.rawLen * W0, rawBytes, hipMemcpyHostToDevice));
             HIPCHK(hipMemsetAsync(crt, 0, (size_t)np * q.crtLen * 4, 0));
             CHK(cuhe_hip_crt(crt, raw, q.logCoeff(0), dev, nullptr));
-            CHK(ct_forward(ntt, crt, np, dev, nullptr));
-            // ek[prime i][key j][L]
-            HIPCHK(hipMemcpy2DAsync(D.ek + (size_t)j * L, (size_t)K * L * 8, ntt, (size_t)L * 8, (size_t)L * 8, np,
+            CHK(ct_forward(ntt, crt + (size_t)p0 * q.crtLen, pc, dev, nullptr));
+            // ek[prime i - p0][key j][L]
+            HIPCHK(hipMemcpy2DAsync(D.ek + (size_t)j * L, (size_t)K * L * 8, ntt, (size_t)L * 8, (size_t)L * 8, pc,
                                     hipMemcpyDeviceToDevice, 0));
         }
         HIPCHK(hipDeviceSynchronize());
@@ -1478,6 +1489,33 @@ int cuhe_hip_init_relin(const uint32_t *ek_host) {
     G_.relin_ready = true;
     return CUHE_OK;
 }
+int cuhe_hip_init_relin(const uint32_t *ek_host) { return init_relin_impl(ek_host, nullptr, nullptr); }
+// The keys of `count` CRT primes from `prime0` on only: what a participant of the CRT-prime-sharded multiply needs
+// (cuhe_hip_key_range gives the range that covers its block at every level): key memory / number of participants.
+int cuhe_hip_init_relin_range(const uint32_t *ek_host, int prime0, int count) {
+    std::vector<int> f(std::max(G_.ndev, 1), prime0), c(std::max(G_.ndev, 1), count);
+    return init_relin_impl(ek_host, f.data(), c.data());
+}
+// primes participant `rank` of `nranks` owns at ANY level (its contiguous block moves down as the levels drop primes)
+int cuhe_hip_key_range(int nranks, int rank, int *first, int *count) {
+    if (!G_.params_set || nranks < 1 || rank < 0 || rank >= nranks || !first || !count) return fail(CUHE_EINVAL, "key_range(nranks %d, rank %d)", nranks, rank);
+    int lo = 1 << 30, hi = 0;
+    for (int lvl = 0; lvl < G_.prm.depth; ++lvl) {
+        int f = 0, c = 0;
+        comm::shard_bounds(G_.prm.numCrtPrimeAt(lvl), nranks, rank, &f, &c);
+        if (c > 0) { lo = std::min(lo, f); hi = std::max(hi, f + c); }
+    }
+    if (hi <= lo) { lo = 0; hi = 1; }
+    *first = lo; *count = hi - lo;
+    return CUHE_OK;
+}
+// in-process form: device d of multiGPUs(n) keeps the keys of the primes it owns in cuhe_hip_mul_relin_sharded_inproc
+int cuhe_hip_init_relin_sharded(const uint32_t *ek_host) {
+    std::vector<int> f(G_.ndev), c(G_.ndev);
+    for (int d = 0; d < G_.ndev; ++d) CHK(cuhe_hip_key_range(G_.ndev, d, &f[d], &c[d]));
+    return init_relin_impl(ek_host, f.data(), c.data());
+}
+
 // ---- binary evaluation-key cache.  initRelinearization costs numEvalKey * numCrtPrime forward
 // transforms plus the upload of the raw keys; the NTT-domain keys it produces depend only on the parameter set,
 // the CRT primes and the key polynomials, so a deployment computes them once and reloads this image.
@@ -1538,6 +1576,7 @@ int cuhe_hip_relin_export(void *dst, size_t cap, int dev) {
     EkHeader h = ek_header_now();
     if (!dst || cap < sizeof h + h.payload_bytes) return fail(CUHE_EINVAL, "export buffer too small: %zu < %zu", cap, sizeof h + (size_t)h.payload_bytes);
     uint8_t *out = (uint8_t *)dst;
+    CHK(need_all_keys(G_.dev[dev]));
     HIPCHK(hipMemcpy(out + sizeof h, G_.dev[dev].ek, h.payload_bytes, hipMemcpyDeviceToHost));
     h.payload_hash = hash_words((const uint64_t *)(out + sizeof h), h.payload_bytes / 8, nullptr);
     memcpy(out, &h, sizeof h);
@@ -1562,7 +1601,9 @@ int cuhe_hip_relin_import(const void *src, size_t bytes) {
     for (int dev = 0; dev < G_.ndev; ++dev) {
         CHK(set_dev(dev));
         DevCtx &D = G_.dev[dev];
+        if (D.ek && (D.ek_first != 0 || D.ek_count != G_.prm.numCrtPrime)) { hipFree(D.ek); D.ek = nullptr; }     // a partial set: re-allocate
         if (!D.ek) HIPCHK(hipMalloc((void **)&D.ek, h.payload_bytes));
+        D.ek_first = 0; D.ek_count = G_.prm.numCrtPrime;
         if (D.ekd) { hipFree(D.ekd); D.ekd = nullptr; }
         D.ekd_unavailable = false;
         HIPCHK(hipMemcpy(D.ek, payload, h.payload_bytes, hipMemcpyHostToDevice));
@@ -1590,7 +1631,9 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     // primes per workgroup (each window value fetched from cache serves PB key streams): as many as still leave ~6
     // workgroups per CU -- the kernel streams the keys from HBM and needs that many loads in flight (12 waves per CU reach
     // 4.3 TB/s, 24 reach 6 TB/s: profiles/r02_experiments_log.txt)
-    const u64 *ekp = D.ek + (size_t)prime0 * q.numEvalKey * L;
+    if (prime0 < D.ek_first || prime0 + count > D.ek_first + D.ek_count)
+        return fail(CUHE_EINVAL, "keys of primes [%d, %d) wanted, device %d holds [%d, %d)", prime0, prime0 + count, dev, D.ek_first, D.ek_first + D.ek_count);
+    const u64 *ekp = D.ek + (size_t)(prime0 - D.ek_first) * q.numEvalKey * L;
     const long target = 6L * 256;
     auto blocks = [&](int pb) { return (long)(L / 512) * ((count + pb - 1) / pb); };
     if (blocks(4) >= target || count <= 1)
@@ -1633,6 +1676,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
     hipStream_t st = S(st_);
     DevCtx &D = G_.dev[dev];
+    CHK(need_all_keys(D));
     const int np = q.numCrtPrimeAt(lvl), k = q.numEvalKeyAt(lvl), W = q.wordsCoeff(lvl), L = ct_len(), cl = q.crtLen;
     const int rows = batch * np;
     Workspace *Wp = nullptr;
@@ -1713,8 +1757,8 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
 // the inner-product kernel places the ciphertext groups of one column tile next to each other on one XCD (a key value
 // then leaves HBM once per BATCH, not once per group) one launch sequence over the whole batch is faster on every ring
 // measured (profiles/r02_relin_lanes_ab.txt), so the default is 1 lane; cuhe_hip_set_relin_lanes(n) still selects more.
-static int g_relin_lanes = 1;
-static bool g_relin_lanes_any_size = false;          // -n: n lanes whatever the ring size (tests)
+static int g_relin_lanes = getenv("CUHE_RELIN_LANES") ? atoi(getenv("CUHE_RELIN_LANES")) : 1;
+static bool g_relin_lanes_any_size = getenv("CUHE_RELIN_LANES") != nullptr;          // -n: n lanes whatever the ring size (tests)
 int cuhe_hip_set_relin_lanes(int n) {
     const int m = n < 0 ? -n : n;
     if (m < 1 || m > kLanes) return fail(CUHE_EINVAL, "lanes %d (1..%d)", n, kLanes);
@@ -1722,9 +1766,12 @@ int cuhe_hip_set_relin_lanes(int n) {
     return CUHE_OK;
 }
 static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b, const uint32_t *crt_in, int lvl, int batch, int dev, void *st_) {
-    constexpr int GB = 4;
-    const int groups = (batch + GB - 1) / GB, lanes = std::min(g_relin_lanes, groups);
+    // a group is what one launch sequence handles: 16 ciphertexts (one tile of the matrix-core inner product) when that
+    // kernel will run, 4 (one window tile of the VALU kernel) otherwise
     const Params &q = G_.prm;
+    const bool mfma = g_mac_mfma_min > 0 && batch >= 2 * kMacMfmaCts && G_.inited && mac_mfma_supported(q.numEvalKey);
+    const int GB = mfma ? kMacMfmaCts : 4;
+    const int groups = (batch + GB - 1) / GB, lanes = std::min(g_relin_lanes, groups);
     if (lanes <= 1 || !G_.inited || lvl < 0 || lvl >= q.depth ||
         (!g_relin_lanes_any_size && (size_t)q.numEvalKeyAt(lvl) * q.numCrtPrimeAt(lvl) * ct_len() * sizeof(u64) < ((size_t)1 << 30)))
         return relin_batch_run(dst, a, b, crt_in, lvl, batch, dev, st_);
@@ -1734,6 +1781,7 @@ static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b,
     Workspace *W0 = nullptr, *LW[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     CHK(workspace(dev, st, &W0));
     if (!W0->ev_in) HIPCHK(hipEventCreateWithFlags(&W0->ev_in, hipEventDisableTiming));
+    if (mfma) CHK(ensure_key_digits(dev, st));                     // built once, on the caller's stream, before any lane can want it
     HIPCHK(hipEventRecord(W0->ev_in, st));                         // whatever produced the operands on `st` is before this
     LaneReset reset;
     for (int g = 0; g < groups; ++g) {
@@ -2028,6 +2076,10 @@ int cuhe_hip_mul_relin_sharded_inproc(uint32_t *dst, const uint64_t *a, const ui
     const int nd = G_.ndev, np = q.numCrtPrimeAt(lvl), cl = q.crtLen;
     const size_t Lc = ct_len();
     if (np < nd) return fail(CUHE_EINVAL, "%d primes at level %d cannot be split over %d devices", np, lvl, nd);
+    // the helper stream and the two stage events are per DEVICE, not per host thread: concurrent callers enqueue one after
+    // the other (the enqueue is short; the work of successive calls still overlaps on the devices' streams)
+    static std::mutex enqueue_mu;
+    std::lock_guard<std::mutex> enqueue_lock(enqueue_mu);
     hipStream_t st0 = S(st_);
     std::vector<Workspace *> W(nd, nullptr);
     std::vector<hipStream_t> sd(nd, nullptr);

@@ -174,6 +174,17 @@ int cuhe_hip_intt_one(uint32_t *x, const uint64_t *X, int crtidx, int dev, void 
 /* initRelinearization: evalkey = numEvalKey polynomials in raw layout at level 0,
  * HOST memory u32[numEvalKey][rawLen][W0]; keys are converted once and stay in HBM. */
 int cuhe_hip_init_relin(const uint32_t *evalkey_raw_host);
+/* The same for the keys of the CRT primes [prime0, prime0 + count) only: what ONE participant of the CRT-prime-sharded
+ * multiply needs (the evaluation keys are partitioned with the primes; key memory / participants).
+ * cuhe_hip_key_range gives the range that covers a participant's block at every level (its contiguous block moves down
+ * as the levels drop primes).  Entry points that need every prime's keys (cuhe_hip_relinearization over a whole level,
+ * the batched calls, the key cache) fail with a message on such a device; cuhe_hip_relin_range and
+ * cuhe_hip_mul_relin_sharded work on the owned primes.  cuhe_hip_init_relin_sharded: device d of multiGPUs(n) keeps
+ * the range of participant d (for cuhe_hip_mul_relin_sharded_inproc).  Replaces Relinearization.cu:43-75 like
+ * cuhe_hip_init_relin. */
+int cuhe_hip_init_relin_range(const uint32_t *evalkey_raw_host, int prime0, int count);
+int cuhe_hip_key_range(int nranks, int rank, int *first, int *count);
+int cuhe_hip_init_relin_sharded(const uint32_t *evalkey_raw_host);
 /* relinearization(dst, src, lvl, dev, st) (Relinearization.cu:76-88): src raw, dst in the ct domain u64[np][ct_len]
  * (the keys are kept in the ct domain only; the reference's sole consumer of dst is n2c, CuHE.cu:570-581) */
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *stream);
@@ -250,7 +261,8 @@ int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *stream);
 int cuhe_hip_mul_relin_sharded(uint32_t *dst_own, const uint64_t *a_own, const uint64_t *b_own, int lvl, int dev, void *stream);
 /* (2) one process driving the multiGPUs(n) devices: a, b = ct rows of all primes on device dev0, dst = reduced CRT rows
  *     of all primes on dev0; rows travel by peer copies over xGMI ordered by events, each device on its own stream; the
- *     caller's stream continues when every device is done. */
+ *     caller's stream continues when every device is done.  Host threads may call it concurrently: the enqueue is
+ *     serialised inside (the helper streams and stage events are per device), the enqueued work still overlaps. */
 int cuhe_hip_mul_relin_sharded_inproc(uint32_t *dst, const uint64_t *a, const uint64_t *b, int lvl, int dev0, void *stream);
 
 /* ---- batched transform primitives (the shape tests/test_ntt.cu:67-100 times):

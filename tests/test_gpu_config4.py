@@ -1,0 +1,182 @@
+"""-m gpu: BASELINE config 4 at FULL size (48 CRT primes, 72 / 69 evaluation keys of 16-bit windows) pinned by exact integers
+that do not come from the oracle:
+
+ * the batched key switch on the matrix cores (cuhe_hip_relin_batch -> k_relin_mac_mfma<1,32>: three 16-prime tiles, a
+   full ciphertext tile and a partial one) for 21 DISTINCT ciphertexts, every ciphertext, every prime, every coefficient;
+ * the CRT-prime-sharded multiply + relinearise (cuhe_hip_mul_relin_sharded_inproc) over 2, 4, 5 and 8 virtual devices
+   (5: unequal blocks), every device holding the keys of its own primes only (cuhe_hip_init_relin_sharded);
+ * the 2-rank launch of bench.py (gloo, both ranks on the one GPU): its N > 1 legs run and report no error.
+
+With evaluation keys ek_j = s * 2^(w j) mod q0 the key-switch sum  sum_j window_j(c) * ek_j  equals  c * s  modulo x^n + 1 and
+q (the windows recompose c); q is the product of the level's primes, so the residue of the result modulo a prime p is
+(c * s mod x^n + 1) mod p -- for a sparse s a few negacyclic shifts of the residue rows, exact in 64-bit numpy arithmetic.
+Reference: cuhe/Relinearization.cu:43-88, cuhe/CuHE.cu:101,570-581 (the chain), cuhe/CuHE.cu:217-256 (devices)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RINGS = {"x^32768+1": (25, 2, 16, 576, 24, 65536), "x^65536+1": (25, 2, 16, 552, 23, 131072)}
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X (no CPU fallback exists for the HIP path)")
+    import gpu_util
+    return gpu_util
+
+
+def sparse_terms(n, q0, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(e), int.from_bytes(rng.bytes(150), "little") % q0) for e in (0, 1, 777, 20011, n - 1)]          # s = sum v x^e
+
+
+def structured_keys(terms, K, w, q0, raw_len, W0):
+    ek = np.zeros((K, raw_len, W0), dtype=np.uint32)
+    for j in range(K):
+        for e, v in terms:
+            ek[j, e] = np.frombuffer(((v << (w * j)) % q0).to_bytes(4 * W0, "little"), dtype=np.uint32)
+    return ek
+
+
+def negacyclic_times_sparse(rows, terms, primes, n):
+    """rows u32[np][>= n] residues of c; returns the residues of c * s mod (x^n + 1), s = sum v x^e, as u64[np][n]"""
+    out = np.zeros((len(primes), n), dtype=np.uint64)
+    for t, p in enumerate(primes):
+        c = rows[t, :n].astype(np.uint64)
+        acc = np.zeros(n, dtype=np.uint64)
+        for e, v in terms:
+            vp = np.uint64(v % p)
+            sh = np.concatenate(((np.uint64(p) - c[n - e:]) % np.uint64(p), c[:n - e])) if e else c      # x^e c: the wrapped part changes sign
+            acc = (acc + sh * vp) % np.uint64(p)                                                            # < 2^24 * 2^24 + 2^24
+        out[t] = acc
+    return out
+
+
+@pytest.mark.parametrize("ring", list(RINGS))
+def test_batched_key_switch_21_distinct_ciphertexts_vs_integers(gu, ring):
+    lib, ck = gu.lib, gu.ck
+    g = gu.GpuCtx(*RINGS[ring])
+    try:
+        q = g.prm
+        n, K, W0, q0 = q.modLen, q.numEvalKey, g.words(0), g.coeff_modulus(0)
+        assert q.numCrtPrime == 48 and K in (72, 69)
+        primes = g.crt_primes()
+        terms = sparse_terms(n, q0, 11)
+        g.init_relin(structured_keys(terms, K, q.logRelin, q0, q.rawLen, W0))
+        B = 21
+        for lvl in (0, 3):
+            npr = g.np_(lvl)
+            rng = np.random.default_rng(100 + lvl)
+            src = np.zeros((B, npr, q.crtLen), dtype=np.uint32)
+            for t in range(npr):
+                src[:, t, :n] = rng.integers(0, primes[t], (B, n), dtype=np.uint32)
+            src[0, :, :n] = 0                                   # edge rows: zero, all p - 1, a single non-zero coefficient
+            for t in range(npr):
+                src[1, t, :n] = primes[t] - 1
+            src[2, :, :n] = 0; src[2, :, n - 1] = 1
+            d_src = gu.to_dev(src.reshape(B * npr, q.crtLen))
+            d_dst = gu.empty_u32(B * npr, q.crtLen)
+            ck(lib.cuhe_hip_set_relin_mfma(5))                  # the matrix-core kernel from 5 ciphertexts on (the default)
+            ck(lib.cuhe_hip_relin_batch(d_dst.data_ptr(), d_src.data_ptr(), lvl, B, 0, None))
+            got = gu.host_u32(d_dst).reshape(B, npr, q.crtLen)
+            for b in range(B):
+                want = negacyclic_times_sparse(src[b], terms, primes[:npr], n)
+                assert np.array_equal(got[b, :, :n].astype(np.uint64), want), (ring, lvl, b)
+            # the same rows through the VALU kernels (matrix cores off): bit-identical
+            ck(lib.cuhe_hip_set_relin_mfma(0))
+            d_dst2 = gu.empty_u32(B * npr, q.crtLen)
+            ck(lib.cuhe_hip_relin_batch(d_dst2.data_ptr(), d_src.data_ptr(), lvl, B, 0, None))
+            assert np.array_equal(gu.host_u32(d_dst2).reshape(B, npr, q.crtLen), got), (ring, lvl)
+            ck(lib.cuhe_hip_set_relin_mfma(5))
+    finally:
+        lib.cuhe_hip_set_relin_mfma(5)
+        g.close()
+
+
+def test_sharded_multiply_at_config4_size_on_2_4_5_8_virtual_devices(gu):
+    """a * b with a sparse b (so that the product is exact in numpy), then the key switch: residues of a * b * s."""
+    lib, ck = gu.lib, gu.ck
+    args = RINGS["x^32768+1"]
+    try:
+        for ndev in (2, 4, 5, 8):
+            lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+            ck(lib.cuhe_hip_set_virtual_devices(1))
+            ck(lib.cuhe_hip_set_parameters(*args))
+            ck(lib.cuhe_hip_multi_gpus(ndev))
+            ck(lib.cuhe_hip_init(None, 0))
+            q = gu.capi.get_params()
+            n, K = q.modLen, q.numEvalKey
+            W0 = lib.cuhe_hip_words_coeff(0)
+            buf = (ctypes.c_uint8 * 4096)(); ln = ctypes.c_size_t(0)
+            ck(lib.cuhe_hip_get_coeff_modulus(0, buf, 4096, ctypes.byref(ln)))
+            q0 = int.from_bytes(bytes(buf[:ln.value]), "little")
+            pr = (ctypes.c_uint32 * q.numCrtPrime)()
+            ck(lib.cuhe_hip_get_crt_primes(pr, q.numCrtPrime))
+            primes = [int(x) for x in pr]
+            terms = sparse_terms(n, q0, 12)
+            ek = np.ascontiguousarray(structured_keys(terms, K, q.logRelin, q0, q.rawLen, W0))
+            ck(lib.cuhe_hip_init_relin_sharded(ek.ctypes.data_as(ctypes.c_void_p)))        # device d: the keys of its primes only
+            f, c = ctypes.c_int(), ctypes.c_int()
+            held = 0
+            for d in range(ndev):
+                ck(lib.cuhe_hip_key_range(ndev, d, ctypes.byref(f), ctypes.byref(c)))
+                held += c.value
+            assert held <= q.numCrtPrime + (q.depth - 1) * (ndev - 1), (ndev, held)          # ~1/ndev each (blocks overlap by the level drift only)
+            bterms = [(0, 3), (5, 1), (n - 2, 7)]
+            ctlen = lib.cuhe_hip_ct_len()
+            for lvl in (0, 4):
+                npr, logq = lib.cuhe_hip_num_crt_prime(lvl), lib.cuhe_hip_log_coeff(lvl)
+                rng = np.random.default_rng(200 + lvl + ndev)
+                a = np.zeros((npr, q.crtLen), dtype=np.uint32)
+                b = np.zeros((npr, q.crtLen), dtype=np.uint32)
+                for t in range(npr):
+                    a[t, :n] = rng.integers(0, primes[t], n, dtype=np.uint32)
+                    for e, v in bterms:
+                        b[t, e] = v
+                ab = negacyclic_times_sparse(a, bterms, primes[:npr], n)
+                want = negacyclic_times_sparse(ab.astype(np.uint32), terms, primes[:npr], n)
+                for dev0 in (0, ndev - 1):
+                    na, nb = gu.empty_u64(npr, ctlen), gu.empty_u64(npr, ctlen)
+                    ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), gu.to_dev(a).data_ptr(), logq, dev0, None))
+                    ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), gu.to_dev(b).data_ptr(), logq, dev0, None))
+                    out = gu.empty_u32(npr, q.crtLen)
+                    for rep in range(2):
+                        out.zero_()
+                        ck(lib.cuhe_hip_mul_relin_sharded_inproc(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, dev0, None))
+                        ck(lib.cuhe_hip_stream_sync(dev0, None))
+                        assert np.array_equal(gu.host_u32(out)[:, :n].astype(np.uint64), want), (ndev, lvl, dev0, rep)
+            # an entry point that needs EVERY prime's keys says so on a device that holds a part of them
+            raw = gu.empty_u32(q.rawLen, W0)
+            acc = gu.empty_u64(q.numCrtPrime, ctlen)
+            assert lib.cuhe_hip_relinearization(acc.data_ptr(), raw.data_ptr(), 0, 0, None) != 0
+            assert b"holds" in lib.cuhe_hip_last_error()
+    finally:
+        lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_virtual_devices(0); lib.cuhe_hip_multi_gpus(1)
+
+
+def test_bench_two_ranks_on_one_gpu_runs_every_leg():
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --dist-backend gloo with both ranks on GPU 0:
+    the N > 1 legs (sharded multiply with its exchange, replicated multiplies, PRINCE over two devices) complete."""
+    env = dict(os.environ, CUHE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--batch", "1024"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2
+    for leg in ("mul_relin_sharded", "mul_relin_replicated", "prince"):
+        assert d.get(leg) and "error" not in d[leg], (leg, d.get(leg))
+    sh = d["mul_relin_sharded"]
+    assert sh["primes_per_rank"] == 24 and sh["key_primes_per_rank"] <= 30 and 0 < sh["serial_fraction"] < 1
+    assert d["prince"]["known_answer_ok"] is True
