@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--no-mulrelin", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="transforms in the CPU baseline sample (0 = auto)")
-    ap.add_argument("--ring", choices=list(RING_PARAMS), default="2^15",
+    ap.add_argument("--ring", choices=list(RING_PARAMS), default="2^16",
                     help="ciphertext mul+relin leg: x^32768+1 (the reference's largest ring, 64K-point cyclic or 32K-point negacyclic "
                          "transforms) or x^65536+1 (BASELINE config 4 read literally: 64K-point negacyclic transforms, 23-bit primes); "
                          "the other ring is reported beside it unless --one-ring")
@@ -218,9 +218,29 @@ def main():
             # the limiter that actually binds: integer VALU issue under the chip's power limit.  Dense
             # streams of these instructions saturate near 36.5 T lane-instructions/s (profiles/r02_valu_cost_model.txt)
             got = n_tr * lane_instr / pair_s / 1e12
+            ceil_t = rec.get("dense_stream_ceiling_T_per_s")        # measured figure, carried by the same hash-guarded record
             roofline["valu_ceiling"] = {"lane_instructions_per_transform": lane_instr, "achieved_T_per_s": round(got, 2),
-                                        "dense_stream_ceiling_T_per_s": 36.5, "frac_of_dense_stream_ceiling": round(got / 36.5, 3),
-                                        "note": "ceiling = pure v_lshl_add_u64 / v_mad_u64_u32 / v_cmp_u64 streams at 4 waves per SIMD (power-limited clock)"}
+                                        "dense_stream_ceiling_T_per_s": ceil_t, "frac_of_dense_stream_ceiling": round(got / ceil_t, 3) if ceil_t else None,
+                                        "note": "ceiling = pure v_lshl_add_u64 / v_mad_u64_u32 / v_cmp_u64 streams at 4 waves per SIMD (profiles/r02_valu_cost_model.txt)"}
+
+        # ---- the shorter zero-padded transforms of the reference contract (cuhe/Base.cu:309-437, 492-608): same bytes per step
+        # as the 64K-point batch.  Their sub-transforms of 16K / 8K points run in the one-workgroup form (ntt_onewg.cuh)
+        other_lengths = {}
+        if L == 65536:
+            for L2 in (32768, 16384):
+                try:
+                    B2 = B * (L // L2)
+                    ck(lib.cuhe_hip_ntt_prepare(L2, 0))
+                    s2 = src.view(-1)[:B2 * (L2 // 2)].view(B2, L2 // 2)
+                    d2 = dst.view(-1)[:B2 * L2].view(B2, L2)
+                    a1, a2, at = C.c_float(0), C.c_float(0), C.c_float(0)
+                    ck(lib.cuhe_hip_time_ntt_fwd(d2.data_ptr(), s2.data_ptr(), L2, B2, 3, 0, None, C.byref(a1), C.byref(a2), C.byref(at)))
+                    per = at.value * 1e-3 / (3 * B2)
+                    other_lengths[str(L2)] = {"value": round(1.0 / per, 1), "unit": "NTT/s", "batch": B2, "frac": round(10 * L2 / per / 1e9 / HBM_PEAK_GBS, 4),
+                                              "kernel": "ntt_onewg<%d, zero-padded halves> (one launch)" % (13 if L2 == 16384 else 14)}
+                except Exception as ex:
+                    other_lengths[str(L2)] = {"error": repr(ex)[:200]}
+        roofline["other_lengths"] = other_lengths
 
         # measured device-to-device copy ceiling of this box: 1 GiB read + 1 GiB written per copy
         ca = torch.empty(1 << 28, dtype=torch.int32, device=dev); cb = torch.empty_like(ca)
@@ -502,19 +522,27 @@ def bench_mul_full(lib, ck, torch, np, dev, with_cpu=True, batch=16, cyclic=Fals
     batched = None
     try:
         B = batch
-        rab = ra.repeat(B, 1).contiguous(); rbb = rb.repeat(B, 1).contiguous()
+        # B DISTINCT operand pairs; every result row is compared with the single chain on the same pair
+        rab = torch.randint(-(1 << 31), (1 << 31) - 1, (B * q.rawLen, W), dtype=torch.int32, device=dev, generator=gen)
+        rbb = torch.randint(-(1 << 31), (1 << 31) - 1, (B * q.rawLen, W), dtype=torch.int32, device=dev, generator=gen)
         outb = torch.empty((B * q.rawLen, W), dtype=torch.int32, device=dev)
         for _ in range(2):
             ck(lib.cuhe_hip_mul_raw_batch(outb.data_ptr(), rab.data_ptr(), rbb.data_ptr(), 0, B, 0, None))
         torch.cuda.synchronize()
-        assert torch.equal(outb[:q.rawLen], out) and torch.equal(outb[(B - 1) * q.rawLen:], out), "batched result differs from the single chain"
+        keep_a, keep_b = ra.clone(), rb.clone()
+        for i in range(B):
+            ra.copy_(rab[i * q.rawLen:(i + 1) * q.rawLen]); rb.copy_(rbb[i * q.rawLen:(i + 1) * q.rawLen])
+            one()
+            assert torch.equal(outb[i * q.rawLen:(i + 1) * q.rawLen], out), "batched result %d differs from the single chain" % i
+        ra.copy_(keep_a); rb.copy_(keep_b); one(); torch.cuda.synchronize()
         breps = max(3, 64 // B)
         t0 = time.perf_counter()
         for _ in range(breps):
             ck(lib.cuhe_hip_mul_raw_batch(outb.data_ptr(), rab.data_ptr(), rbb.data_ptr(), 0, B, 0, None))
         torch.cuda.synchronize()
         bdt = (time.perf_counter() - t0) / breps / B
-        batched = {"value": round(1.0 / bdt, 1), "unit": "full multiplies/s (raw -> raw)", "ms_per_multiply": round(bdt * 1e3, 4), "batch": B}
+        batched = {"value": round(1.0 / bdt, 1), "unit": "full multiplies/s (raw -> raw)", "ms_per_multiply": round(bdt * 1e3, 4), "batch": B,
+                   "checked": "%d distinct operand pairs, every result equal to the single chain" % B}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_negacyclic(-1)
@@ -602,12 +630,25 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
     batched = None
     try:
         B = args.relin_batch
-        nab = na.repeat(B, 1).contiguous(); nbb = nb.repeat(B, 1).contiguous()
+        # B DISTINCT ciphertext pairs; every result row is compared with the single chain on the same pair
+        ab = torch.randint(0, 1 << (q.logCrtPrime - 1), (B * npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+        bb = torch.randint(0, 1 << (q.logCrtPrime - 1), (B * npn, q.crtLen), dtype=torch.int32, device=dev, generator=gen)
+        nab = torch.empty((B * npn, L), dtype=torch.int64, device=dev); nbb = torch.empty_like(nab)
+        for i in range(B):
+            ck(lib.cuhe_hip_ct_ntt(nab[i * npn:].data_ptr(), ab[i * npn:].data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ct_ntt(nbb[i * npn:].data_ptr(), bb[i * npn:].data_ptr(), logq, 0, None))
         out = torch.empty((B * npn, q.crtLen), dtype=torch.int32, device=dev)
         for _ in range(2):
             ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), nab.data_ptr(), nbb.data_ptr(), 0, B, 0, None))
         torch.cuda.synchronize()
-        assert torch.equal(out[:npn], cr) and torch.equal(out[(B - 1) * npn:], cr), "batched result differs from the single chain"
+        keep_a, keep_b = na.clone(), nb.clone()
+        singles = []
+        for i in range(B):
+            na.copy_(nab[i * npn:(i + 1) * npn]); nb.copy_(nbb[i * npn:(i + 1) * npn])
+            one()
+            singles.append(cr.clone())
+            assert torch.equal(out[i * npn:(i + 1) * npn], cr), "batched result %d differs from the single chain" % i
+        na.copy_(keep_a); nb.copy_(keep_b); one(); torch.cuda.synchronize()
         breps = max(6, 40 // B)
         t0 = time.perf_counter()
         for _ in range(breps):
@@ -619,6 +660,7 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
         batched = {"value": round(1.0 / bdt, 2), "unit": "mul+relin/s", "ms_per_ciphertext": round(bdt * 1e3, 4), "batch": B,
                    "key_bytes_per_ciphertext": key_bytes // min(B, 16),
                    "algorithmic_bytes_per_ciphertext": int(alg), "frac_hbm": round(alg / bdt / 1e9 / HBM_PEAK_GBS, 4),
+                   "checked": "%d distinct ciphertext pairs, every result equal to the single chain" % B,
                    "note": "B independent chains per call on one stream; products formed on load by the inverse transforms; key-switch inner product on the matrix cores (int8 MFMA over signed base-256 digits) in tiles of 16 ciphertexts"}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
@@ -631,12 +673,13 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
         bufs = []
         for _ in range(T):
             st = C.c_void_p(); ck(lib.cuhe_hip_stream_create(0, C.byref(st)))
-            bufs.append((st, na.repeat(Bc, 1).contiguous(), nb.repeat(Bc, 1).contiguous(),
-                         torch.empty((Bc * npn, q.crtLen), dtype=torch.int32, device=dev)))
+            lo = (len(bufs) * Bc) % max(1, B - Bc + 1)                      # a different slice of the distinct pairs per thread
+            bufs.append((st, nab[lo * npn:(lo + Bc) * npn].contiguous(), nbb[lo * npn:(lo + Bc) * npn].contiguous(),
+                         torch.empty((Bc * npn, q.crtLen), dtype=torch.int32, device=dev), lo))
         torch.cuda.synchronize()
 
         def work(t, n):
-            st, x, y, o = bufs[t]
+            st, x, y, o, _ = bufs[t]
             for _ in range(n):
                 ck(lib.cuhe_hip_mul_relin_batch(o.data_ptr(), x.data_ptr(), y.data_ptr(), 0, Bc, 0, st))
             ck(lib.cuhe_hip_stream_sync(0, st))
@@ -649,7 +692,9 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
         for x in th:
             x.join()
         cdt = (time.perf_counter() - t0) / (T * Bc * creps)
-        assert all(torch.equal(bf[3][:npn], cr) and torch.equal(bf[3][(Bc - 1) * npn:], cr) for bf in bufs), "concurrent result differs from the single chain"
+        for bf in bufs:
+            for i in range(Bc):
+                assert torch.equal(bf[3][i * npn:(i + 1) * npn], singles[bf[4] + i]), "concurrent result differs from the single chain"
         for bf in bufs:
             ck(lib.cuhe_hip_stream_destroy(0, bf[0]))
         concurrent = {"value": round(1.0 / cdt, 2), "unit": "mul+relin/s", "ms_per_ciphertext": round(cdt * 1e3, 4), "host_threads": T, "batch": Bc,

@@ -1054,6 +1054,7 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
     return CUHE_OK;
 }
 
+int cuhe_hip_is_initialised(void) { return G_.inited ? 1 : 0; }
 int cuhe_hip_shutdown(void) {
     std::lock_guard<std::mutex> lk(G_.mu);
     for (int d = 0; d < (int)G_.dev.size(); ++d) {

@@ -97,17 +97,63 @@ static void *devAlloc(int dev, size_t bytes, cudaStream_t st = 0) {
 // ------------------------------------------------------------------ Operations.h drivers
 static vector<ZZ> coeffModuli;
 void getCoeffModuli(ZZ *dst) { for (int i = 0; i < param.depth; i++) dst[i] = coeffModuli[i]; }
-void initCrt(ZZ *coeffModulus) { getCoeffModuli(coeffModulus); }
+// The pre-computation entry points of Operations.h.  initCuHE composes them in the reference (cuhe/CuHE.cu:36-50:
+// initNtt ; initCrt ; initBarrett); here the C-ABI library does the whole set-up in cuhe_hip_init, so a client that
+// composes them ITSELF gets the same end state: initCrt initialises the library on the ring's cyclotomic polynomial
+// if nothing has yet (the CRT primes and coefficient moduli depend on the parameters only), initBarrett installs the
+// polynomial modulus it is given (a second initialisation if initCrt had to guess), initNtt has nothing left to do (the
+// transform tables are made by cuhe_hip_init and on first use).  The gen* / set* helpers of cuhe/Operations.cu:37-160
+// produced host-side tables that live inside the library now: called on an initialised library they are no-ops,
+// called before any initialisation they stop the program with a message, like every misuse in this API.
+static bool initialisedByParts = false;
+static void loadCoeffModuli() {
+	coeffModuli.assign(param.depth, ZZ());
+	vector<uint8> buf(4096);
+	for (int lvl = 0; lvl < param.depth; lvl++) {
+		size_t n = 0;
+		CSC(cuhe_hip_get_coeff_modulus(lvl, buf.data(), buf.size(), &n));
+		coeffModuli[lvl] = ZZFromBytes(buf.data(), (long)n);
+	}
+}
+static void installModulus(const ZZX &modulus) {
+	// polynomial modulus as small signed integers, low to high, monic of degree modLen
+	vector<int32_t> mod(param.modLen + 1, 0);
+	for (int i = 0; i <= param.modLen; i++) {
+		ZZ c = coeff(modulus, i);
+		long v; conv(v, c);
+		mod[i] = (int32_t)v;
+	}
+	if (cuhe_hip_is_initialised()) CSC(cuhe_hip_shutdown());
+	CSC(cuhe_hip_init(mod.data(), (int)mod.size()));
+	loadCoeffModuli();
+}
+static void requireInit(const char *fn) {
+	if (!cuhe_hip_is_initialised()) {
+		cout << "Error: " << fn << "() called before initCuHE / initCrt: the tables it stands for are made by the library's initialisation." << endl;
+		terminate();
+	}
+}
+void initCrt(ZZ *coeffModulus) {
+	if (!cuhe_hip_is_initialised()) {
+		CSC(cuhe_hip_init(NULL, 0));                   // the m-th cyclotomic polynomial until initBarrett names the modulus
+		loadCoeffModuli();
+		initialisedByParts = true;
+	}
+	getCoeffModuli(coeffModulus);
+}
 void initNtt() {}
-void initBarrett(ZZX) {}
-void loadIcrtConst(int, int, cudaStream_t) {}   // every level's constants stay resident (no re-upload, no sync)
-void genCrtPrimes() {}
-void genCoeffModuli() {}
-void genCrtInvPrimes() {}
-void genIcrtByLevel(int) {}
-void genIcrt() {}
-void setPolyModulus(ZZX) {}
-void createBarrettTemporySpace() {}
+void initBarrett(ZZX m) {
+	if (!cuhe_hip_is_initialised() || initialisedByParts) installModulus(m);
+	initialisedByParts = false;
+}
+void loadIcrtConst(int, int, cudaStream_t) { requireInit("loadIcrtConst"); }   // every level's constants stay resident (no re-upload, no sync)
+void genCrtPrimes() { requireInit("genCrtPrimes"); }
+void genCoeffModuli() { requireInit("genCoeffModuli"); }
+void genCrtInvPrimes() { requireInit("genCrtInvPrimes"); }
+void genIcrtByLevel(int) { requireInit("genIcrtByLevel"); }
+void genIcrt() { requireInit("genIcrt"); }
+void setPolyModulus(ZZX) { requireInit("setPolyModulus"); }
+void createBarrettTemporySpace() { requireInit("createBarrettTemporySpace"); }
 uint32 *inttResult(int dev) { return cuhe_hip_intt_result(dev); }
 
 #define U64P(p) ((uint64_t *)(p))
@@ -179,21 +225,9 @@ void stopAllocator() { haltDeviceAllocator(); }
 void initRelinearization(ZZX *evalkey) { initRelin(evalkey); }
 
 void initCuHE(ZZ *coeffMod_, ZZX modulus) {
-	// polynomial modulus as small signed integers, low to high, monic of degree modLen
-	vector<int32_t> mod(param.modLen + 1, 0);
-	for (int i = 0; i <= param.modLen; i++) {
-		ZZ c = coeff(modulus, i);
-		long v; conv(v, c);
-		mod[i] = (int32_t)v;
-	}
-	CSC(cuhe_hip_init(mod.data(), (int)mod.size()));
-	coeffModuli.assign(param.depth, ZZ());
-	vector<uint8> buf(4096);
-	for (int lvl = 0; lvl < param.depth; lvl++) {
-		size_t n = 0;
-		CSC(cuhe_hip_get_coeff_modulus(lvl, buf.data(), buf.size(), &n));
-		coeffModuli[lvl] = ZZFromBytes(buf.data(), (long)n);
-	}
+	initNtt();
+	installModulus(modulus);
+	initialisedByParts = false;
 	initCrt(coeffMod_);
 }
 

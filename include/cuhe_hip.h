@@ -78,6 +78,7 @@ int cuhe_hip_set_virtual_devices(int on);
  * modulus: monic integer polynomial, modLen+1 coefficients low-to-high
  * (NULL => the cyclotomic polynomial Phi_m).  Synchronous. */
 int cuhe_hip_init(const int32_t *modulus, int ncoeffs);
+int cuhe_hip_is_initialised(void);       /* 1 between a successful cuhe_hip_init and cuhe_hip_shutdown */
 int cuhe_hip_shutdown(void);
 /* coefficient modulus q_lvl as little-endian bytes (initCuHE's ZZ* output, Operations.cu:157-160) */
 int cuhe_hip_get_coeff_modulus(int lvl, uint8_t *le_bytes, size_t cap, size_t *len);

@@ -35,7 +35,22 @@ int main() {
 	ZZX phi = cyclotomic(m);
 	CHECK(deg(phi) == param.modLen, "cyclotomic degree");
 	std::vector<ZZ> q(d);
-	initCuHE(q.data(), phi);
+	// a client that composes the pre-computation itself, in the order of the reference's initCuHE (cuhe/CuHE.cu:47-49), with a
+	// modulus that is NOT the cyclotomic initCrt has to assume: x^480 + 1 here, then the real one through initCuHE below
+	{
+		ZZX other; SetCoeff(other, param.modLen, 1); SetCoeff(other, 0, 1);
+		std::vector<ZZ> q2(d);
+		initNtt();
+		initCrt(q2.data());
+		initBarrett(other);
+		const int n2 = param.modLen;
+		ZZX a = randomPoly(n2, q2[0]), b = randomPoly(n2, q2[0]), c;
+		mulZZX(c, a, b, 0, 0);
+		CHECK(c == hostMul(a, b, other, q2[0], n2), "initNtt ; initCrt ; initBarrett composed by the client: mulZZX modulo the modulus given to initBarrett");
+		genCrtPrimes(); genIcrt(); loadIcrtConst(0, 0);          // no-ops on an initialised library
+		initCuHE(q.data(), phi);
+		CHECK(q2[0] == q[0] && q2[d - 1] == q[d - 1], "initCrt alone returns the coefficient moduli initCuHE returns");
+	}
 	const int n = param.modLen;
 	bool chain = true;
 	for (int i = 0; i < d; ++i) chain = chain && NumBits(q[i]) <= param._logCoeff(i) && (i == 0 || (q[i - 1] % q[i] == to_ZZ(0) && q[i] < q[i - 1]));

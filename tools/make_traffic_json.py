@@ -35,5 +35,7 @@ rec = {"source": "profiles/%s_ntt64k_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE
        "kernel_sha16": h.hexdigest()[:16], "transform_len": L, "transforms_per_launch_pair": PER_LAUNCH,
        "bytes_per_launch_pair": int(bytes_pair), "bytes_per_transform": int(bytes_pair / PER_LAUNCH),
        "valu_lane_instructions_per_point": {"pass1": round(lane(p1), 2), "pass2": round(lane(p2), 2)},
-       "valu_lane_instructions_per_transform": int((lane(p1) + lane(p2)) * L)}
+       "valu_lane_instructions_per_transform": int((lane(p1) + lane(p2)) * L),
+       # issue rate of dense streams of the instructions the field arithmetic lowers to (tools/ubench_rates.hip, 4 waves per SIMD)
+       "dense_stream_ceiling_T_per_s": 36.5, "dense_stream_ceiling_source": "profiles/r02_valu_cost_model.txt"}
 print(json.dumps(rec, indent=1))
