@@ -128,6 +128,7 @@ SIGNATURES = {
     "cuhe_hip_key_range": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
     "cuhe_hip_init_relin_sharded": (i32, [vp]),
     "cuhe_hip_is_initialised": (i32, []),
+    "cuhe_hip_ct_prod_headroom": (i32, []),
     "cuhe_hip_shard_bounds": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
     "cuhe_hip_comm_unique_id": (i32, [vp]),
     "cuhe_hip_comm_init": (i32, [i32, i32, vp]),

@@ -883,7 +883,13 @@ void shl_dispatch(int l, uint64_t *z, const uint64_t *x, size_t n, hipStream_t s
 }
 
 // ---- key-switch inner product on the matrix cores: key digits, launch
-bool mac_mfma_supported(int K) { return K >= 1 && K <= 128; }          // at most two K steps are instantiated
+// at most two K steps are instantiated, and the window tile of a workgroup (8 columns x 16 ciphertexts x max(keys, padded
+// primes) words) has to fit the LDS: beyond that (levels with more than 144 primes) the VALU kernels serve
+bool mac_mfma_supported(int K, int k_lvl = 0, int np_lvl = 0) {
+    const int JS = (k_lvl + 2) & ~1, NPAD = ((np_lvl + 15) / 16) * 16;
+    const size_t lds = (size_t)kMacMfmaCols * (kMacMfmaCts * std::max(JS, NPAD) + 1) * sizeof(u64);
+    return K >= 1 && K <= 128 && lds <= 160 * 1024;
+}
 int need_all_keys(const DevCtx &D) {
     if (D.ek_first != 0 || D.ek_count != G_.prm.numCrtPrime)
         return fail(CUHE_EINVAL, "this device holds the keys of primes [%d, %d) only (cuhe_hip_init_relin_range): the call needs all %d", D.ek_first, D.ek_first + D.ek_count, G_.prm.numCrtPrime);
@@ -1414,6 +1420,16 @@ int cuhe_hip_set_negacyclic(int mode) {
     G_.nc_mode = mode;
     return CUHE_OK;
 }
+// products of two reduced polynomials whose SUM the inverse ct transform still recovers exactly: the integer coefficients of
+// a product are below n p^2 in magnitude and must stay below P (cyclic) / P/2 (negacyclic: centred lift)
+int cuhe_hip_ct_prod_headroom(void) {
+    if (!G_.inited) return 0;
+    host::u128 pmax = 0;
+    for (uint32_t p : G_.primes) pmax = std::max<host::u128>(pmax, p);
+    const host::u128 one = (host::u128)G_.prm.modLen * (pmax - 1) * (pmax - 1) * (G_.nc ? 2 : 1);
+    const host::u128 h = one ? (host::u128)host::P / one : 1;
+    return h > 1000000 ? 1000000 : (int)h;
+}
 int cuhe_hip_ct_negacyclic(void) { return G_.inited && G_.nc ? 1 : 0; }
 int cuhe_hip_ct_len(void) { return G_.params_set ? (G_.inited ? ct_len() : G_.prm.nttLen) : 0; }
 int cuhe_hip_ct_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *st) {
@@ -1712,7 +1728,7 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     // Batches of >= g_mac_mfma_min ciphertexts: the products run on the matrix cores in groups of 16 ciphertexts
     // (k_relin_mac_mfma); a remainder below that size and small batches take the VALU kernel below.
     int done = 0;
-    if (g_mac_mfma_min > 0 && batch >= g_mac_mfma_min && mac_mfma_supported(q.numEvalKey) && (L % 64) == 0) {
+    if (g_mac_mfma_min > 0 && batch >= g_mac_mfma_min && mac_mfma_supported(q.numEvalKey, k, np) && (L % 64) == 0) {
         CHK(ensure_key_digits(dev, st));
         if (D.ekd) {
             const int rem = batch % kMacMfmaCts;
@@ -1770,7 +1786,8 @@ static int relin_batch_core(uint32_t *dst, const uint64_t *a, const uint64_t *b,
     // a group is what one launch sequence handles: 16 ciphertexts (one tile of the matrix-core inner product) when that
     // kernel will run, 4 (one window tile of the VALU kernel) otherwise
     const Params &q = G_.prm;
-    const bool mfma = g_mac_mfma_min > 0 && batch >= 2 * kMacMfmaCts && G_.inited && mac_mfma_supported(q.numEvalKey);
+    const bool mfma = g_mac_mfma_min > 0 && batch >= 2 * kMacMfmaCts && G_.inited && lvl >= 0 && lvl < q.depth &&
+                      mac_mfma_supported(q.numEvalKey, q.numEvalKeyAt(lvl), q.numCrtPrimeAt(lvl));
     const int GB = mfma ? kMacMfmaCts : 4;
     const int groups = (batch + GB - 1) / GB, lanes = std::min(g_relin_lanes, groups);
     if (lanes <= 1 || !G_.inited || lvl < 0 || lvl >= q.depth ||

@@ -234,19 +234,19 @@ void initCuHE(ZZ *coeffMod_, ZZX modulus) {
 // ------------------------------------------------------------------ CuPolynomial
 static void misuse(const char *msg) { cout << msg << endl; terminate(); }
 
-CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), rRep_(NULL), cRep_(NULL), nRep_(NULL), stream_(0) { clear(zRep_); }
+CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), prodTerms_(0), rRep_(NULL), cRep_(NULL), nRep_(NULL), stream_(0) { clear(zRep_); }
 CuPolynomial::~CuPolynomial() { reset(); }
 void CuPolynomial::reset() {
 	clear(zRep_);
 	if (rRep_ != NULL) rRepFree();
 	if (cRep_ != NULL) cRepFree();
 	if (nRep_ != NULL) nRepFree();
-	isProd_ = false; logq_ = -1; domain_ = -1; device_ = -1;
+	isProd_ = false; prodTerms_ = 0; logq_ = -1; domain_ = -1; device_ = -1;
 }
 void CuPolynomial::logq(int val) { logq_ = val; }
 void CuPolynomial::domain(int val) { domain_ = val; }
 void CuPolynomial::device(int val) { device_ = val; }
-void CuPolynomial::isProd(bool val) { isProd_ = val; }
+void CuPolynomial::isProd(bool val) { isProd_ = val; prodTerms_ = val ? (prodTerms_ > 0 ? prodTerms_ : 1) : 0; }
 void CuPolynomial::zRep(ZZX val) { zRep_ = std::move(val); }
 void CuPolynomial::rRep(uint32 *val) { rRep_ = val; }
 void CuPolynomial::cRep(uint32 *val) { cRep_ = val; }
@@ -480,7 +480,7 @@ void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	src.stream(st);
 	dst.reset();
 	dst.setLevelForOutput(src.level(), src.domain(), src.device(), st);
-	dst.isProd(src.isProd());
+	dst.isProd(src.isProd()); dst.prodTerms(src.prodTerms());
 	const int dev = dst.device();
 	if (dst.domain() == 0) dst.zRep(src.zRep());
 	else if (dst.domain() == 1) CSC(cuhe_hip_memcpy_d2d(dev, dst.rRep(), src.rRep(), dst.rRepSize(), st));
@@ -518,9 +518,26 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 		prepareOut(out, in0, 2, st);
 		crtAdd(out.cRep(), in0.cRep(), in1.cRep(), out.logq(), out.device(), st);
 	} else if (in0.domain() == 3 && in1.domain() == 3) {
-		const bool prod = in0.isProd() || in1.isProd();
-		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
-		CSC(cuhe_hip_ct_add(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
+		// A sum of products stays exact in the NTT domain only while its integer coefficients stay inside the range the
+		// inverse transform recovers (cuhe_hip_ct_prod_headroom products: ONE on the largest rings in the negacyclic
+		// representation, where 2 n p^2 is just below P).  Beyond that the operands are reduced first (n2c), added as
+		// residues and taken back (c2n): the reference's contract "NTT-domain in, NTT-domain out", always exact.
+		const int terms = in0.prodTerms() + in1.prodTerms();
+		if (in0.isProd() && in1.isProd() && terms > cuhe_hip_ct_prod_headroom()) {
+			GateScope chain;
+			CuCtxt a, b;
+			copy(a, in0, st); copy(b, in1, st);
+			a.x2c(st); b.x2c(st);
+			crtAdd(a.cRep(), a.cRep(), b.cRep(), a.logq(), a.device(), st);
+			a.x2n(st);
+			if (&out != &in0 && &out != &in1) { out.reset(); }
+			copy(out, a, st);
+		} else {
+			const bool prod = in0.isProd() || in1.isProd();
+			if (&out != &in0) { prepareOut(out, in0, 3, st); }
+			CSC(cuhe_hip_ct_add(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
+			out.isProd(prod); out.prodTerms(prod ? (terms > 0 ? terms : 1) : 0);
+		}
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
 	GATE_SYNC(out.device(), st);
 }

@@ -44,6 +44,8 @@ public:
 	int domain();
 	int device();
 	bool isProd();
+	int prodTerms() { return prodTerms_; }
+	void prodTerms(int n) { prodTerms_ = n; }
 	ZZX zRep();
 	void swapZRep(ZZX &other);       // (addition) exchange the host value without copying it
 	uint32 *rRep();
@@ -83,6 +85,7 @@ protected:
 	int domain_;
 	int device_;
 	bool isProd_;
+	int prodTerms_;                  // products summed into an NTT-domain value since it was last reduced (cXor keeps the sum exact)
 	ZZX zRep_;
 	uint32 *rRep_;
 	uint32 *cRep_;

@@ -156,6 +156,11 @@ int cuhe_hip_barrett_hold(uint32_t *dst, int lvl, int dev, void *stream);
  * and setParameters picks primes of at most 23 bits.
  * Row length of a ct-domain polynomial: cuhe_hip_ct_len() (= modLen or nttLen).  ct arrays are u64[rows][ct_len]. */
 int cuhe_hip_set_negacyclic(int mode);   /* before init: -1 = negacyclic wherever it applies (default), 0 = never */
+/* How many PRODUCTS of reduced polynomials may be summed in the ct domain (cuhe_hip_ct_add of isProd operands) before
+ * cuhe_hip_ct_intt(..., is_prod = 1): the integer coefficients of the sum must stay inside the range the inverse
+ * transform recovers (P in the cyclic representation, +-P/2 in the negacyclic one, where it is ONE on the largest
+ * rings: 2 n p^2 is just below P).  The C ABI does not track this; the C++ gates (cXor, CuHE.cpp) do and reduce first. */
+int cuhe_hip_ct_prod_headroom(void);
 int cuhe_hip_ct_negacyclic(void);        /* 1 if the initialised context uses the negacyclic representation */
 int cuhe_hip_ct_len(void);
 int cuhe_hip_ct_ntt(uint64_t *X, const uint32_t *x, int logq, int dev, void *stream);                /* c2n, CuHE.cu:383 */

@@ -261,6 +261,36 @@ int main() {
 		CHECK(cb.zRep() == a, "copy / moveTo(same device) / explicit destructor with the pooled allocator");
 		stopAllocator();
 	}
+	// ---- a SUM of two products in the NTT domain on a ring whose negacyclic representation has room for ONE product
+	// (x^16384 + 1, 24-bit primes: 2 n p^2 just below P).  Operands with every residue p - 1 drive the integer coefficients
+	// of each product to n (p - 1)^2; cXor has to notice that their sum leaves the range the inverse transform recovers.
+	{
+		cuhe_hip_shutdown();
+		setParameters(3, 2, 16, 48, 24, 32768);
+		const int n2 = param.modLen;
+		ZZX xn1; SetCoeff(xn1, n2, 1); SetCoeff(xn1, 0, 1);
+		std::vector<ZZ> q2(3);
+		initCuHE(q2.data(), xn1);
+		CHECK(cuhe_hip_ct_negacyclic() == 1 && cuhe_hip_ct_prod_headroom() == 1, "x^16384 + 1 with 24-bit primes: negacyclic, room for one product");
+		ZZX a, b;
+		for (int i = 0; i < n2; ++i) { SetCoeff(a, i, q2[0] - 1); SetCoeff(b, i, (i & 1) ? q2[0] - 1 : to_ZZ(1)); }
+		CuCtxt ca, cb, p1, p2, sum;
+		ca.setLevel(0, 0, a); cb.setLevel(0, 0, b);
+		ca.x2n(); cb.x2n();
+		cAnd(p1, ca, ca);
+		cAnd(p2, ca, cb);
+		cXor(sum, p1, p2);
+		CHECK(sum.domain() == 3, "cXor of two products answers in the NTT domain");
+		sum.x2z();
+		ZZX want = reduceCoeffs(hostMul(a, a, xn1, q2[0], n2) + hostMul(a, b, xn1, q2[0], n2), q2[0], n2);
+		CHECK(sum.zRep() == want, "a*a + a*b added in the NTT domain on a ring with headroom 1");
+		ZZX ra = randomPoly(n2, q2[0]), rb = randomPoly(n2, q2[0]);
+		CuCtxt cra, crb, s2;
+		cra.setLevel(0, 0, ra); crb.setLevel(0, 0, rb); cra.x2n(); crb.x2n();
+		cXor(s2, cra, crb);                                      // no products involved: plain NTT-domain addition
+		s2.x2z();
+		CHECK(s2.zRep() == reduceCoeffs(ra + rb, q2[0], n2), "cXor of two fresh NTT-domain ciphertexts");
+	}
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;
 }
