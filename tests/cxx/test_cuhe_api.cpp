@@ -261,9 +261,10 @@ int main() {
 		CHECK(cb.zRep() == a, "copy / moveTo(same device) / explicit destructor with the pooled allocator");
 		stopAllocator();
 	}
-	// ---- a SUM of two products in the NTT domain on a ring whose negacyclic representation has room for ONE product
-	// (x^16384 + 1, 24-bit primes: 2 n p^2 just below P).  Operands with every residue p - 1 drive the integer coefficients
-	// of each product to n (p - 1)^2; cXor has to notice that their sum leaves the range the inverse transform recovers.
+	// ---- SUMS of products in the NTT domain on a ring whose negacyclic representation has room for TWO products
+	// (x^16384 + 1, 24-bit primes: 2 n p^2 just below P / 2; ONE on x^32768 + 1).  Operands with every residue p - 1 drive the
+	// integer coefficients of each product to n (p - 1)^2; cXor has to notice when a sum leaves the range the inverse
+	// transform recovers and reduce the operands first.
 	{
 		cuhe_hip_shutdown();
 		setParameters(3, 2, 16, 48, 24, 32768);
@@ -271,7 +272,7 @@ int main() {
 		ZZX xn1; SetCoeff(xn1, n2, 1); SetCoeff(xn1, 0, 1);
 		std::vector<ZZ> q2(3);
 		initCuHE(q2.data(), xn1);
-		CHECK(cuhe_hip_ct_negacyclic() == 1 && cuhe_hip_ct_prod_headroom() == 1, "x^16384 + 1 with 24-bit primes: negacyclic, room for one product");
+		CHECK(cuhe_hip_ct_negacyclic() == 1 && cuhe_hip_ct_prod_headroom() == 2, "x^16384 + 1 with 24-bit primes: negacyclic, room for two products");
 		ZZX a, b;
 		for (int i = 0; i < n2; ++i) { SetCoeff(a, i, q2[0] - 1); SetCoeff(b, i, (i & 1) ? q2[0] - 1 : to_ZZ(1)); }
 		CuCtxt ca, cb, p1, p2, sum;
@@ -283,7 +284,17 @@ int main() {
 		CHECK(sum.domain() == 3, "cXor of two products answers in the NTT domain");
 		sum.x2z();
 		ZZX want = reduceCoeffs(hostMul(a, a, xn1, q2[0], n2) + hostMul(a, b, xn1, q2[0], n2), q2[0], n2);
-		CHECK(sum.zRep() == want, "a*a + a*b added in the NTT domain on a ring with headroom 1");
+		CHECK(sum.zRep() == want, "a*a + a*b added in the NTT domain (two products: inside the headroom)");
+		{
+			CuCtxt q1, q2c, q3, s12, s123;
+			cAnd(q1, ca, ca); cAnd(q2c, ca, ca); cAnd(q3, ca, ca);
+			cXor(s12, q1, q2c);
+			cXor(s123, s12, q3);                                 // three products: beyond the headroom, the operands are reduced first
+			CHECK(s123.domain() == 3, "cXor beyond the headroom still answers in the NTT domain");
+			s123.x2z();
+			ZZX aa = hostMul(a, a, xn1, q2[0], n2);
+			CHECK(s123.zRep() == reduceCoeffs(aa + aa + aa, q2[0], n2), "a*a + a*a + a*a added in the NTT domain (three products: beyond the headroom)");
+		}
 		ZZX ra = randomPoly(n2, q2[0]), rb = randomPoly(n2, q2[0]);
 		CuCtxt cra, crb, s2;
 		cra.setLevel(0, 0, ra); crb.setLevel(0, 0, rb); cra.x2n(); crb.x2n();
