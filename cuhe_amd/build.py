@@ -19,6 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcuhe_hip.so")
 # (object name, source, extra flags)
 UNITS = [("cuhe_hip", "cuhe_hip.hip", []),
+         ("ntt_onewg_12", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=12"]),
          ("ntt_onewg_13", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=13"]),
          ("ntt_onewg_14", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=14"]),
          ("ntt_onewg_15", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=15"])]

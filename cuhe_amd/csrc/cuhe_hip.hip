@@ -64,8 +64,8 @@ struct NttTab {
 // calls into the library gets its own set, so several threads can drive the same GPU on their own streams and the
 // small kernels of independent ciphertext operations overlap on the device.
 struct Workspace {
-    u64 *slab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // pass-1 -> pass-2 slabs per length
-    size_t slab_bytes[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    u64 *slab[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // pass-1 -> pass-2 slabs per length
+    size_t slab_bytes[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     size_t n_barrett = 0, n_alias = 0, n_relin = 0;     // rows / elements the buffers below currently hold
     // scratch of the batched multiply + relinearise (cuhe_hip_mul_relin_batch), sized by the largest batch seen
     u64 *bt_ntt = nullptr; u32 *bt_crt = nullptr; size_t n_bt = 0;
@@ -95,8 +95,8 @@ struct OwTab {
 };
 struct DevCtx {
     bool ready = false;
-    NttTab ntt[3];                       // LG 14,15,16
-    OwTab ow[3];                         // sub-transforms of 8K, 16K, 32K points
+    NttTab ntt[4];                       // LG 13 (one-workgroup form only: twist tables), 14, 15, 16
+    OwTab ow[4];                         // sub-transforms of 4K, 8K, 16K, 32K points
     int cus = 0;                         // compute units (policy of the one-workgroup transforms)
     // prime tables
     u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
@@ -153,7 +153,7 @@ struct Global {
     uint64_t generation = 1;      // bumped by shutdown: thread-local workspace pointers of older generations are stale
 } G_;
 
-inline int lg_index(int len) { return len == 16384 ? 0 : len == 32768 ? 1 : len == 65536 ? 2 : -1; }
+inline int lg_index(int len) { return len == 8192 ? 0 : len == 16384 ? 1 : len == 32768 ? 2 : len == 65536 ? 3 : -1; }
 inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
 inline int phys_dev(int dev) { return G_.virtual_devices ? G_.dev_base : G_.dev_base + dev; }
@@ -321,17 +321,17 @@ int make_ntt_tables(NttTab &tab) {
 int ensure_ntt(int dev, int len, int batch_hint) {
     (void)batch_hint;
     const int li = lg_index(len);
-    if (li < 0) return fail(CUHE_EINVAL, "unsupported transform length %d (16384/32768/65536 only)", len);
+    if (li < 0) return fail(CUHE_EINVAL, "unsupported transform length %d (8192/16384/32768/65536 only)", len);
     {
         const NttTab &t0 = G_.dev[dev].ntt[li];         // launch path: tables exist and the chunk setting is unchanged -> no lock
         if (t0.ready.load(std::memory_order_acquire) == (G_.ntt_chunk + 1)) return CUHE_OK;
     }
     std::lock_guard<std::mutex> lk(G_.mu);
     NttTab &tab = G_.dev[dev].ntt[li];
-    if (!tab.T1w) {
-        if (li == 0) CHK(make_ntt_tables<14>(tab));
-        else if (li == 1) CHK(make_ntt_tables<15>(tab));
-        else CHK(make_ntt_tables<16>(tab));
+    if (!tab.T1w) {                               // (8192 points: the one-workgroup form only, its tables are made by ensure_onewg)
+        if (li == 1) CHK(make_ntt_tables<14>(tab));
+        else if (li == 2) CHK(make_ntt_tables<15>(tab));
+        else if (li == 3) CHK(make_ntt_tables<16>(tab));
     }
     // transforms per launch pair
     int chunk = G_.ntt_chunk > 0 ? G_.ntt_chunk : (256 << 20) / (len * 8);     // slab of 256 MiB: profiles/r01_chunk_sweep.txt
@@ -399,7 +399,8 @@ int ensure_onewg(OwTab &tab, int lgh) {
     return CUHE_OK;
 }
 int onewg_launch(int lgh, int mode, int out, bool half, const OwArgs &a, hipStream_t st) {
-    hipError_t e = lgh == 13 ? ow_launch_13(mode, out, half, a, st) : lgh == 14 ? ow_launch_14(mode, out, half, a, st) : ow_launch_15(mode, out, half, a, st);
+    hipError_t e = lgh == 12 ? ow_launch_12(mode, out, half, a, st) : lgh == 13 ? ow_launch_13(mode, out, half, a, st)
+                 : lgh == 14 ? ow_launch_14(mode, out, half, a, st) : ow_launch_15(mode, out, half, a, st);
     if (e != hipSuccess) return fail(CUHE_EHIP, "one-workgroup transform (2^%d points, source %d, store %d%s): %s", lgh, mode, out, half ? ", half" : "", hipGetErrorString(e));
     return CUHE_OK;
 }
@@ -486,7 +487,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod,
                const Epilogue *ep) {
     constexpr int L = 1 << LG;
-    NttTab &tab = D.ntt[LG - 14];
+    NttTab &tab = D.ntt[LG - 13];
     const int chunk = tab.chunk;
     // Two-stage software pipeline over chunks: pass 1 (VALU/LDS bound) of chunk c+1 runs on stream s1 while
     // pass 2 (load/store heavy, 1 wave/SIMD fits beside pass 1's 2) of chunk c runs on s2.
@@ -498,9 +499,10 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         // worth it once the call's workgroups (1 / 2 / 4 fit a CU at 32K / 16K / 8K points) fill the chip; below that the
         // two-pass kernels spread a row over 8 - 16 workgroups and finish sooner
         const long wgs = (long)batch * (half ? 2 : 1);
-        const bool fills = G_.onewg == 2 || (lgh >= 13 && lgh <= 15 && wgs >= (long)D.cus * (1 << (15 - lgh)));
+        // (8192-point transforms exist in this form only: whatever the row count)
+        const bool fills = LG == 13 || G_.onewg == 2 || (lgh >= 13 && lgh <= 15 && wgs >= (long)D.cus * (1 << (15 - lgh)));
         const bool rows64 = half && lgh == 15;
-        if (G_.onewg && lgh <= 15 && fills && (!rows64 || G_.onewg64)) {
+        if ((G_.onewg || LG == 13) && lgh <= 15 && fills && (!rows64 || G_.onewg64)) {
             int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
             if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
                 if (ep && ep->kind) { out = ep->kind == 1 ? kOutModPRevQ : kOutFoldFinal; e = *ep; }
@@ -509,7 +511,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 else out = kOutModP;
             } else { out = mul_tab ? kOutU64Mul : kOutU64; xt = mul_tab; }
             if (ow_supported(mode, out, half)) {
-                OwTab &ot = D.ow[lgh - 13];
+                OwTab &ot = D.ow[lgh - 12];
                 CHK(ensure_onewg(ot, lgh));
                 const u64 *tw = mode == kSrcU64NegMul ? mul_tab : mode == kSrcU32Twist ? (const u64 *)tab.tw : nullptr;
                 if (mode == kSrcU64NegMul && !tw) return fail(CUHE_EINVAL, "second operand missing");
@@ -533,12 +535,15 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             }
         }
     }
+    if constexpr (LG == 13) {
+        return fail(CUHE_EINVAL, "8192-point transforms exist in the one-workgroup form only (source %d, %s)", mode, ep && ep->kind ? "folded-reduction store" : "plain store");
+    } else {
     const bool pipe = G_.ntt_overlap && !(tm && tm->on) && batch > chunk;
     hipStream_t q1 = pipe ? D.s1 : st, q2 = pipe ? D.s2 : st;
     const size_t slab_bytes = (size_t)((std::min(chunk, batch) + 7) & ~7) * L * sizeof(u64);
     u64 *slabs[2] = {nullptr, nullptr};
-    CHK(ws_slab(W, LG - 14, 0, slab_bytes, &slabs[0]));
-    if (pipe) CHK(ws_slab(W, LG - 14, 1, slab_bytes, &slabs[1]));
+    CHK(ws_slab(W, LG - 13, 0, slab_bytes, &slabs[0]));
+    if (pipe) CHK(ws_slab(W, LG - 13, 1, slab_bytes, &slabs[1]));
     if (pipe) {
         HIPCHK(hipEventRecord(D.ev_start, st));
         HIPCHK(hipStreamWaitEvent(D.s1, D.ev_start, 0));
@@ -592,6 +597,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
     }
     if (pipe) HIPCHK(hipStreamWaitEvent(st, D.ev_p2[last], 0));
     return CUHE_OK;
+    }
 }
 
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
@@ -603,6 +609,7 @@ int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_s
     Workspace *W = nullptr;
     CHK(workspace(dev, st, &W));
     switch (len) {
+        case 8192:  return run_ntt_lg<13>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
         case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
         case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
         default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);

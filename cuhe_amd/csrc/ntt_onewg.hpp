@@ -17,6 +17,7 @@ struct OwArgs {
     const u32 *aux; long aux_stride; FoldGeom fg; const u64 *xtab;
 };
 // hipErrorInvalidValue: this (sub-transform size, source, epilogue, half) combination is not instantiated
+hipError_t ow_launch_12(int mode, int out, bool half, const OwArgs &a, hipStream_t st);        // 4K-point halves of the zero-padded 8K-point transform only
 hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);

@@ -1,5 +1,6 @@
 // ntt_onewg_inst.hip -- instantiations + launcher of the one-workgroup transforms for ONE sub-transform size
-// (-DCUHE_OW_LGH=13|14|15; cuhe_amd/build.py compiles the three sizes in parallel).
+// (-DCUHE_OW_LGH=12|13|14|15; cuhe_amd/build.py compiles the sizes in parallel; 12 = the 4K-point halves of the
+// zero-padded 8K-point transform only).
 #include "ntt_onewg.hpp"
 #include "ntt_onewg.cuh"
 
@@ -7,7 +8,7 @@
 #include <mutex>
 
 #ifndef CUHE_OW_LGH
-#error "compile with -DCUHE_OW_LGH=13, 14 or 15"
+#error "compile with -DCUHE_OW_LGH=12, 13, 14 or 15"
 #endif
 
 namespace cuhe {
@@ -50,6 +51,7 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
     OW_CASE(kSrcU32Ext, kOutU64, true)
     OW_CASE(kSrcU32Ext, kOutU64Mul, true)
     OW_CASE(kSrcWindow, kOutU64, true)
+#if CUHE_OW_LGH >= 13
     // full-length transforms of 2^LGH points: negacyclic forward, inverses with their store epilogues
     OW_CASE(kSrcU32Twist, kOutU64, false)
     OW_CASE(kSrcU32Twist, kOutU64Mul, false)
@@ -61,6 +63,7 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
     OW_CASE(kSrcU64NegMul, kOutModP, false)
     OW_CASE(kSrcU64NegMul, kOutModPFoldXn1, false)
     OW_CASE(kSrcU64NegMul, kOutModPNc, false)
+#endif
     return hipErrorInvalidValue;
 }
 #if CUHE_OW_LGH == 15

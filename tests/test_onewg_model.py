@@ -8,7 +8,7 @@ import onewg_model as M
 import oracle_lib as O
 
 
-@pytest.mark.parametrize("R", [8, 16])
+@pytest.mark.parametrize("R", [4, 8, 16])
 def test_half_mode_equals_zero_padded_transform(R):
     Lh = 32 * 32 * R
     x = O.splitmix_u32_below(Lh, (1 << 32) - 1, 7 + R)
@@ -42,6 +42,6 @@ def test_32k_balanced_exchanges_equal_zero_padded_transform():
 
 def test_lds_budget():
     # bytes of the exchange buffer + the stage-2 twiddle table: 4 / 2 / 1 workgroups per CU inside 160 KiB
-    for R, per_cu in ((8, 4), (16, 2)):
+    for R, per_cu in ((4, 7), (8, 4), (16, 2)):
         bytes_ = (M.lds_words(R) + 32 * R) * 8
         assert bytes_ * per_cu <= 160 * 1024, (R, bytes_)
