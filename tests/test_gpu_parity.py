@@ -254,6 +254,8 @@ def test_mul_pipeline_vs_golden(gu, golden, name, fixture):
     g = gu.GpuCtx(*gold["args"])
     try:
         q = g.prm
+        if name == "c1_pow2_1prime":                   # x^8192 + 1: the ciphertext domain is the negacyclic transform of 8192 points
+            assert g.nc and g.ctlen == 8192 == q.modLen
         for lvl_s, rec in gold["levels"].items():
             lvl = int(lvl_s)
             W, M = g.words(lvl), g.coeff_modulus(lvl)

@@ -6,14 +6,15 @@
 # transform, tagged with the hash of the kernel sources bench.py checks).  Every step runs under its own timeout.
 # usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r02]
 export TMPDIR=/tmp
-tag=${2:-r02}
+tag=${2:-r03}
 out=$PWD/gpurun_out/final; mkdir -p $out
 if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
 timeout 600 python bench.py 2>/dev/null | tail -1 > $out/bench_n1.json
 python - <<PY
 import json; d = json.load(open("$out/bench_n1.json")); r = d["roofline"]
-print("NTT/s", d["value"], "frac", r["frac"], "copy GB/s", r.get("measured_copy_GBs"), "mul_relin ms", d["mul_relin"]["ms"], "batched", d["mul_relin"]["batched"]["ms_per_ciphertext"],
-      "other ring", d["mul_relin_other_ring"]["batched"]["ms_per_ciphertext"], "mul_full ms", d["mul_full"]["ms"], "batched", d["mul_full"]["batched"]["ms_per_multiply"], "prince", (d.get("prince") or {}).get("value"))
+print("NTT/s", d["value"], "frac", r["frac"], "other lengths", {k: (v.get("value"), v.get("frac")) for k, v in r.get("other_lengths", {}).items()}, "copy GB/s", r.get("measured_copy_GBs"))
+print("mul_relin (x^65536+1) ms", d["mul_relin"]["ms"], "batched", d["mul_relin"]["batched"]["ms_per_ciphertext"], d["mul_relin"]["batched"].get("checked"),
+      "| x^32768+1", d["mul_relin_other_ring"]["ms"], d["mul_relin_other_ring"]["batched"]["ms_per_ciphertext"], "| mul_full ms", d["mul_full"]["ms"], "batched", d["mul_full"]["batched"]["ms_per_multiply"], "| prince", (d.get("prince") or {}).get("value"))
 PY
 R=$PWD
 cd /tmp
@@ -34,5 +35,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python tools/make_traffic_json.py $out $tag > $out/traffic_$tag.json && cat $out/traffic_$tag.json
+# the one-workgroup transforms against the two-pass kernels (equality + timing), and the table of doc/Perf_NTT.txt
+timeout 300 $R/cuhe_amd/lib/ow_ab 4096 10 > $out/onewg_ab.txt 2>&1; grep -v mismatch $out/onewg_ab.txt; grep -c identical $out/onewg_ab.txt
+timeout 300 python bench.py --perf-table $out/perf_ntt_table.txt > /dev/null 2>&1; tail -11 $out/perf_ntt_table.txt
 head -14 $out/kernel_trace_stats.txt | cut -c1-72,110-200
 cat $out/batched_trace.txt
