@@ -241,6 +241,7 @@ def main():
                 except Exception as ex:
                     other_lengths[str(L2)] = {"error": repr(ex)[:200]}
         roofline["other_lengths"] = other_lengths
+        step(); torch.cuda.synchronize()                     # (the shorter transforms borrowed dst: the 64K-point outputs are checked below)
 
         # measured device-to-device copy ceiling of this box: 1 GiB read + 1 GiB written per copy
         ca = torch.empty(1 << 28, dtype=torch.int32, device=dev); cb = torch.empty_like(ca)
