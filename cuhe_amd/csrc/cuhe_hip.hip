@@ -98,6 +98,7 @@ struct DevCtx {
     NttTab ntt[4];                       // LG 13 (one-workgroup form only: twist tables), 14, 15, 16
     OwTab ow[4];                         // sub-transforms of 4K, 8K, 16K, 32K points
     int cus = 0;                         // compute units (policy of the one-workgroup transforms)
+    unsigned *pair_cnt = nullptr;        // rendezvous counters of the persistent one-workgroup transform (one per pair of workgroups)
     // prime tables
     u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
     u64 *pinv = nullptr;
@@ -144,9 +145,11 @@ struct Global {
     int ntt_chunk = 0;
     // one-workgroup transforms: 0 never; 1 where they exist and the call fills the chip; 2 wherever they exist (tests)
     int onewg = getenv("CUHE_ONEWG") ? atoi(getenv("CUHE_ONEWG")) : 1;
-    // zero-padded rows of 64K points (32K-point halves, ONE workgroup per CU): 0 two-pass kernels (default: same speed,
-    // profiles/r03_onewg_ab.txt), 1 one workgroup per half, 2 persistent workgroups with LDS-DMA prefetch of the samples
-    int onewg64 = getenv("CUHE_ONEWG64") ? atoi(getenv("CUHE_ONEWG64")) : 0;
+    // zero-padded rows of 64K points (32K-point halves, ONE workgroup per CU): 0 two-pass kernels, 1 one workgroup per half,
+    // 2 (default) persistent workgroups with LDS-DMA prefetch of the samples and a rendezvous of the two halves of a row before
+    // their stores, for calls that give every workgroup at least two halves (2.71 vs 2.56 M transforms/s,
+    // profiles/r03_onewg_ab.txt); smaller calls and unaligned rows take the two-pass kernels
+    int onewg64 = getenv("CUHE_ONEWG64") ? atoi(getenv("CUHE_ONEWG64")) : 2;
     bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
     std::mutex mu;
@@ -502,7 +505,10 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         // (8192-point transforms exist in this form only: whatever the row count)
         const bool fills = LG == 13 || G_.onewg == 2 || (lgh >= 13 && lgh <= 15 && wgs >= (long)D.cus * (1 << (15 - lgh)));
         const bool rows64 = half && lgh == 15;
-        if ((G_.onewg || LG == 13) && lgh <= 15 && fills && (!rows64 || G_.onewg64)) {
+        const int grid64 = D.cus & ~15;
+        const bool stream_ok = rows64 && mode == kSrcU32Ext && grid64 >= 16 && wgs >= 2L * grid64 && ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
+        const bool rows64_onewg = G_.onewg64 == 1 || (G_.onewg64 == 2 && stream_ok);
+        if ((G_.onewg || LG == 13) && lgh <= 15 && fills && (!rows64 || rows64_onewg)) {
             int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
             if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
                 if (ep && ep->kind) { out = ep->kind == 1 ? kOutModPRevQ : kOutFoldFinal; e = *ep; }
@@ -523,11 +529,11 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 // 64K-point rows: one workgroup per CU walks over its share of the halves, the next half's samples arriving by
                 // LDS-DMA beside stage 3 of the current one (16-byte aligned rows, at least two halves per workgroup)
-                const int grid = D.cus & ~15;
-                const bool stream = G_.onewg64 == 2 && rows64 && mode == kSrcU32Ext && grid >= 16 && wgs >= 2L * grid &&
-                                    ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
+                const int grid = grid64;
+                const bool stream = G_.onewg64 == 2 && stream_ok;
                 if (stream) {
-                    hipError_t he = ow_launch_stream(out, a, grid, st);
+                    if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, 128 * sizeof(unsigned)));
+                    hipError_t he = ow_launch_stream(out, a, grid, D.pair_cnt, st);
                     if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform: %s", hipGetErrorString(he));
                 } else CHK(onewg_launch(lgh, mode, out, half, a, st));
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }

@@ -297,7 +297,8 @@ __device__ __forceinline__ void glds16(const void *gsrc, u32 lds_byte_addr) {   
 // same for every item of a workgroup and the odd half's sample shifts sit on a straight-line path.
 template <int OUT, int H>
 __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, u64 *buf, const u64 *tw2,
-                                               long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod) {
+                                               long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod,
+                                               unsigned *pair_cnt, int *give_up) {
     constexpr int R = 32;
     using G = OwGeom<R>;
     constexpr int T = G::T, Lh = G::Lh;
@@ -317,6 +318,7 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
         }
     };
     if ((int)blockIdx.x < nitems) fetch(blockIdx.x);
+    int round = 0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int batch = (item >> 4) * 8 + (item & 7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -337,21 +339,44 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
         ow32_stage1_x1(x, y, lb, TW1 + (long)H * Lh + t + opaque, H != 0, t);
         ow32_stage2_x2(y, z, lb, tw2 + opaque, t, true);
         if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);      // the buffer is idle until exchange 1 of the next item
+        // Rendezvous with the workgroup that computes the OTHER parity of this row (block ^ 8: same XCD, same round): the two
+        // write alternate 8-byte words of the same lines, and only stores issued within a few microseconds of each other meet in
+        // L2 (measured: 1.9x the output bytes leave L2 when the pair drifts -- the odd half has 3 % more work --, 2.33 -> 2.72 M
+        // transforms/s when it does not; tools/ubench_onewg.hip).  Performance only: the wait is bounded and nothing depends on
+        // it having succeeded.  Every workgroup of the grid is resident (one per CU), so the partner is running.
+        if (pair_cnt) {
+            if (t == 0) {
+                unsigned *c = pair_cnt + (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
+                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = 2u * (unsigned)(round + 1);
+                bool met = false;
+                for (int spin = 0; spin < 256 && !met; ++spin) {
+                    met = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+                    if (!met) __builtin_amdgcn_s_sleep(4);
+                }
+                if (!met) *give_up = 1;                     // the partner is not running beside us (another kernel holds its CU): stop waiting for it
+            }
+            __syncthreads();
+            if (*give_up) pair_cnt = nullptr;
+        }
         dft_regs<32, false>(z);
         if (batch < nbatch) ow_store_half<R, OUT>(z, dst_, dst_stride, batch, H, t, xtab, prime0, np_mod);
+        ++round;
     }
 }
 template <int OUT>
 __global__ __launch_bounds__(1024, 4)
 void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
-                      long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod) {
+                      long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod, unsigned *pair_cnt) {
     using G = OwGeom<32>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     u64 *buf = lds;
     u64 *tw2 = lds + G::XW;
+    __shared__ int give_up;
     tw2[threadIdx.x] = TW2[threadIdx.x];
-    if ((blockIdx.x >> 3) & 1) ow_stream_loop<OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod);
-    else ow_stream_loop<OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod);
+    if (threadIdx.x == 0) give_up = 0;
+    if ((blockIdx.x >> 3) & 1) ow_stream_loop<OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up);
+    else ow_stream_loop<OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up);
 }
 
 }  // namespace cuhe

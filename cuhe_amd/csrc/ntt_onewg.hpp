@@ -21,7 +21,8 @@ hipError_t ow_launch_12(int mode, int out, bool half, const OwArgs &a, hipStream
 hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
-hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, hipStream_t st);      // kSrcU32Ext rows of 64K-point transforms
+// kSrcU32Ext rows of 64K-point transforms; pair_cnt: grid / 2 counters for the rendezvous of the two halves of a row (or null)
+hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st);
 bool ow_supported(int mode, int out, bool half);
 
 }  // namespace cuhe

@@ -69,7 +69,7 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
 #if CUHE_OW_LGH == 15
 // persistent form of the 32K-point halves of the 64K-point zero-padded forward transform (ntt_onewg_stream): `grid`
 // workgroups (a multiple of 16, at most one per CU) walk over the 2 * batch halves
-hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, hipStream_t st) {
+hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st) {
     if (out != kOutU64 && out != kOutU64Mul) return hipErrorInvalidValue;
     if (grid < 16 || (grid & 15)) return hipErrorInvalidValue;
     auto k0 = ntt_onewg_stream<kOutU64>;
@@ -88,10 +88,14 @@ hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, hipStream_t st) 
             done.fetch_or(bit, std::memory_order_release);
         }
     }
+    if (pair_cnt) {                                   // (grid / 2) rendezvous counters of the row pairs, zero at launch
+        e = hipMemsetAsync(pair_cnt, 0, (size_t)(grid / 2) * sizeof(unsigned), st);
+        if (e != hipSuccess) return e;
+    }
     if (out == kOutU64)
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod);
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod, pair_cnt);
     else
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod);
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod, pair_cnt);
     return hipGetLastError();
 }
 bool ow_supported(int mode, int out, bool half) {

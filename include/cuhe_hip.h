@@ -301,8 +301,10 @@ int cuhe_hip_set_ll_rows(int rows);
  * its workgroups (1 / 2 / 4 per CU at 32K / 16K / 8K points; below that the two-pass kernels finish sooner); 2: wherever
  * it exists, whatever the row count (the parity tests run every form); 0: the two-pass kernels only.
  * rows64k selects the form of zero-padded rows of 64K points, whose 32K-point halves leave room for ONE workgroup per
- * CU: 0 (default) the two-pass kernels (equal speed, profiles/r03_onewg_ab.txt), 1 one workgroup per half, 2 persistent
- * workgroups (one per CU, the next half's samples prefetched into LDS by DMA).  Same results in every form.
+ * CU: 0 the two-pass kernels, 1 one workgroup per half, 2 (default) persistent workgroups (one per CU, the next half's
+ * samples prefetched into LDS by DMA, the two halves of a row meeting before their interleaved stores) for calls that
+ * give every workgroup at least two halves and 16-byte aligned rows, the two-pass kernels otherwise (2.71 vs 2.56 M
+ * transforms/s, profiles/r03_onewg_ab.txt).  Same results in every form.
  * Environment CUHE_ONEWG / CUHE_ONEWG64 override the defaults for A/B runs of whole programs.  Replaces the same
  * reference code as the two-pass kernels (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398). */
 int cuhe_hip_set_onewg(int mode, int rows64k);

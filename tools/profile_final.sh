@@ -23,7 +23,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o s -- python $R/
 python $R/tools/rocpd_summary.py /tmp/pf_stats/s_results.db > $out/kernel_trace_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pf_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-mulrelin --no-cpu --no-prince > /dev/null 2>&1
-  python $R/tools/rocpd_summary.py /tmp/pf_$c/p_results.db 2>&1 | grep -E "^==|^kernel|ntt_pass" > $out/pmc_$c.txt
+  python $R/tools/rocpd_summary.py /tmp/pf_$c/p_results.db 2>&1 | grep -E "^==|^kernel|ntt_pass|ntt_onewg" > $out/pmc_$c.txt
 done
 # the batched multiply + relinearise call alone (config 4, 32 ciphertexts per call): per-kernel time, then the HBM
 # counters of its inner-product kernel

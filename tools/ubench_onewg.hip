@@ -1,6 +1,6 @@
 // tools/ubench_onewg.hip -- where the time of the 32K-point one-workgroup half-transform goes (ntt_onewg.cuh, persistent
 // form): per-phase s_memtime stamps of one wave, and ablations of the memory-side pieces (store pattern, table loads,
-// sample prefetch).  Timing only: results are not checked here (tools/ow_ab.cpp and the parity tests do that).
+// sample prefetch; 16 = every workgroup runs the parity-0 code, to see what the two parities' code paths cost in the shared instruction cache).  Timing only: results are not checked here (tools/ow_ab.cpp and the parity tests do that).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_onewg.hip -o tools/ubench_onewg
 #include <hip/hip_runtime.h>
 
@@ -19,7 +19,7 @@ enum { kPhases = 10 };
 // condition); 4 = no stage-1 table loads (the sample itself stands in); 8 = samples by plain global loads (no LDS-DMA prefetch)
 template <int H, int variant>
 __device__ __forceinline__ void loop(u64 *dst_, const u32 *src, const u64 *TW1, u64 *buf, const u64 *tw2, int nbatch,
-                                     unsigned long long *stamps) {
+                                     unsigned long long *stamps, int hs) {
     constexpr int T = 1024, Lh = 32768;
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -102,11 +102,11 @@ __device__ __forceinline__ void loop(u64 *dst_, const u32 *src, const u64 *TW1, 
         if constexpr (variant & 2) {
             if (z[3] == 0x123456789abcdef0ull) dst_[t] = z[5];
         } else if constexpr (variant & 1) {
-            u64 *dst = dst_ + (long)batch * 65536 + (long)H * Lh;
+            u64 *dst = dst_ + (long)batch * 65536 + (long)hs * Lh;
 #pragma unroll
             for (int kc = 0; kc < 32; ++kc) dst[t + T * kc] = z[bitrev<32>(kc)];
         } else {
-            u64 *dst = dst_ + (long)batch * 65536 + H;
+            u64 *dst = dst_ + (long)batch * 65536 + hs;
 #pragma unroll
             for (int kc = 0; kc < 32; ++kc) dst[2L * (t + T * kc)] = z[bitrev<32>(kc)];
         }
@@ -124,8 +124,9 @@ void k_stream(u64 *dst, const u32 *src, const u64 *TW1, const u64 *TW2, int nbat
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     u64 *buf = lds, *tw2 = lds + OwGeom<32>::XW;
     tw2[threadIdx.x] = TW2[threadIdx.x];
-    if ((blockIdx.x >> 3) & 1) loop<1, variant>(dst, src, TW1, buf, tw2, nbatch, stamps);
-    else loop<0, variant>(dst, src, TW1, buf, tw2, nbatch, stamps);
+    const int hs = (blockIdx.x >> 3) & 1;                // where the results go: always the workgroup's own parity (same memory traffic in every variant)
+    if (hs && !(variant & 16)) loop<1, variant>(dst, src, TW1, buf, tw2, nbatch, stamps, hs);
+    else loop<0, variant>(dst, src, TW1, buf, tw2, nbatch, stamps, hs);
 }
 
 int main(int argc, char **argv) {
@@ -154,7 +155,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char *names[] = {"drain+barrier", "samples->regs", "stage1 dft+tw", "exchange 1", "stage 2", "exchange 2", "prefetch+stage3", "store issue"};
     typedef void (*kern_t)(u64 *, const u32 *, const u64 *, const u64 *, int, unsigned long long *);
-    struct V { int variant; kern_t k; } vs[] = {{0, k_stream<0>}, {1, k_stream<1>}, {2, k_stream<2>}, {4, k_stream<4>}, {8, k_stream<8>}, {6, k_stream<6>}, {14, k_stream<14>}};
+    struct V { int variant; kern_t k; } vs[] = {{0, k_stream<0>}, {1, k_stream<1>}, {2, k_stream<2>}, {16, k_stream<16>}, {17, k_stream<17>}, {0, k_stream<0>}, {16, k_stream<16>}};
     for (auto &v : vs) {
         const int variant = v.variant;
         HK(hipFuncSetAttribute((const void *)v.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -167,7 +168,7 @@ int main(int argc, char **argv) {
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         const double per = ms / iters * 1e-3 / nbatch;
         printf("variant %2d [%s%s%s%s]: %.4f ms per %d transforms, %.3f M/s, frac %.4f\n", variant, variant & 1 ? "contiguous-stores " : "", variant & 2 ? "no-stores " : "",
-               variant & 4 ? "no-table-loads " : "", variant & 8 ? "plain-loads " : "", ms / iters, nbatch, 1e-6 / per, 655360.0 / per / 8e12);
+               variant & 4 ? "no-table-loads " : "", variant & 8 ? "plain-loads " : variant & 16 ? "one-code-path " : "", ms / iters, nbatch, 1e-6 / per, 655360.0 / per / 8e12);
         std::vector<unsigned long long> st(256 * 2 * kPhases);
         HK(hipMemcpy(st.data(), dst_amps, st.size() * 8, hipMemcpyDeviceToHost));
         for (int blk : {0, 8, 100}) for (int wv = 0; wv < 2; ++wv) {
