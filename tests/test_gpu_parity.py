@@ -1147,7 +1147,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                         assert np.array_equal(v, res[k]), (name, k)
             finally:
                 ck(lib.cuhe_hip_set_ll_rows(24))
-                ck(lib.cuhe_hip_set_onewg(1, 0))
+                ck(lib.cuhe_hip_set_onewg(1, 2))
                 g.close()
         # the standalone batched forward entry point at all three lengths, odd batch
         for length in (16384, 32768, 65536):
@@ -1161,7 +1161,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
                 ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), gu.to_dev(x).data_ptr(), length, 5, length // 2, 0, None))
                 got.append(gu.host_u64(dX))
             ck(lib.cuhe_hip_set_ll_rows(24))
-            ck(lib.cuhe_hip_set_onewg(1, 0))
+            ck(lib.cuhe_hip_set_onewg(1, 2))
             assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]), length
             assert np.array_equal(got[1][4], O.ntt_ext(x[4], length)), length
         if name == "toy1155":
@@ -1181,8 +1181,15 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
             assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
             for b in (0, 150, 300):
                 assert np.array_equal(got[1][b], O.ntt_ext(x[b], length)), b
+            # rows that are not 16-byte aligned cannot be fetched by LDS-DMA: the default policy takes the two-pass kernels for them
+            ck(lib.cuhe_hip_set_onewg(1, 2))
+            flat = gu.to_dev(np.concatenate((np.zeros(1, dtype=np.uint32), x.reshape(-1))))
+            dX = gu.empty_u64(batch, length)
+            ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), flat.data_ptr() + 4, length, batch, length // 2, 0, None))
+            assert np.array_equal(gu.host_u64(dX), got[0])
+            ck(lib.cuhe_hip_set_onewg(1, 2))
     finally:
         ck(lib.cuhe_hip_set_ll_rows(24))
-        ck(lib.cuhe_hip_set_onewg(1, 0))
+        ck(lib.cuhe_hip_set_onewg(1, 2))
         if o is not None:
             o.close()
