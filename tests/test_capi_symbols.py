@@ -82,3 +82,30 @@ def test_degree_65536_ring_parameters(capi):
 def test_drivers_fail_loudly_without_init(capi):
     assert capi.lib.cuhe_hip_get_crt_primes(None, 0) != 0
     assert b"not initialised" in capi.lib.cuhe_hip_last_error()
+
+
+@pytest.mark.parametrize("args", [(25, 2, 16, 576, 24, 65536), (3, 2, 8, 40, 20, 1155)])
+def test_key_range_covers_the_owned_primes_at_every_level(capi, args):
+    """cuhe_hip_key_range (host logic only): the range a participant of the CRT-prime-sharded multiply has to hold contains
+    its block of every level (cuhe_hip_shard_bounds), and the ranges of all participants together cost little more than one
+    copy of the keys (the evaluation keys are partitioned with the primes)."""
+    from cuhe_amd.sharded import shard_bounds
+    capi.lib.cuhe_hip_reset_parameters()
+    capi.check(capi.lib.cuhe_hip_set_parameters(*args))
+    q = capi.get_params()
+    f, c, kf, kc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    for n in range(1, min(9, q.numCrtPrime - q.depth + 2)):
+        total = 0
+        for r in range(n):
+            capi.check(capi.lib.cuhe_hip_key_range(n, r, C.byref(kf), C.byref(kc)))
+            total += kc.value
+            for lvl in range(q.depth):
+                npl = capi.lib.cuhe_hip_num_crt_prime(lvl)
+                if npl < n:
+                    continue
+                capi.check(capi.lib.cuhe_hip_shard_bounds(lvl, n, r, C.byref(f), C.byref(c)))
+                assert (f.value, c.value) == shard_bounds(npl, n, r)
+                assert kf.value <= f.value and f.value + c.value <= kf.value + kc.value, (n, r, lvl)
+        assert q.numCrtPrime <= total <= q.numCrtPrime + (q.depth - 1) * (n - 1), (n, total)
+    assert capi.lib.cuhe_hip_key_range(0, 0, C.byref(kf), C.byref(kc)) != 0
+    capi.lib.cuhe_hip_reset_parameters()
