@@ -1,5 +1,5 @@
-// ntt_onewg.cuh -- ONE-WORKGROUP transforms: a whole sub-transform of Lh = 8K / 16K / 32K points lives in the registers of
-// one workgroup (32 values per thread, T = Lh/32 threads), three shift-only register stages 32 x R x 32 (R = 8 / 16 / 32),
+// ntt_onewg.cuh -- ONE-WORKGROUP transforms: a whole sub-transform of Lh = 4K / 8K / 16K / 32K points lives in the registers of
+// one workgroup (32 values per thread, T = Lh/32 threads), three shift-only register stages 32 x R x 32 (R = 4 / 8 / 16 / 32),
 // two general twiddle multiplications per point, two exchanges through LDS -- ONE launch, no slab in HBM: a transform's
 // bytes cross the memory system once in and once out (the two-pass scheme of ntt_kernels.cuh writes and re-reads a
 // u64[L] slab per transform, 2.6x the algorithmic traffic at 64K points).
@@ -8,7 +8,8 @@
 // cuhe/Operations.cu:306-398).  The zero-padded forward transform of the reference contract (u32[L/2] -> u64[L],
 // cuhe/Base.cu:309-437) is done as its two decimation-in-frequency halves: the outputs of parity h are the L/2-point
 // transform of x[j] W^(j h), W = w_L -- W^(a T) = 2^(3a) is a shift of the samples, W^m joins the stage-1 twiddle table --
-// one workgroup per half (HALF mode), both halves of a transform on one XCD.
+// one workgroup per half (HALF mode), both halves of a transform on one XCD.  The halves write alternate 8-byte words of the
+// same lines: only stores issued close together in time meet in L2, which is why the persistent form lets the pair meet first.
 //
 // Dataflow (tests/onewg_model.py is the executable statement of the index formulas; tests/test_onewg_model.py pins it to
 // the oracle):
@@ -17,13 +18,16 @@
 //   stage 2  B[i][kb] = DFT_R_b(y[i]) * TW2[32 kb + c]                                                 (w_T^(c kb))
 //   X2       -> thread t3 = ka + 32 kb: z[c] = B_{(kq, c), i}[kb]
 //   stage 3  Y[t3 + T kc] = DFT32_c(z), stored through the same epilogues as pass 2 (ntt_kernels.cuh: pass2_store)
-// Each exchange moves half of every thread's values at a time (the LDS holds half a transform: 1 / 2 / 4 workgroups
-// per CU at 32K / 16K / 8K points); rows are padded to odd strides (R + 1, 33 u64): conflict-free on both sides.
+// Each exchange moves half of every thread's values at a time (the LDS holds half a transform: 1 / 2 / 4 / 7 workgroups
+// per CU at 32K / 16K / 8K / 4K points); rows are padded to odd strides (R + 1, 33 u64): conflict-free on both sides.  At
+// R = 32 the exchanges use a layout whose read side is balanced and unconditional (ow32_*: stage-2 thread kq + 32 c).
 //
 // Two kernels share the stages: ntt_onewg (one workgroup per sub-transform: 2 / 4 of them overlap on a CU at 16K / 8K
 // points) and ntt_onewg_stream (32K-point halves of the 64K-point zero-padded transform, where only ONE workgroup fits a
-// CU: a persistent workgroup walks over its share of the batch and the u32 samples of the NEXT half arrive in the idle
-// exchange buffer by LDS-DMA while stage 3 of the current one computes and stores).
+// CU: a persistent workgroup walks over its share of the batch, the u32 samples of the NEXT half arrive in the idle
+// exchange buffer by LDS-DMA while stage 3 of the current one computes and stores, and the two workgroups of a row meet
+// before their stores: 2.71-2.78 M transforms/s against 2.54-2.64 for the two-pass pair, 0.81 MB instead of 1.71 MB per
+// transform at the L2/fabric boundary; profiles/r03_onewg_ab.txt).
 #pragma once
 #include "ntt_kernels.cuh"
 
