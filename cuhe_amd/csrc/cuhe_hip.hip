@@ -88,10 +88,11 @@ struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = 
 // tables of the one-workgroup transforms (ntt_onewg.cuh) of Lh = 2^(13 + index) points
 struct OwTab {
     u64 *TW1f = nullptr, *TW1i = nullptr, *TW1h = nullptr, *TW2 = nullptr;      // forward, inverse (x Lh^-1), both parities of the zero-padded form, stage 2
+    u64 *TW1g = nullptr; u64 c128 = 0; int i4neg = 0;                           // 32K points only: halves of the negacyclic 64K-point forward transform (ensure_onewg_twist64)
     std::atomic<int> ready{0};
     OwTab() {}
-    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), ready(o.ready.load()) {}
-    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; ready.store(o.ready.load()); return *this; }
+    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), TW1g(o.TW1g), c128(o.c128), i4neg(o.i4neg), ready(o.ready.load()) {}
+    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; TW1g = o.TW1g; c128 = o.c128; i4neg = o.i4neg; ready.store(o.ready.load()); return *this; }
 };
 struct DevCtx {
     bool ready = false;
@@ -401,6 +402,27 @@ int ensure_onewg(OwTab &tab, int lgh) {
     tab.ready.store(1, std::memory_order_release);
     return CUHE_OK;
 }
+// tables of the two 32K-point halves of the NEGACYCLIC forward transform of 64K points (ntt_onewg.cuh: StreamTwist):
+// TW1g[h][ka 1024 + m] = psi^(m (1 + 2h + 4 ka)), c128 = psi^1024, i4 = psi^32768 = +-2^48; psi = root_2len(65536)
+int ensure_onewg_twist64(OwTab &tab) {
+    CHK(ensure_onewg(tab, 15));
+    std::lock_guard<std::mutex> lk(G_.mu);
+    if (tab.TW1g) return CUHE_OK;
+    const u64 psi = host::root_2len(65536);
+    if (!psi) return fail(CUHE_EINVAL, "no primitive 2^17-th root of unity found");
+    std::vector<u64> r((size_t)1 << 17);
+    r[0] = 1;
+    for (size_t i = 1; i < r.size(); ++i) r[i] = host::mulP(r[i - 1], psi);
+    const u64 i4 = r[32768], p48 = (u64)1 << 48;
+    if (i4 != p48 && i4 != host::P - p48) return fail(CUHE_EINVAL, "psi^32768 is not +-2^48");
+    std::vector<u64> g(2 * (size_t)32768);
+    for (int h = 0; h < 2; ++h)
+        for (int ka = 0; ka < 32; ++ka)
+            for (int m = 0; m < 1024; ++m) g[(size_t)h * 32768 + (size_t)ka * 1024 + m] = r[((long)m * (1 + 2 * h + 4 * ka)) & ((1 << 17) - 1)];
+    CHK(upload(&tab.TW1g, g));
+    tab.c128 = r[1024]; tab.i4neg = i4 == p48 ? 0 : 1;
+    return CUHE_OK;
+}
 int onewg_launch(int lgh, int mode, int out, bool half, const OwArgs &a, hipStream_t st) {
     hipError_t e = lgh == 12 ? ow_launch_12(mode, out, half, a, st) : lgh == 13 ? ow_launch_13(mode, out, half, a, st)
                  : lgh == 14 ? ow_launch_14(mode, out, half, a, st) : ow_launch_15(mode, out, half, a, st);
@@ -508,6 +530,20 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         const int grid64 = D.cus & ~15;
         const bool stream_ok = rows64 && mode == kSrcU32Ext && grid64 >= 16 && wgs >= 2L * grid64 && ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
         const bool rows64_onewg = G_.onewg64 == 1 || (G_.onewg64 == 2 && stream_ok);
+        // negacyclic forward transform of full 64K-point rows (the ciphertext domain of x^65536 + 1): the persistent form, two
+        // 32K-point halves per row meeting before their interleaved stores, from two halves per workgroup on (or forced)
+        if (LG == 16 && mode == kSrcU32Twist && !mul_tab && G_.onewg && G_.onewg64 == 2 && grid64 >= 16 &&
+            (G_.onewg == 2 || 2L * batch >= 2L * grid64) && ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0) {
+            OwTab &ot = D.ow[3];
+            CHK(ensure_onewg_twist64(ot));
+            OwArgs a{dst, src, ot.TW1g, ot.TW2, src_stride, dst_stride, batch, nstore, wa, nullptr, D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, nullptr};
+            if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+            if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, 128 * sizeof(unsigned)));
+            hipError_t he = ow_launch_stream(kSrcU32Twist, kOutU64, a, grid64, D.pair_cnt, ot.c128, ot.i4neg, st);
+            if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (negacyclic rows): %s", hipGetErrorString(he));
+            if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+            return CUHE_OK;
+        }
         if ((G_.onewg || LG == 13) && lgh <= 15 && fills && (!rows64 || rows64_onewg)) {
             int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
             if (mode == kSrcU64Neg || mode == kSrcU64NegMul) {
@@ -533,7 +569,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 const bool stream = G_.onewg64 == 2 && stream_ok;
                 if (stream) {
                     if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, 128 * sizeof(unsigned)));
-                    hipError_t he = ow_launch_stream(out, a, grid, D.pair_cnt, st);
+                    hipError_t he = ow_launch_stream(kSrcU32Ext, out, a, grid, D.pair_cnt, 0, 0, st);
                     if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform: %s", hipGetErrorString(he));
                 } else CHK(onewg_launch(lgh, mode, out, half, a, st));
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }

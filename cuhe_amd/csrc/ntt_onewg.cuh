@@ -288,6 +288,29 @@ void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64
     }
 }
 
+// ---- full-length NEGACYCLIC forward transform of 64K points (the ciphertext domain of x^65536 + 1) as two 32K-point halves:
+//   X[2k + h] = sum_{j < 32K} u_h[j] w_32K^(j k),   u_h[j] = (x[j] + (-1)^h i4 x[j + 32K]) psi^((1 + 2h) j),
+// psi the primitive 2^17-th root (psi^2 = w_64K), i4 = psi^32768 = +-2^48.  With j = 1024 a + m:
+// psi^((1 + 2h) 1024 a) = c^((1 + 2h) a), c = psi^1024 a 128-th root with c^2 = 8 -- a shift, times c when the exponent is odd
+// (16 of the 32 samples of a thread, in BOTH halves: equal work) -- and psi^((1 + 2h) m) joins the stage-1 table,
+// TW1g[h][ka 1024 + m] = psi^(m (1 + 2h + 4 ka)).
+template <int K>
+__device__ __forceinline__ u64 mulpow2(u64 v) {           // v * 2^K, K in [0, 192)
+    if constexpr (K >= 96) return negp(shlp<K - 96>(v));
+    else return shlp<K>(v);
+}
+template <int H, int A>
+struct StreamTwist {                                      // x[a] *= c^((1 + 2H) a)
+    static __device__ __forceinline__ void run(u64 (&x)[32], u64 c) {
+        constexpr int e = (1 + 2 * H) * A;
+        u64 v = mulpow2<(3 * (e >> 1)) % 192>(x[A]);
+        if constexpr (e & 1) v = mulp(v, c);
+        x[A] = v;
+        if constexpr (A + 1 < 32) StreamTwist<H, A + 1>::run(x, c);
+    }
+};
+struct StreamTwistArgs { u64 c128; int i4neg; };            // c = psi^1024; i4neg: psi^32768 = -2^48 (else +2^48)
+
 // ---- persistent form for the 32K-point halves of the 64K-point zero-padded forward transform (u32 rows).
 // Work item i = 2 * transform + parity, in the order of ntt_onewg's blocks; workgroup g takes items g, g + grid, ...
 // The u32 samples of an item (128 KB) arrive by LDS-DMA in the exchange buffer, which is idle from the last read of
@@ -299,10 +322,14 @@ __device__ __forceinline__ void glds16(const void *gsrc, u32 lds_byte_addr) {   
 }
 // H: the parity this workgroup produces.  The grid is a multiple of 16 workgroups, so that the parity (item >> 3) & 1 is the
 // same for every item of a workgroup and the odd half's sample shifts sit on a straight-line path.
-template <int OUT, int H>
+// SRC = kSrcU32Ext: the zero-padded transform (32K samples per row); kSrcU32Twist: the negacyclic transform of a full row of 64K
+// samples -- the lower 32K by LDS-DMA like the zero-padded form, the upper 32K straight from global memory, requested before
+// the wait for the DMA.
+template <int SRC, int OUT, int H>
 __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, u64 *buf, const u64 *tw2,
                                                long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod,
-                                               unsigned *pair_cnt, int *give_up) {
+                                               unsigned *pair_cnt, int *give_up, StreamTwistArgs ta) {
+    static_assert(SRC == kSrcU32Ext || SRC == kSrcU32Twist, "row sources of the persistent form");
     constexpr int R = 32;
     using G = OwGeom<R>;
     constexpr int T = G::T, Lh = G::Lh;
@@ -325,12 +352,18 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
     int round = 0;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int batch = (item >> 4) * 8 + (item & 7);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // every wave's part of the samples has landed
         // an offset the compiler cannot see through, new in every iteration: otherwise the ~100 loop-invariant table and
         // LDS addresses of the body are hoisted out of the loop and live across it (600+ bytes of spills per lane)
         int opaque = 0;
         asm volatile("" : "+v"(opaque));
+        u32 xh[32];
+        if constexpr (SRC == kSrcU32Twist) {
+            const u32 *hi = src + (long)min(batch, nbatch - 1) * src_stride + Lh + t + opaque;
+#pragma unroll
+            for (int a = 0; a < 32; ++a) xh[a] = hi[a * T];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every wave's part of the samples has landed
         u64 *lb = buf + opaque;
         u64 x[32], y[32], z[32];
         {
@@ -339,8 +372,17 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
             for (int a = 0; a < 32; ++a) x[a] = in[a * T];
         }
         __syncthreads();                                   // samples are in registers: the buffer is free for exchange 1
-        if constexpr (H) HalfShift<0>::run(x);
-        ow32_stage1_x1(x, y, lb, TW1 + (long)H * Lh + t + opaque, H != 0, t);
+        if constexpr (SRC == kSrcU32Twist) {
+            const bool neg = ((H ^ ta.i4neg) & 1) != 0;   // the sign of (-1)^h i4 / 2^48
+#pragma unroll
+            for (int a = 0; a < 32; ++a) {
+                u64 sft = shlp32<48>(xh[a]);
+                if (neg) sft = negp(sft);
+                x[a] = addp(x[a], sft);
+            }
+            StreamTwist<H, 0>::run(x, ta.c128);
+        } else if constexpr (H) HalfShift<0>::run(x);
+        ow32_stage1_x1(x, y, lb, TW1 + (long)H * Lh + t + opaque, H != 0 || SRC == kSrcU32Twist, t);
         ow32_stage2_x2(y, z, lb, tw2 + opaque, t, true);
         if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);      // the buffer is idle until exchange 1 of the next item
         // Rendezvous with the workgroup that computes the OTHER parity of this row (block ^ 8: same XCD, same round): the two
@@ -368,10 +410,11 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
         ++round;
     }
 }
-template <int OUT>
+template <int SRC, int OUT>
 __global__ __launch_bounds__(1024, 4)
 void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
-                      long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod, unsigned *pair_cnt) {
+                      long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod, unsigned *pair_cnt,
+                      StreamTwistArgs ta) {
     using G = OwGeom<32>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     u64 *buf = lds;
@@ -379,8 +422,8 @@ void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, cons
     __shared__ int give_up;
     tw2[threadIdx.x] = TW2[threadIdx.x];
     if (threadIdx.x == 0) give_up = 0;
-    if ((blockIdx.x >> 3) & 1) ow_stream_loop<OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up);
-    else ow_stream_loop<OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up);
+    if ((blockIdx.x >> 3) & 1) ow_stream_loop<SRC, OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
+    else ow_stream_loop<SRC, OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
 }
 
 }  // namespace cuhe

@@ -21,8 +21,10 @@ hipError_t ow_launch_12(int mode, int out, bool half, const OwArgs &a, hipStream
 hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
-// kSrcU32Ext rows of 64K-point transforms; pair_cnt: grid / 2 counters for the rendezvous of the two halves of a row (or null)
-hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st);
+// persistent form for rows of 64K points: kSrcU32Ext (zero-padded forward, a.TW1 = the parity tables) or kSrcU32Twist
+// (negacyclic forward of full rows, a.TW1 = the twisted tables, c128 = psi^1024, i4neg: psi^32768 = -2^48);
+// pair_cnt: grid / 2 counters for the rendezvous of the two halves of a row (or null)
+hipError_t ow_launch_stream(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
 bool ow_supported(int mode, int out, bool half);
 
 }  // namespace cuhe

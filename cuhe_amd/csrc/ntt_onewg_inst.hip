@@ -67,13 +67,13 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
     return hipErrorInvalidValue;
 }
 #if CUHE_OW_LGH == 15
-// persistent form of the 32K-point halves of the 64K-point zero-padded forward transform (ntt_onewg_stream): `grid`
-// workgroups (a multiple of 16, at most one per CU) walk over the 2 * batch halves
-hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st) {
-    if (out != kOutU64 && out != kOutU64Mul) return hipErrorInvalidValue;
-    if (grid < 16 || (grid & 15)) return hipErrorInvalidValue;
-    auto k0 = ntt_onewg_stream<kOutU64>;
-    auto k1 = ntt_onewg_stream<kOutU64Mul>;
+// persistent form of the 32K-point halves of a 64K-point row (ntt_onewg_stream): `grid` workgroups (a multiple of 16, at most
+// one per CU) walk over the 2 * batch halves.  mode kSrcU32Ext: the zero-padded forward transform (a.TW1 = u64[2][32768], the
+// parity tables of the half mode); kSrcU32Twist: the negacyclic forward transform of full rows (a.TW1 = the twisted tables,
+// c128 / i4neg the two constants of the twist).
+template <int SRC, int OUT>
+static hipError_t launch_stream(const OwArgs &a, int grid, unsigned *pair_cnt, StreamTwistArgs ta, hipStream_t st) {
+    auto kern = ntt_onewg_stream<SRC, OUT>;
     static std::mutex mu; static std::atomic<uint64_t> done{0};
     int cur = 0;
     hipError_t e = hipGetDevice(&cur);
@@ -82,8 +82,7 @@ hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, unsigned *pair_c
     if (!(done.load(std::memory_order_acquire) & bit)) {
         std::lock_guard<std::mutex> lk(mu);
         if (!(done.load(std::memory_order_relaxed) & bit)) {
-            e = hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
+            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
             if (e != hipSuccess) return e;
             done.fetch_or(bit, std::memory_order_release);
         }
@@ -92,11 +91,17 @@ hipError_t ow_launch_stream(int out, const OwArgs &a, int grid, unsigned *pair_c
         e = hipMemsetAsync(pair_cnt, 0, (size_t)(grid / 2) * sizeof(unsigned), st);
         if (e != hipSuccess) return e;
     }
-    if (out == kOutU64)
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod, pair_cnt);
-    else
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch, a.xtab, a.prime0, a.np_mod, pair_cnt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
+                       a.xtab, a.prime0, a.np_mod, pair_cnt, ta);
     return hipGetLastError();
+}
+hipError_t ow_launch_stream(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st) {
+    if (grid < 16 || (grid & 15)) return hipErrorInvalidValue;
+    const StreamTwistArgs ta{c128, i4neg};
+    if (mode == kSrcU32Ext && out == kOutU64) return launch_stream<kSrcU32Ext, kOutU64>(a, grid, pair_cnt, ta, st);
+    if (mode == kSrcU32Ext && out == kOutU64Mul) return launch_stream<kSrcU32Ext, kOutU64Mul>(a, grid, pair_cnt, ta, st);
+    if (mode == kSrcU32Twist && out == kOutU64) return launch_stream<kSrcU32Twist, kOutU64>(a, grid, pair_cnt, ta, st);
+    return hipErrorInvalidValue;
 }
 bool ow_supported(int mode, int out, bool half) {
     if (half) return (mode == kSrcU32Ext && (out == kOutU64 || out == kOutU64Mul)) || (mode == kSrcWindow && out == kOutU64);

@@ -1094,10 +1094,11 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
     o = O.Ctx(*args) if name != "n65536" else None
     res = {}
     try:
-        for form, onewg in ((NONE, 0), (ALL, 0), (NONE, 2)):
+        # (rows64k = 2 with the one-workgroup form forced: the persistent kernels also take the negacyclic 64K-point rows of x^65536 + 1)
+        for form, onewg, r64 in ((NONE, 0, 0), (ALL, 0, 0), (NONE, 2, 1)) + (((NONE, 2, 2),) if name in ("n65536", "c3_65536") else ()):
             g = gu.GpuCtx(*args)
             ck(lib.cuhe_hip_set_ll_rows(form))
-            ck(lib.cuhe_hip_set_onewg(onewg, 1))
+            ck(lib.cuhe_hip_set_onewg(onewg, r64))
             try:
                 q = g.prm
                 K, W0, M0 = q.numEvalKey, g.words(0), g.coeff_modulus(0)
