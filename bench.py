@@ -84,6 +84,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     single_dev = os.environ.get("CUHE_BENCH_SINGLE_DEVICE") == "1"
+    if os.environ.get("CUHE_BENCH_WATCHDOG"):      # a stuck rank prints every thread's stack and exits (the launcher then stops the others)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CUHE_BENCH_WATCHDOG"]), exit=True)
     if single_dev:
         local_rank = 0                      # test hook: every rank on device 0 (use with --dist-backend gloo)
     if world > 1:
@@ -144,7 +147,7 @@ def main():
     sharded = None
     if world > 1 and not args.no_mulrelin:
         try:
-            sharded = bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args)
+            sharded = bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, single_dev)
         except Exception as ex:                      # never lose the headline line to the secondary figure
             sharded = {"error": repr(ex)[:300]}
         ck(lib.cuhe_hip_ntt_prepare(L, 0))
@@ -373,7 +376,7 @@ def bench_prince(world, single_dev):
         return {"error": repr(ex)[:300]}
 
 
-def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
+def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, single_dev=False):
     """primes of ONE ciphertext sharded over the ranks, one all-gather (CRT rows before ICRT) per
     multiply+relinearise; value = multiplies per second of the whole job (max time over ranks).  The whole chain, RCCL
     all-gather included, is one C-ABI call per multiply (cuhe_hip_mul_relin_sharded) enqueued on the compute stream;
@@ -419,7 +422,9 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
     idt = torch.zeros(129, dtype=torch.uint8, device=dev)
     if rank == 0:
         uid = (C.c_uint8 * 128)()
-        made = lib.cuhe_hip_comm_unique_id(uid) == 0
+        # every rank on ONE device (the gloo smoke test): RCCL refuses duplicate devices, and a communicator set-up that one rank
+        # has left while the other still waits in it has no time-out -- it is not attempted at all
+        made = (not single_dev) and lib.cuhe_hip_comm_unique_id(uid) == 0
         idt = torch.tensor(list(uid) + [1 if made else 0], dtype=torch.uint8, device=dev)
     dist.broadcast(idt, 0)
     host_id = [int(v) for v in idt.cpu().tolist()]
@@ -427,7 +432,7 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args):
     if ok:
         uid = (C.c_uint8 * 128)(*host_id[:128])
         ok = 1 if lib.cuhe_hip_comm_init(world, rank, uid) == 0 else 0
-    comm_err = None if ok else lib.cuhe_hip_last_error().decode()[:200]
+    comm_err = None if ok else ("every rank on one device" if single_dev else lib.cuhe_hip_last_error().decode()[:200])
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     in_library = int(flag.item()) == 1

@@ -166,12 +166,15 @@ def test_sharded_multiply_at_config4_size_on_2_4_5_8_virtual_devices(gu):
 def test_bench_two_ranks_on_one_gpu_runs_every_leg():
     """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --dist-backend gloo with both ranks on GPU 0:
     the N > 1 legs (sharded multiply with its exchange, replicated multiplies, PRINCE over two devices) complete."""
-    env = dict(os.environ, CUHE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CUHE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CUHE_BENCH_WATCHDOG="240")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
            "--no-cpu", "--batch", "1024"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=330)
+    except subprocess.TimeoutExpired as ex:        # a rank that stops answering dumps its stacks after 240 s (CUHE_BENCH_WATCHDOG)
+        pytest.fail("2-rank bench did not finish: " + str(ex.stderr or b"")[-3000:])
+    assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2

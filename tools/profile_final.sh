@@ -8,7 +8,7 @@
 export TMPDIR=/tmp
 tag=${2:-r03}
 out=$PWD/gpurun_out/final; mkdir -p $out
-if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
+if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q --durations=8 --timeout 400 2>&1 | tail -40 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
 timeout 600 python bench.py 2>/dev/null | tail -1 > $out/bench_n1.json
 python - <<PY
 import json; d = json.load(open("$out/bench_n1.json")); r = d["roofline"]
@@ -27,7 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
 done
 # the batched multiply + relinearise call alone (config 4, 32 ciphertexts per call): per-kernel time, then the HBM
 # counters of its inner-product kernel
-timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pf_batched -o s -- python $R/tools/trace_batched.py 32 10 > $out/batched_trace.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pf_batched -o s -- python $R/tools/trace_batched.py 32 10 2>&1 | grep -v "^[WEI][0-9]\{8\} " > $out/batched_trace.txt
 python $R/tools/rocpd_summary.py /tmp/pf_batched/s_results.db 2>&1 | head -16 | cut -c1-84,112-200 >> $out/batched_trace.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c -d /tmp/pf_b$c -o p -- python $R/tools/trace_batched.py 32 3 > /dev/null 2>&1
