@@ -73,3 +73,22 @@ def test_device_code_has_no_sgpr_hazards():
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:]
     assert "findings: 0" in r.stdout
+
+
+def test_checker_rejects_a_matrix_core_result_that_overlaps_its_operands():
+    """Second rule (profiles/r03_mac_tile_experiments.txt): the destination of a v_mfma must not share registers with its A / B
+    source -- hipcc allows it for 128-bit results, MI355X then returned wrong values in the overlapping registers."""
+    import asm_hazard_check as H
+    bad = """_Z1kv:
+	v_mfma_i32_16x16x32_i8 v[98:101], v[98:99], v[160:161], v[108:111]
+	v_mfma_i32_16x16x64_i8 v[102:105], v[70:73], v[102:105], v[78:81]
+	v_mfma_f32_32x32x8_f16 a[0:15], a[16:17], a[2:3], a[0:15]
+"""
+    found = H.check_mfma_overlap(bad.split("\n"))
+    assert len(found) == 3 and "source A" in found[0] and "source B" in found[1], found
+    good = """_Z1kv:
+	v_mfma_i32_16x16x32_i8 v[98:101], v[102:103], v[160:161], v[98:101]
+	v_mfma_i32_16x16x64_i8 v[66:69], v[70:73], v[2:5], v[100:103]
+	v_mfma_f32_32x32x8_f16 a[0:15], v[0:1], v[2:3], a[0:15]
+"""
+    assert H.check_mfma_overlap(good.split("\n")) == []

@@ -10,6 +10,10 @@ and replays the rule over EVERY instruction of every kernel (not only the asm si
 that every SGPR it reads was last written by a VALU instruction at least two wait states earlier (an instruction = one
 wait state, s_nop N = N + 1; an SALU write in between clears the hazard: SALU -> VALU is interlocked).  Branches and
 labels are followed: a read at a loop head or behind a taken branch sees the writes of every predecessor.
+Second rule (found on hardware, round 3): the destination registers of a v_mfma must not overlap its A / B source registers.
+hipcc lets the result of v_mfma_i32_16x16x32_i8 start in the two registers of its 64-bit A operand when that operand dies
+there; on MI355X the first two result registers then came out wrong (k_relin_mac_mfma_t32, ciphertext rows 4g, 4g + 1 of every
+tile).  The kernels keep their operands alive past the instruction (`keep_alive` in ops_kernels.cuh); this check keeps it so.
 Exit code 0 = clean.  usage: tools/asm_hazard_check.py [extra hipcc flags] | --asm file.s
 cuhe_amd/build.py runs it after compiling and refuses to keep a library whose code has findings."""
 import os, re, subprocess, sys, tempfile
@@ -29,6 +33,32 @@ def sregs(tok):
     m = re.fullmatch(r"s(\d+)", tok)
     if m: return {int(m.group(1))}
     return set()
+
+
+def vrange(tok):
+    """(file, first, last) of a VGPR / AGPR operand, None for anything else"""
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok.strip())
+    if m: return m.group(1), int(m.group(2)), int(m.group(3))
+    m = re.fullmatch(r"([va])(\d+)", tok.strip())
+    if m: return m.group(1), int(m.group(2)), int(m.group(2))
+    return None
+
+
+def check_mfma_overlap(lines):
+    found, func = [], "?"
+    for ln, raw in enumerate(lines, 1):
+        m = re.match(r"^(_Z\w+):", raw)
+        if m: func = m.group(1); continue
+        t = raw.split(";")[0].strip()
+        if not t.startswith("v_mfma"): continue
+        ops = t.split(None, 1)
+        args = [a.strip() for a in ops[1].split(",")]
+        d = vrange(args[0])
+        for name, a in (("A", args[1]), ("B", args[2])):
+            r = vrange(a)
+            if d and r and d[0] == r[0] and not (d[2] < r[1] or r[2] < d[1]):
+                found.append("%s line %d: '%s': destination overlaps source %s" % (func[:50], ln, t, name))
+    return found
 
 
 def check(lines):
@@ -122,7 +152,7 @@ def main(argv):
     findings, asm_sites, reads = [], 0, 0
     for lines in listings:
         f, a, r = check(lines)
-        findings += f; asm_sites += a; reads += r
+        findings += f + check_mfma_overlap(lines); asm_sites += a; reads += r
     for f in findings[:40]: print(f)
     print("asm sites: %d, VALU instructions reading an SGPR / VCC: %d, findings: %d" % (asm_sites, reads, len(findings)))
     return 1 if findings else 0
