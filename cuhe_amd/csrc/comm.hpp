@@ -8,7 +8,7 @@
 //    primes is not a multiple of the number of ranks, so the gather is a group of ncclBroadcast calls (root r sends its
 //    block in place) rather than one ncclAllGather.
 //  * one process driving several devices (the reference's multiGPUs(n) model, cuhe/CuHE.cu:217-256): peer copies over
-//    xGMI ordered by events (cuhe_hip.hip, cuhe_hip_mul_relin_sharded_inproc) -- every block goes straight over the
+//    xGMI ordered by events (cuhe_keyswitch.hip, cuhe_hip_mul_relin_sharded_inproc) -- every block goes straight over the
 //    link between its two devices, which is what a direct all-gather of 0.2-1.5 MiB blocks amounts to on a fully
 //    connected xGMI topology, and it also runs on the virtual devices the single-GPU tests use.
 #pragma once

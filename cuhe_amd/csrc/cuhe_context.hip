@@ -1,0 +1,550 @@
+// cuhe_context.hip -- the library's state behind the C ABI (include/cuhe_hip.h): parameters, device tables, per-thread
+// workspaces, the pooled allocator, streams.  Replaces cuhe/DeviceManager.cu and the upload half of cuhe/Base.cu
+// (cuhe/Base.cu:40-305, cuhe/DeviceManager.cu:40-138).  One of three translation units: cuhe_transforms.hip (NTT launch
+// sequencing), cuhe_keyswitch.hip (CRT / ICRT, relinearisation, batched and sharded chains).
+#include "cuhe_internal.hpp"
+#include "comm.hpp"
+
+namespace cuhe_impl {
+
+// ------------------------------------------------------------------ errors
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+Global G_;
+
+int set_dev(int dev) {
+    if (dev < 0 || dev >= G_.ndev) return fail(CUHE_EINVAL, "device %d out of range (numGPUs=%d)", dev, G_.ndev);
+    HIPCHK(hipSetDevice(phys_dev(dev)));
+    if ((int)G_.dev.size() < G_.ndev) {            // (multi_gpus / init size it already; kept for callers that skip them)
+        std::lock_guard<std::mutex> lk(G_.mu);
+        if ((int)G_.dev.size() < G_.ndev) G_.dev.resize(G_.ndev);
+    }
+    return CUHE_OK;
+}
+
+// the calling thread's workspace on `dev`, ordered after whatever this thread last enqueued with it
+// A thread has kLanes workspaces per device: lane 0 is the one every entry point uses; lanes 1.. exist only while a
+// batched relinearisation spreads groups of ciphertexts over helper streams (tls_lane selects the lane for everything
+// the group's stages fetch through workspace_of_thread).
+thread_local int tls_lane = 0;
+struct TlsSpaces {
+    uint64_t gen = 0;
+    std::vector<Workspace *> lanes[kLanes];
+    ~TlsSpaces();                                 // a finished thread hands its workspaces to later threads
+};
+TlsSpaces::~TlsSpaces() {
+    std::lock_guard<std::mutex> lk(G_.mu);
+    if (gen != G_.generation) return;             // the library was shut down since: already freed
+    for (auto &per_dev : lanes)
+        for (size_t d = 0; d < per_dev.size() && d < G_.dev.size(); ++d)
+            if (per_dev[d]) G_.dev[d].idle.push_back(per_dev[d]);
+}
+thread_local TlsSpaces tls_spaces;
+int workspace_of_thread(int dev, Workspace **out) {
+    TlsSpaces &T = tls_spaces;
+    if (T.gen != G_.generation) { for (auto &v : T.lanes) v.clear(); T.gen = G_.generation; }
+    std::vector<Workspace *> &per_dev = T.lanes[tls_lane];
+    if ((int)per_dev.size() <= dev) per_dev.resize(dev + 1, nullptr);
+    Workspace *w = per_dev[dev];
+    if (!w) {
+        {
+            std::lock_guard<std::mutex> lk(G_.mu);
+            auto &idle = G_.dev[dev].idle;
+            if (!idle.empty()) { w = idle.back(); idle.pop_back(); }
+        }
+        if (w) {                                  // adopted from a finished thread: its last work may still be in flight
+            HIPCHK(hipDeviceSynchronize());
+            w->used = false; w->last = nullptr;
+        } else {
+            w = new Workspace();
+            HIPCHK(hipEventCreateWithFlags(&w->ev, hipEventDisableTiming));
+            std::lock_guard<std::mutex> lk(G_.mu);
+            G_.dev[dev].spaces.push_back(w);
+        }
+        per_dev[dev] = w;
+    }
+    *out = w;
+    return CUHE_OK;
+}
+int workspace(int dev, hipStream_t st, Workspace **out) {
+    Workspace *w = nullptr;
+    CHK(workspace_of_thread(dev, &w));
+    if (w->used && w->last != st) {               // same thread, other stream: keep the scratch hazards ordered
+        if (hipEventRecord(w->ev, w->last) == hipSuccess) HIPCHK(hipStreamWaitEvent(st, w->ev, 0));
+        else { (void)hipGetLastError(); HIPCHK(hipDeviceSynchronize()); }     // the previous stream no longer exists
+    }
+    w->last = st; w->used = true;
+    *out = w;
+    return CUHE_OK;
+}
+// Barrett / inttResult scratch for `rows` polynomial rows (at least one level-0 ciphertext)
+int ws_barrett(Workspace &w, int rows) {
+    const Params &q = G_.prm;
+    const size_t need = (size_t)std::max(rows, q.numCrtPrime);
+    if (w.n_barrett >= need && w.hold) return CUHE_OK;
+    size_t a = 0, b = 0, c = 0, d = 0;
+    CHK(ws_grow(&w.b_mq, &a, need * q.nttLen)); CHK(ws_grow(&w.b_crt, &b, need * q.nttLen));
+    CHK(ws_grow(&w.b_ntt, &c, need * q.nttLen)); CHK(ws_grow(&w.hold, &d, need * q.nttLen));
+    w.n_barrett = need;
+    return CUHE_OK;
+}
+// window rows and their transforms for `cts` ciphertexts
+int ws_relin(Workspace &w, int cts) {
+    const Params &q = G_.prm;
+    if (w.n_relin >= (size_t)cts && w.relin) return CUHE_OK;
+    size_t a = 0, b = 0;
+    if (w.relin) { HIPCHK(hipFree(w.relin)); w.relin = nullptr; }
+    if (w.win) { HIPCHK(hipFree(w.win)); w.win = nullptr; }
+    CHK(ws_grow(&w.relin, &a, (size_t)cts * q.numEvalKey * q.nttLen)); CHK(ws_grow(&w.win, &b, (size_t)cts * q.numEvalKey * q.crtLen));
+    w.n_relin = cts;
+    return CUHE_OK;
+}
+int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        // grow-only
+    if (w.slab_bytes[li][which] < bytes) {
+        if (w.slab[li][which]) HIPCHK(hipFree(w.slab[li][which]));            // (synchronises: rare, sizes settle at once)
+        w.slab[li][which] = nullptr; w.slab_bytes[li][which] = 0;
+        HIPCHK(hipMalloc((void **)&w.slab[li][which], bytes));
+        w.slab_bytes[li][which] = bytes;
+    }
+    *out = w.slab[li][which];
+    return CUHE_OK;
+}
+void free_workspace(Workspace *w) {
+    for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
+    void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->mr_ntt, w->mr_crt,
+                    w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (w->ev) hipEventDestroy(w->ev);
+    if (w->ev_lane) hipEventDestroy(w->ev_lane);
+    if (w->ev_in) hipEventDestroy(w->ev_in);
+    if (w->lane_stream) hipStreamDestroy(w->lane_stream);
+    delete w;
+}
+
+
+// ------------------------------------------------------------------ helpers
+int need_init(int dev) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "cuhe_hip_init has not been called");
+    CHK(set_dev(dev));
+    if (!G_.dev[dev].ready) return fail(CUHE_ENOTINIT, "device %d not initialised", dev);
+    return CUHE_OK;
+}
+int level_of(int logq, int *lvl, int *np, int *W) {
+    const Params &q = G_.prm;
+    *lvl = q.getLevel(logq);
+    if (*lvl >= q.depth) return fail(CUHE_EINVAL, "logq %d maps to level %d >= depth %d", logq, *lvl, q.depth);
+    *np = q.numCrtPrimeAt(*lvl);
+    *W = q.wordsCoeff(*lvl);
+    return CUHE_OK;
+}
+
+// PrimeTab whose row 0 is prime `prime0` (CRT-prime-sharded calls address their own rows from 0)
+PrimeTab prime_tab_at(const DevCtx &D, int prime0) {
+    return PrimeTab{D.p + prime0, D.pinv + prime0, D.e64 + prime0, D.pow32 + (size_t)prime0 * D.maxW, D.maxW};
+}
+
+int init_device(int dev) {
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    const Params &q = G_.prm;
+    const int pnum = q.numCrtPrime, L = q.nttLen, n = q.modLen, cl = q.crtLen;
+    // ---- prime tables (preload_crt_p / preload_crt_invp: cuhe/Base.cu:145-160)
+    // rows padded to a multiple of 8 words and kCrtPB zero rows appended: k_crt reads the table in unguarded blocks
+    D.maxW = (q.wordsCoeff(0) + 1 + 7) & ~7;
+    std::vector<u32> hp(G_.primes), he(pnum), hpow((size_t)(pnum + kCrtPB) * D.maxW, 0), hinv((size_t)pnum * (pnum - 1) / 2 + 1, 0);
+    std::vector<u64> hpi(pnum);
+    for (int i = 0; i < pnum; ++i) {
+        const u32 p = hp[i];
+        hpi[i] = (u64)(((host::u128)1 << 64) / p);
+        he[i] = (u32)((((host::u128)1) << 64) % p);
+        u64 c = 1 % p;
+        for (int k = 0; k <= q.wordsCoeff(0); ++k) { hpow[(size_t)i * D.maxW + k] = (u32)c; c = (c << 32) % p; }
+    }
+    for (int i = 1; i < pnum; ++i)                                 // cuhe/Operations.cu:91-99
+        for (int j = 0; j < i; ++j) hinv[(size_t)i * (i - 1) / 2 + j] = host::invmod32(hp[i] % hp[j], hp[j]);
+    CHK(upload(&D.p, hp)); CHK(upload(&D.pinv, hpi)); CHK(upload(&D.e64, he));
+    CHK(upload(&D.pow32, hpow)); CHK(upload(&D.invp, hinv));
+    // ---- ICRT constants for every level, all resident (cuhe/Operations.cu:107-156)
+    D.icrt.resize(q.depth);
+    for (int lvl = 0; lvl < q.depth; ++lvl) {
+        IcrtLevel &I = D.icrt[lvl];
+        I.np = pnum - lvl; I.W = q.wordsCoeff(lvl);
+        const BigU &M = G_.coeffModulus[lvl];
+        const int W4 = (I.W + 3) & ~3, np8 = (I.np + 7) & ~7;        // padded for k_icrt's unguarded scalar blocks
+        std::vector<u32> hM(I.W), hmi((size_t)np8 * W4, 0), hbi(I.np);
+        std::vector<double> hrp(I.np);
+        M.to_words(hM.data(), I.W);
+        for (int i = 0; i < I.np; ++i) {
+            BigU mi = M.div_small(hp[i]);
+            mi.to_words(&hmi[(size_t)i * W4], I.W);
+            hbi[i] = host::invmod32(mi.mod_small(hp[i]), hp[i]);
+            hrp[i] = 1.0 / (double)hp[i];
+        }
+        CHK(upload(&I.M, hM)); CHK(upload(&I.mi, hmi)); CHK(upload(&I.bi, hbi)); CHK(upload(&I.rp, hrp));
+    }
+    // ---- transforms + scratch (initNtt: cuhe/Operations.cu:173-184)
+    CHK(ensure_ntt(dev, L, pnum));
+    if (G_.nc) CHK(ensure_twist(dev, n));
+    if (q.ncOnly()) {                    // no cyclic representation, hence no Barrett tables (the ring has x^n + 1 only)
+        HIPCHK(hipDeviceSynchronize());
+        D.ready = true;
+        return CUHE_OK;
+    }
+    // ---- Barrett (initBarrett: cuhe/Operations.cu:196-238)
+    HIPCHK(hipMalloc((void **)&D.u_ntt, (size_t)pnum * L * sizeof(u64)));
+    HIPCHK(hipMalloc((void **)&D.m_ntt, (size_t)pnum * L * sizeof(u64)));
+    std::vector<long long> u;
+    if (!host::barrett_u(G_.modulus, u)) return fail(CUHE_EINVAL, "polynomial modulus has unbounded Barrett quotient");
+    std::vector<u32> hu((size_t)pnum * cl, 0), hm((size_t)pnum * cl, 0);
+    for (int i = 0; i < pnum; ++i)
+        for (int k = 0; k < n; ++k) {
+            hu[(size_t)i * cl + k] = host::smod(u[k], hp[i]);
+            hm[(size_t)i * cl + k] = host::smod(G_.modulus[k], hp[i]);   // m - x^n: coefficient n dropped
+        }
+    CHK(upload(&D.m_crt, hm));
+    u32 *tmp = nullptr;
+    CHK(upload(&tmp, hu));
+    WindowArgs wa{0, 0, 0};
+    // folded form of the generic reduction (barrett_impl): applicable when the half-length transform exists
+    // (Lh >= 16384) and the quotient fits its half-length input
+    {
+        const int m = q.mSize, Lh = L / 2, Dg = (m < 2 * n - 1) ? m : 2 * n - 1, Kq = Dg - n;
+        D.fold_ok = G_.reduce_kind == 0 && lg_index(Lh) >= 0 && Kq >= 1 && Kq <= Lh / 2 && Kq <= n - 1 && n <= Lh;
+        if (D.fold_ok) {
+            D.fold = FoldGeom{n, m, Dg, Kq, Lh};
+            std::vector<u64> huh((size_t)pnum * Lh), hmh((size_t)pnum * Lh);
+            std::vector<uint64_t> a(Lh);
+            for (int i = 0; i < pnum; ++i) {
+                std::fill(a.begin(), a.end(), 0);
+                for (int j = 0; j < Kq; ++j) a[j] = host::smod(u[n - 1 - j], hp[i]);          // inverse series of rev(Phi), Kq terms
+                host::ntt_host(a, Lh);
+                for (int t = 0; t < Lh; ++t) huh[(size_t)i * Lh + t] = (u64)a[t];
+                std::fill(a.begin(), a.end(), 0);
+                for (int k = 0; k <= n; ++k) {                                                // Phi mod (x^Lh - 1)
+                    const uint32_t c = k < n ? host::smod(G_.modulus[k], hp[i]) : 1u;
+                    a[k % Lh] = (a[k % Lh] + c) % hp[i];
+                }
+                host::ntt_host(a, Lh);
+                for (int t = 0; t < Lh; ++t) hmh[(size_t)i * Lh + t] = (u64)a[t];
+            }
+            CHK(upload(&D.uh_ntt, huh)); CHK(upload(&D.mh_ntt, hmh));
+            CHK(ensure_ntt(dev, Lh, pnum));
+        }
+    }
+    CHK(run_ntt(L, kSrcU32Ext, D.u_ntt, tmp, pnum, cl, L, L, 0, wa, dev, 0));
+    CHK(run_ntt(L, kSrcU32Ext, D.m_ntt, D.m_crt, pnum, cl, L, L, 0, wa, dev, 0));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(tmp));
+    D.ready = true;
+    return CUHE_OK;
+}
+
+}  // namespace cuhe_impl
+
+using namespace cuhe_impl;
+
+extern "C" {
+
+
+const char *cuhe_hip_last_error(void) { return g_err.c_str(); }
+const char *cuhe_hip_version(void) { return "cuhe_amd 0.1 (gfx950)"; }
+
+int cuhe_hip_set_parameters(int d, int p, int w, int min, int cut, int m) {
+    if (d < 1 || p < 2 || w < 0 || w > 31 || min < 1 || cut < 1 || m < 3)
+        return fail(CUHE_EINVAL, "setParameters(%d,%d,%d,%d,%d,%d): invalid", d, p, w, min, cut, m);
+    G_.prm.set(d, p, w, min, cut, m);
+    if (lg_index(G_.prm.nttLen) < 0)
+        return fail(CUHE_EINVAL, "ring degree %d needs nttLen %d (supported: 16384/32768/65536; degree 65536 only as m = 131072, x^65536 + 1)", G_.prm.modLen, G_.prm.nttLen);
+    if (G_.prm.numCrtPrime > 103 * 4) return fail(CUHE_EINVAL, "too many CRT primes (%d)", G_.prm.numCrtPrime);
+    G_.params_set = true;
+    return CUHE_OK;
+}
+int cuhe_hip_reset_parameters(void) { G_.prm = Params(); G_.params_set = false; return CUHE_OK; }
+int cuhe_hip_get_parameters(cuhe_params_t *o) {
+    if (!o) return fail(CUHE_EINVAL, "null");
+    const Params &q = G_.prm;
+    *o = cuhe_params_t{q.mSize, q.modLen, q.modLen2, q.rawLen, q.crtLen, q.nttLen, q.logCoeffMax, q.logCoeffMin,
+                       q.logCoeffCut, q.depth, q.modMsg, q.logMsg, q.wordsMsg, q.logRelin, q.numEvalKey,
+                       q.logCrtPrime, q.numCrtPrime};
+    return CUHE_OK;
+}
+int cuhe_hip_num_crt_prime(int lvl) { return G_.prm.numCrtPrimeAt(lvl); }
+int cuhe_hip_log_coeff(int lvl) { return G_.prm.logCoeff(lvl); }
+int cuhe_hip_words_coeff(int lvl) { return G_.prm.wordsCoeff(lvl); }
+int cuhe_hip_num_eval_key(int lvl) { return G_.prm.numEvalKeyAt(lvl); }
+int cuhe_hip_get_level(int logq) { return G_.prm.getLevel(logq); }
+
+int cuhe_hip_multi_gpus(int num) {
+    int cnt = 0;
+    HIPCHK(hipGetDeviceCount(&cnt));
+    if (num < 1 || (!G_.virtual_devices && G_.dev_base + num > cnt)) return fail(CUHE_EINVAL, "multiGPUs(%d): %d device(s) visible", num, cnt);
+    if (G_.inited) return fail(CUHE_EINVAL, "multiGPUs must precede initCuHE (cuhe/DeviceManager.cu:38-41)");
+    G_.ndev = num;
+    G_.dev.resize(num);
+    return CUHE_OK;
+}
+int cuhe_hip_num_gpus(void) { return G_.ndev; }
+// test hook: with `on`, multi_gpus(n) accepts any n and every logical device is backed by the one physical device,
+// each with its own context (tables, keys, allocator, workspaces) -- the in-process multi-device code paths
+// (per-device indexing, moveTo / copyTo) can then be exercised on a single-GPU box
+int cuhe_hip_set_virtual_devices(int on) {
+    if (G_.inited) return fail(CUHE_EINVAL, "set_virtual_devices must precede init");
+    G_.virtual_devices = on != 0;
+    return CUHE_OK;
+}
+int cuhe_hip_set_device_base(int dev) {
+    if (G_.inited) return fail(CUHE_EINVAL, "set_device_base must precede init");
+    G_.dev_base = dev;
+    return CUHE_OK;
+}
+
+int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
+    if (!G_.params_set) return fail(CUHE_EINVAL, "setParameters must precede initCuHE");
+    if (G_.inited) return fail(CUHE_EINVAL, "already initialised");
+    const Params &q = G_.prm;
+    if (modulus) {
+        if (ncoeffs != q.modLen + 1 || modulus[q.modLen] != 1)
+            return fail(CUHE_EINVAL, "modulus must be monic of degree modLen=%d", q.modLen);
+        G_.modulus.assign(modulus, modulus + ncoeffs);
+    } else {
+        G_.modulus = host::cyclotomic(q.mSize);
+        if ((int)G_.modulus.size() != q.modLen + 1) return fail(CUHE_EINVAL, "cyclotomic(%d) degree mismatch", q.mSize);
+    }
+    // which exact reduction applies
+    {
+        const int n = q.modLen;
+        bool xn1 = (G_.modulus[0] == 1), ones = true;
+        for (int i = 1; i < n; ++i) { if (G_.modulus[i] != 0) xn1 = false; }
+        for (int i = 0; i <= n; ++i) { if (G_.modulus[i] != 1) ones = false; }
+        G_.reduce_kind = xn1 ? 1 : (ones ? 2 : 0);
+    }
+    G_.primes = host::gen_crt_primes(q);                           // cuhe/Operations.cu:37-80
+    // negacyclic ciphertext domain: modulus x^n + 1, n a transform length, and the centred lift must be unambiguous:
+    // a product coefficient is a signed sum of n terms below p^2 (2 n p^2 < P), a key-switch sum one of k n terms below 2^w p
+    {
+        const int n = q.modLen;
+        host::u128 pmax = 0;
+        for (uint32_t p : G_.primes) pmax = std::max<host::u128>(pmax, p);
+        const bool shape = G_.reduce_kind == 1 && lg_index(n) >= 0 && q.crtLen == n;
+        const bool bound = 2 * (host::u128)n * (pmax - 1) * (pmax - 1) < host::P &&
+                           (!q.logRelin || 2 * (host::u128)q.numEvalKey * n * (((host::u128)1 << q.logRelin) - 1) * (pmax - 1) < host::P);
+        G_.nc = G_.nc_mode != 0 && shape && bound;
+        if (q.ncOnly() && !G_.nc)
+            return fail(CUHE_EINVAL, "ring degree %d needs the negacyclic representation: modulus x^n + 1, primes with 2 n p^2 < P%s", n,
+                        G_.nc_mode == 0 ? " (and cuhe_hip_set_negacyclic(0) is in effect)" : "");
+    }
+    G_.coeffModulus.assign(q.depth, BigU(1));                      // cuhe/Operations.cu:81-90
+    for (int i = 0; i < q.depth; ++i)
+        for (int j = 0; j < q.numCrtPrime - i; ++j) G_.coeffModulus[i].mul_small(G_.primes[j]);
+    G_.dev.resize(G_.ndev);
+    G_.inited = true;
+    for (int dev = 0; dev < G_.ndev; ++dev) {
+        int r = init_device(dev);
+        if (r != CUHE_OK) { G_.inited = false; return r; }
+    }
+    for (int i = 0; i < G_.ndev && !G_.virtual_devices; ++i) {      // cuhe/CuHE.cu:42-45 peer access
+        hipSetDevice(G_.dev_base + i);
+        for (int j = 0; j < G_.ndev; ++j)
+            if (i != j) { int can = 0; hipDeviceCanAccessPeer(&can, G_.dev_base + i, G_.dev_base + j);
+                          if (can) hipDeviceEnablePeerAccess(G_.dev_base + j, 0); }
+    }
+    (void)hipGetLastError();
+    return CUHE_OK;
+}
+
+int cuhe_hip_is_initialised(void) { return G_.inited ? 1 : 0; }
+int cuhe_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(G_.mu);
+    for (int d = 0; d < (int)G_.dev.size(); ++d) {
+        if (hipSetDevice(phys_dev(d)) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (void)hipDeviceSynchronize();
+        DevCtx &D = G_.dev[d];
+        for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); hipFree(t.Wn1); t = NttTab(); }
+        if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
+        if (D.sh_stream) { hipStreamDestroy(D.sh_stream); hipEventDestroy(D.sh_e1); hipEventDestroy(D.sh_e2); }
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek, D.ekd, D.pair_cnt};
+        for (auto &t : D.ow) { hipFree(t.TW1f); hipFree(t.TW1i); hipFree(t.TW1h); hipFree(t.TW2); hipFree(t.TW1g); }
+        for (Workspace *w : D.spaces) free_workspace(w);
+        for (void *p : ptrs) if (p) hipFree(p);
+        for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
+        for (auto &kv : D.freeBlocks) hipFree(kv.second);
+        for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) hipFree(kv.second);     // parked in stream order
+        for (auto &kv : D.allocated) hipFree(kv.first);
+        D = DevCtx();
+    }
+    G_.inited = false; G_.relin_ready = false; G_.allocator_on = false;
+    ++G_.generation;
+    return CUHE_OK;
+}
+
+int cuhe_hip_get_coeff_modulus(int lvl, uint8_t *le, size_t cap, size_t *len) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
+    if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    const BigU &M = G_.coeffModulus[lvl];
+    size_t nb = M.w.size() * 4;
+    if (len) *len = nb;
+    if (cap < nb) return fail(CUHE_EINVAL, "buffer too small");
+    memcpy(le, M.w.data(), nb);
+    return CUHE_OK;
+}
+int cuhe_hip_get_crt_primes(uint32_t *out, int cap) {
+    if (!G_.inited) return fail(CUHE_ENOTINIT, "not initialised");
+    if (cap < (int)G_.primes.size()) return fail(CUHE_EINVAL, "buffer too small");
+    memcpy(out, G_.primes.data(), G_.primes.size() * 4);
+    return CUHE_OK;
+}
+int cuhe_hip_reduce_kind(void) { return G_.force_generic ? 0 : G_.reduce_kind; }
+int cuhe_hip_force_generic_reduce(int on) { G_.force_generic = on != 0; G_.no_fold = on == 2; return CUHE_OK; }
+
+// ---------------------------------------------------------------- allocator
+int cuhe_hip_start_allocator(void) { G_.allocator_on = true; return CUHE_OK; }   // no "grab all VRAM" 
+static void drop_cached(DevCtx &D) {
+    for (auto &kv : D.freeBlocks) hipFree(kv.second);            // (hipFree waits for the device: in-flight users are safe)
+    D.freeBlocks.clear();
+    for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) hipFree(kv.second);
+    D.streamBlocks.clear();
+    D.cachedBytes = 0;
+}
+// blocks freed in stream order become ordinary free blocks once that stream has been synchronised
+static void settle_stream_blocks(DevCtx &D, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.streamBlocks.find(st);
+    if (it == D.streamBlocks.end()) return;
+    for (auto &kv : it->second) D.freeBlocks.insert(kv);
+    D.streamBlocks.erase(it);
+}
+int cuhe_hip_stop_allocator(void) {
+    G_.allocator_on = false;
+    std::lock_guard<std::mutex> lk(G_.mu);
+    for (int d = 0; d < (int)G_.dev.size(); ++d) {
+        if (hipSetDevice(phys_dev(d)) != hipSuccess) { (void)hipGetLastError(); continue; }
+        drop_cached(G_.dev[d]);
+    }
+    return CUHE_OK;
+}
+int cuhe_hip_set_alloc_cache(size_t bytes) { G_.cache_cap = bytes; return CUHE_OK; }
+// Size-keyed block cache.  hipMalloc/hipFree cost tens to hundreds of microseconds and hipFree synchronises the
+// device, which is more than a whole CRT or NTT stage of a ciphertext takes, and the API allocates and frees a
+// representation on every domain change (cuhe/CuHE.cu:356-408).  Freed blocks are therefore parked and handed out
+// again for the same size: without limit while startAllocator() is in effect, up to cache_cap bytes otherwise.
+void *cuhe_hip_malloc(int dev, size_t bytes) {
+    if (set_dev(dev) != CUHE_OK) return nullptr;
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.freeBlocks.find(bytes);
+    if (it != D.freeBlocks.end()) {
+        void *p = it->second;
+        D.freeBlocks.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+        return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        drop_cached(D);                                   // give the parked blocks back and try once more
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(CUHE_EHIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    }
+    D.allocated[p] = bytes;
+    return p;
+}
+int cuhe_hip_free(int dev, void *ptr) {
+    if (!ptr) return CUHE_OK;
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.allocated.find(ptr);
+    if (it == D.allocated.end()) return fail(CUHE_EINVAL, "free of unknown pointer");
+    const size_t sz = it->second;
+    D.allocated.erase(it);
+    if (G_.allocator_on || D.cachedBytes + sz <= G_.cache_cap) { D.freeBlocks.insert({sz, ptr}); D.cachedBytes += sz; }
+    else HIPCHK(hipFree(ptr));
+    return CUHE_OK;
+}
+// Stream-ordered variants: a block freed with free_stream may still be in use by work already enqueued on `st`, so it
+// is handed out again only to allocations made for the SAME stream (which run after that work) until the stream has
+// been synchronised through cuhe_hip_stream_sync.  This is what lets a caller enqueue a whole chain of ciphertext
+// operations without a host synchronisation after each (the C++ layer's setAsynchronous(true)).
+void *cuhe_hip_malloc_stream(int dev, size_t bytes, void *st) {
+    if (set_dev(dev) != CUHE_OK) return nullptr;
+    DevCtx &D = G_.dev[dev];
+    {
+        std::lock_guard<std::mutex> lk(G_.mu);
+        auto sb = D.streamBlocks.find(S(st));
+        if (sb != D.streamBlocks.end()) {
+            auto it = sb->second.find(bytes);
+            if (it != sb->second.end()) {
+                void *p = it->second;
+                sb->second.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+                return p;
+            }
+        }
+    }
+    return cuhe_hip_malloc(dev, bytes);
+}
+int cuhe_hip_free_stream(int dev, void *ptr, void *st) {
+    if (!ptr) return CUHE_OK;
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    auto it = D.allocated.find(ptr);
+    if (it == D.allocated.end()) return fail(CUHE_EINVAL, "free of unknown pointer");
+    const size_t sz = it->second;
+    D.allocated.erase(it);
+    if (G_.allocator_on || D.cachedBytes + sz <= G_.cache_cap) { D.streamBlocks[S(st)].insert({sz, ptr}); D.cachedBytes += sz; }
+    else HIPCHK(hipFree(ptr));
+    return CUHE_OK;
+}
+// pinned host staging memory for the ZZX <-> raw conversions of the C++ layer (cuhe/CuHE.cu:317-348 uses pageable)
+void *cuhe_hip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(CUHE_EHIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+int cuhe_hip_host_free(void *ptr) { if (ptr) HIPCHK(hipHostFree(ptr)); return CUHE_OK; }
+int cuhe_hip_memset_async(int dev, void *p, int v, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemsetAsync(p, v, n, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_h2d(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_d2h(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_d2d(int dev, void *d, const void *s, size_t n, void *st) { CHK(set_dev(dev)); HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st))); return CUHE_OK; }
+int cuhe_hip_memcpy_peer(void *d, int dd, const void *s, int sd, size_t n, void *st) {
+    CHK(set_dev(sd));
+    if (dd < 0 || dd >= G_.ndev) return fail(CUHE_EINVAL, "device %d out of range (numGPUs=%d)", dd, G_.ndev);
+    if (G_.virtual_devices) HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, S(st)));
+    else HIPCHK(hipMemcpyPeerAsync(d, G_.dev_base + dd, s, G_.dev_base + sd, n, S(st)));
+    return CUHE_OK;
+}
+int cuhe_hip_stream_create(int dev, void **out) {
+    CHK(set_dev(dev));
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void *)s;
+    return CUHE_OK;
+}
+int cuhe_hip_stream_destroy(int dev, void *st) {
+    CHK(set_dev(dev));
+    if (st) { HIPCHK(hipStreamSynchronize(S(st))); settle_stream_blocks(G_.dev[dev], S(st)); HIPCHK(hipStreamDestroy(S(st))); }
+    return CUHE_OK;
+}
+int cuhe_hip_stream_sync(int dev, void *st) {
+    CHK(set_dev(dev));
+    HIPCHK(hipStreamSynchronize(S(st)));
+    settle_stream_blocks(G_.dev[dev], S(st));
+    return CUHE_OK;
+}
+
+// waits for everything enqueued on the device; every block freed in stream order becomes an ordinary free block
+int cuhe_hip_device_sync(int dev) {
+    CHK(set_dev(dev));
+    HIPCHK(hipDeviceSynchronize());
+    DevCtx &D = G_.dev[dev];
+    std::lock_guard<std::mutex> lk(G_.mu);
+    for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) D.freeBlocks.insert(kv);
+    D.streamBlocks.clear();
+    return CUHE_OK;
+}
+
+}  // extern "C"

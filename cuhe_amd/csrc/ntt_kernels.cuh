@@ -95,7 +95,7 @@ __device__ __forceinline__ void dft_regs(u64 (&x)[N]) {
 // kOutU64Mul: forward transform whose outputs are multiplied by a table row on the way out
 // (the pointwise product with a precomputed NTT-domain constant, fused: `pinv` carries the table, u64[prime][L])
 // kOutModPRevQ / kOutFoldFinal: the two inverse transforms of the folded generic reduction
-// (cuhe_hip.hip: barrett_impl) with the elementwise step that follows each of them done in the store:
+// (cuhe_transforms.hip: barrett_impl) with the elementwise step that follows each of them done in the store:
 //   RevQ      : the first Kq coefficients come out REVERSED (q[t] = C[Kq-1-t]) and zero up to Lh/2 -- the quotient, ready
 //               as input of the next forward transform;
 //   FoldFinal : r[i] = (g mod (x^Lh - 1))[i] - (q Phi mod (x^Lh - 1))[i] for i < n, zero up to the row length, with g the

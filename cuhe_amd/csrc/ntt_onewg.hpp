@@ -1,6 +1,6 @@
 // ntt_onewg.hpp -- host-side entry of the one-workgroup transforms (ntt_onewg.cuh).  The kernels are instantiated in
 // their own translation units (ntt_onewg_inst.hip, compiled once per sub-transform size) so that the sizes build in
-// parallel; cuhe_hip.hip calls them through ow_launch.
+// parallel; cuhe_transforms.hip calls them through ow_launch.
 #pragma once
 #include <hip/hip_runtime.h>
 

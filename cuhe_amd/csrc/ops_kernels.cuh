@@ -52,7 +52,7 @@ void k_ntt_binop_nx1(u64 *__restrict__ z, const u64 *__restrict__ x, const u64 *
 
 // ---------------------------------------------------------------- batched gate helpers (circuit evaluation on arrays)
 // dst[t] = src[ia[t]] (*) src[ib[t]] for t < npairs: ciphertexts are `rows` rows of L (NTT domain); blockIdx.y = t
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_ntt_mul_pairs(u64 *__restrict__ dst, const u64 *__restrict__ src, const int *__restrict__ ia, const int *__restrict__ ib, long ct_pairs) {
     const int t = blockIdx.y;
     const ulonglong2 *x = reinterpret_cast<const ulonglong2 *>(src) + (long)ia[t] * ct_pairs;
@@ -67,7 +67,7 @@ void k_ntt_mul_pairs(u64 *__restrict__ dst, const u64 *__restrict__ src, const i
 // dst[o] = sum of the CRT-domain ciphertexts srcs[list[t]] for t in [off[o], off[o+1])  (+ addc[o] on the constant
 // coefficient), residues mod p_i.  A list entry e < nA addresses srcA[e], otherwise srcB[e - nA].  blockIdx.y = prime
 // row, blockIdx.z = output.  This is a whole layer of cXor / cNot gates (CuHE.cu:122-215) in one launch.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_crt_combine(u32 *__restrict__ dst, const u32 *__restrict__ srcA, int nA, const u32 *__restrict__ srcB,
                    const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ addc,
                    PrimeTab pt, int np, int mlen, int clen) {
@@ -88,7 +88,7 @@ void k_crt_combine(u32 *__restrict__ dst, const u32 *__restrict__ srcA, int nA, 
 // inputs are residues < p_i, so (a+b)%p is one conditional subtract when a,b < p;
 // the reference uses % (Base.cu:1088-1109) which also accepts unreduced inputs --
 // we keep exact % semantics through mod_small.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_crt_add(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__restrict__ b,
                PrimeTab pt, int mlen, int clen) {
     const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,7 +96,7 @@ void k_crt_add(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__rest
     const long o = (long)crt * clen + idx;
     z[o] = mod_small((u64)a[o] + b[o], pt.p[crt], pt.pinv[crt]);
 }
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_crt_add_nx1(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__restrict__ s,
                    PrimeTab pt, int mlen, int clen) {
     const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,7 +105,7 @@ void k_crt_add_nx1(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__
     z[o] = mod_small((u64)a[o] + s[idx], pt.p[crt], pt.pinv[crt]);
 }
 // constant term only (Base.cu:1096-1100)
-__global__ void k_crt_add_int(u32 *__restrict__ z, const u32 *__restrict__ x, unsigned a,
+static __global__ void k_crt_add_int(u32 *__restrict__ z, const u32 *__restrict__ x, unsigned a,
                               PrimeTab pt, int np, int clen) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
@@ -114,7 +114,7 @@ __global__ void k_crt_add_int(u32 *__restrict__ z, const u32 *__restrict__ x, un
     z[(long)i * clen] = mod_small((u64)x[(long)i * clen] + mod_small(a, p, m), p, m);
 }
 // constant term times an integer (crt_mul_int, Base.cu:1078-1087)
-__global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict__ x, int a,
+static __global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict__ x, int a,
                               PrimeTab pt, int np, int clen) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
@@ -125,7 +125,7 @@ __global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict__ x, in
 // ---------------------------------------------------------------- modulus switching (Base.cu:1112-1138)
 // grid.y = target prime i < np-1.  dst may alias src (row i only depends on rows i and np-1,
 // and row np-1 is never written).
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt,
                  const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg, long src_ct_stride, long dst_ct_stride) {
     src += (long)blockIdx.z * src_ct_stride;         // blockIdx.z: ciphertext of a batched call (the result has np-1 rows,
@@ -155,7 +155,7 @@ void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt
 // of Base.cu:951-1001):  f = polynomial to reduce (row stride nlen, residues < p), qrow = quotient q stored at offset
 // mlen of its row, mq = ((m - x^n) q) mod p.  r = f - q x^n - (m - x^n) q has degree <= n; for idx < n the q x^n term
 // does not contribute, and the reference's correction subtracts m once more when the coefficient of x^n is non-zero.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32 *__restrict__ qrow, const u32 *__restrict__ mq,
                      const u32 *__restrict__ m_crt, PrimeTab pt, int mlen, int clen, int nlen, int np_mod) {
     const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,9 +179,9 @@ void k_barrett_final(u32 *__restrict__ dst, const u32 *__restrict__ f, const u32
     dst[(long)crt * clen + idx] = r;
 }
 
-// ---- folded form of the generic reduction (cuhe_hip.hip: barrett_impl; FoldGeom and fold_g live in ntt_kernels.cuh)
+// ---- folded form of the generic reduction (cuhe_transforms.hip: barrett_impl; FoldGeom and fold_g live in ntt_kernels.cuh)
 // A[j] = g[D-1-j] for j < Kq (the top of g, reversed), zero up to Lh/2: input of the half-length forward transform
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_fold_top_rev(u32 *__restrict__ A, const u32 *__restrict__ f, PrimeTab pt, FoldGeom G, int nlen, int np_mod) {
     const int crt = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= G.Lh / 2) return;
@@ -458,7 +458,7 @@ struct MacDigGeom {
 };
 static constexpr int kMacMfmaCols = 8, kMacMfmaCts = 16;
 // key digits: one thread per (column, prime slot, chunk of 16 / 8 windows); reads coalesced over columns
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_ek_digits(unsigned char *__restrict__ ekd, const u64 *__restrict__ ek, int K, int np, int L, long ek_prime_stride, MacDigGeom G) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int slot = blockIdx.y, pt = slot >> 4, n = slot & 15, i = slot;
@@ -665,7 +665,7 @@ void k_relin_mac_mfma(u64 *__restrict__ dst, const u64 *__restrict__ c, const un
 // ONCE, coalesced, through LDS and every window row is written coalesced, so that the k window transforms run on a
 // compact u32 array (the reference re-reads the W-word coefficients with stride W for every window).
 static constexpr int kWinCoef = 64, kWinGroups = 4;
-__global__ __launch_bounds__(kWinCoef * kWinGroups)
+static __global__ __launch_bounds__(kWinCoef * kWinGroups)
 void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W, int w, int k, int ncoef, int clen,
                        long raw_ct_stride, long win_ct_stride) {
     raw += (long)blockIdx.y * raw_ct_stride;         // blockIdx.y: ciphertext of a batched call
@@ -699,7 +699,7 @@ void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W
 // prime index is WAVE-UNIFORM, so the powers 2^(32k) mod p_i come in through scalar loads and every multiply-add is
 // one v_mad_u64_u32 with an SGPR operand plus one carry add; a word is read from LDS once per four primes.
 static constexpr int kCrtCoef = 64, kCrtGroups = 4, kCrtPB = 4;
-__global__ __launch_bounds__(kCrtCoef * kCrtGroups)
+static __global__ __launch_bounds__(kCrtCoef * kCrtGroups)
 void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen,
            long src_ct_stride, long dst_ct_stride) {
     src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: polynomial of a batched call (strides in words)
@@ -867,7 +867,7 @@ __device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, c
         if (k >= W) { k -= W; ++c2; }
     }
 }
-__global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
+static __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
             int np, int W, int mlen, int clen, long src_ct_stride, long dst_ct_stride, IcrtWindows wo) {
     src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: ciphertext of a batched call (strides in words)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Static instruction histogram of the device code: tools/isa_hist.py [kernel-name-substring ...]
-(hipcc --cuda-device-only -S of cuhe_amd/csrc/cuhe_hip.hip; counts per kernel, VALU per point for the 16-points-per-thread NTT kernels)."""
+(hipcc --cuda-device-only -S of cuhe_amd/csrc/cuhe_transforms.hip; counts per kernel, VALU per point for the 16-points-per-thread NTT kernels)."""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pats = sys.argv[1:] or ["ntt_pass1wILi16ELi0", "ntt_pass2wILi16ELi0"]
 with tempfile.TemporaryDirectory() as d:
     s = os.path.join(d, "dev.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only",
-                           "-S", "-o", s, os.path.join(ROOT, "cuhe_amd/csrc/cuhe_hip.hip"), "-I" + os.path.join(ROOT, "include")])
+                           "-S", "-o", s, os.path.join(ROOT, "cuhe_amd/csrc/cuhe_transforms.hip"), "-I" + os.path.join(ROOT, "include")])
     cur, H = None, {}
     for line in open(s):
         m = re.match(r"^(_Z\w+):", line)
