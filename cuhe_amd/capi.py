@@ -140,6 +140,7 @@ SIGNATURES = {
     "cuhe_hip_mul_relin_sharded_inproc": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_set_ll_rows": (i32, [i32]),
     "cuhe_hip_set_onewg": (i32, [i32, i32]),
+    "cuhe_hip_set_onewg_split": (i32, [i32]),
     "cuhe_hip_ntt_prepare": (i32, [i32, i32]),
     "cuhe_hip_set_ntt_chunk": (i32, [i32]),
     "cuhe_hip_set_ntt_overlap": (i32, [i32]),

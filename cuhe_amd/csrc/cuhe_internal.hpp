@@ -82,11 +82,12 @@ struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = 
 // tables of the one-workgroup transforms (ntt_onewg.cuh) of Lh = 2^(13 + index) points
 struct OwTab {
     u64 *TW1f = nullptr, *TW1i = nullptr, *TW1h = nullptr, *TW2 = nullptr;      // forward, inverse (x Lh^-1), both parities of the zero-padded form, stage 2
-    u64 *TW1g = nullptr; u64 c128 = 0; int i4neg = 0;                           // 32K points only: halves of the negacyclic 64K-point forward transform (ensure_onewg_twist64)
+    u64 *TW1hi = nullptr;                                                       // TW1h / (2 Lh): the halves of a SPLIT inverse row of 2 Lh points
+    u64 *TW1g = nullptr; u64 c128 = 0; int i4neg = 0;                           // halves of the negacyclic forward transform of 2 Lh points (ensure_onewg_twist)
     std::atomic<int> ready{0};
     OwTab() {}
-    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), TW1g(o.TW1g), c128(o.c128), i4neg(o.i4neg), ready(o.ready.load()) {}
-    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; TW1g = o.TW1g; c128 = o.c128; i4neg = o.i4neg; ready.store(o.ready.load()); return *this; }
+    OwTab(const OwTab &o) : TW1f(o.TW1f), TW1i(o.TW1i), TW1h(o.TW1h), TW2(o.TW2), TW1hi(o.TW1hi), TW1g(o.TW1g), c128(o.c128), i4neg(o.i4neg), ready(o.ready.load()) {}
+    OwTab &operator=(const OwTab &o) { TW1f = o.TW1f; TW1i = o.TW1i; TW1h = o.TW1h; TW2 = o.TW2; TW1hi = o.TW1hi; TW1g = o.TW1g; c128 = o.c128; i4neg = o.i4neg; ready.store(o.ready.load()); return *this; }
 };
 struct DevCtx {
     bool ready = false;
@@ -145,6 +146,9 @@ struct Global {
     // their stores, for calls that give every workgroup at least two halves (2.71 vs 2.56 M transforms/s,
     // profiles/r03_onewg_ab.txt); smaller calls and unaligned rows take the two-pass kernels
     int onewg64 = getenv("CUHE_ONEWG64") ? atoi(getenv("CUHE_ONEWG64")) : 2;
+    // full-length negacyclic rows as two half-length sub-transforms (32K points: two workgroups per CU instead of one), calls that
+    // fill the chip: 0 off, 1 (default) inverse rows of 32K points, 2 also forward rows of 32K and inverse rows of 64K points (tests, A/B)
+    int onewg_split = getenv("CUHE_ONEWG_SPLIT") ? atoi(getenv("CUHE_ONEWG_SPLIT")) : 1;
     bool ntt_overlap = false;     // measured: concurrent pass-1/pass-2 streams do not help (profiles/r01_chunk_sweep.txt)
     std::vector<DevCtx> dev;
     std::mutex mu;

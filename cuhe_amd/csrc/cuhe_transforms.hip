@@ -100,7 +100,8 @@ int ensure_onewg(OwTab &tab, int lgh) {
     r[0] = 1;
     for (size_t i = 1; i < r.size(); ++i) r[i] = host::mulP(r[i - 1], W);
     const u64 linv = host::powP((u64)Lh, host::P - 2);
-    std::vector<u64> f(Lh), fi(Lh), fh(2 * (size_t)Lh), t2(T);
+    const u64 l2inv = host::powP((u64)(2 * Lh), host::P - 2);
+    std::vector<u64> f(Lh), fi(Lh), fh(2 * (size_t)Lh), fhi(2 * (size_t)Lh), t2(T);
     for (int ka = 0; ka < 32; ++ka)
         for (int m = 0; m < T; ++m) {
             const size_t o = (size_t)ka * T + m;
@@ -108,32 +109,34 @@ int ensure_onewg(OwTab &tab, int lgh) {
             fi[o] = host::mulP(f[o], linv);
             fh[o] = f[o];
             fh[Lh + o] = r[((long)m * (2 * ka + 1)) % (2L * Lh)]; // W^(m (2 ka + 1)): the odd outputs of the zero-padded transform
+            fhi[o] = host::mulP(fh[o], l2inv); fhi[Lh + o] = host::mulP(fh[Lh + o], l2inv);
         }
     for (int kb = 0; kb < R; ++kb)
         for (int c = 0; c < 32; ++c) t2[(size_t)kb * 32 + c] = r[(64L * c * kb) % (2L * Lh)];      // w_T^(c kb) = w_Lh^(32 c kb)
-    CHK(upload(&tab.TW1f, f)); CHK(upload(&tab.TW1i, fi)); CHK(upload(&tab.TW1h, fh)); CHK(upload(&tab.TW2, t2));
+    CHK(upload(&tab.TW1f, f)); CHK(upload(&tab.TW1i, fi)); CHK(upload(&tab.TW1h, fh)); CHK(upload(&tab.TW1hi, fhi)); CHK(upload(&tab.TW2, t2));
     tab.ready.store(1, std::memory_order_release);
     return CUHE_OK;
 }
-// tables of the two 32K-point halves of the NEGACYCLIC forward transform of 64K points (ntt_onewg.cuh: StreamTwist):
-// TW1g[h][ka 1024 + m] = psi^(m (1 + 2h + 4 ka)), c128 = psi^1024, i4 = psi^32768 = +-2^48; psi = root_2len(65536)
-int ensure_onewg_twist64(OwTab &tab) {
-    CHK(ensure_onewg(tab, 15));
+// tables of the two Lh-point halves of the NEGACYCLIC forward transform of L = 2 Lh points (ntt_onewg.cuh: StreamTwist), T = Lh / 32:
+// TW1g[h][ka T + m] = psi^(m (1 + 2h + 4 ka)), c128 = psi^T, i4 = psi^Lh = +-2^48; psi = root_2len(L), the root of ensure_twist
+int ensure_onewg_twist(OwTab &tab, int lgh) {
+    CHK(ensure_onewg(tab, lgh));
     std::lock_guard<std::mutex> lk(G_.mu);
     if (tab.TW1g) return CUHE_OK;
-    const u64 psi = host::root_2len(65536);
-    if (!psi) return fail(CUHE_EINVAL, "no primitive 2^17-th root of unity found");
-    std::vector<u64> r((size_t)1 << 17);
+    const int Lh = 1 << lgh, T = Lh / 32;
+    const u64 psi = host::root_2len(2 * Lh);
+    if (!psi) return fail(CUHE_EINVAL, "no primitive 2^%d-th root of unity found", lgh + 2);
+    std::vector<u64> r((size_t)4 * Lh);
     r[0] = 1;
     for (size_t i = 1; i < r.size(); ++i) r[i] = host::mulP(r[i - 1], psi);
-    const u64 i4 = r[32768], p48 = (u64)1 << 48;
-    if (i4 != p48 && i4 != host::P - p48) return fail(CUHE_EINVAL, "psi^32768 is not +-2^48");
-    std::vector<u64> g(2 * (size_t)32768);
+    const u64 i4 = r[Lh], p48 = (u64)1 << 48;
+    if (i4 != p48 && i4 != host::P - p48) return fail(CUHE_EINVAL, "psi^%d is not +-2^48", Lh);
+    std::vector<u64> g(2 * (size_t)Lh);
     for (int h = 0; h < 2; ++h)
         for (int ka = 0; ka < 32; ++ka)
-            for (int m = 0; m < 1024; ++m) g[(size_t)h * 32768 + (size_t)ka * 1024 + m] = r[((long)m * (1 + 2 * h + 4 * ka)) & ((1 << 17) - 1)];
+            for (int m = 0; m < T; ++m) g[(size_t)h * Lh + (size_t)ka * T + m] = r[((long)m * (1 + 2 * h + 4 * ka)) & (4L * Lh - 1)];
     CHK(upload(&tab.TW1g, g));
-    tab.c128 = r[1024]; tab.i4neg = i4 == p48 ? 0 : 1;
+    tab.c128 = r[T]; tab.i4neg = i4 == p48 ? 0 : 1;
     return CUHE_OK;
 }
 int onewg_launch(int lgh, int mode, int out, bool half, const OwArgs &a, hipStream_t st) {
@@ -209,21 +212,51 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         const bool fills = LG == 13 || G_.onewg == 2 || (lgh >= 13 && lgh <= 15 && wgs >= (long)D.cus * (1 << (15 - lgh)));
         const bool rows64 = half && lgh == 15;
         const int grid64 = D.cus & ~15;
-        const bool stream_ok = rows64 && mode == kSrcU32Ext && grid64 >= 16 && wgs >= 2L * grid64 && ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
-        const bool rows64_onewg = G_.onewg64 == 1 || (G_.onewg64 == 2 && stream_ok);
+        // persistent form of the halves (every workgroup resident: 1 / 2 per CU at 32K / 16K points): from two halves per
+        // workgroup on, rows aligned for the LDS-DMA of their samples
+        // (32K-point rows: measured 3 % slower than one workgroup per half, 6.43 vs 6.64 M/s -- taken only when onewg64 = 3)
+        const int gridp = lgh == 15 || (lgh == 14 && G_.onewg64 == 3) ? (D.cus << (15 - lgh)) & ~15 : 0;
+        const bool stream_ok = half && mode == kSrcU32Ext && gridp >= 16 && gridp / 2 <= kOwPairCounters && wgs >= 2L * gridp &&
+                               ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
+        const bool rows64_onewg = G_.onewg64 == 1 || (G_.onewg64 >= 2 && stream_ok);
         // negacyclic forward transform of full 64K-point rows (the ciphertext domain of x^65536 + 1): the persistent form, two
         // 32K-point halves per row meeting before their interleaved stores, from two halves per workgroup on (or forced)
-        if (LG == 16 && mode == kSrcU32Twist && !mul_tab && G_.onewg && G_.onewg64 == 2 && grid64 >= 16 &&
+        if (LG == 16 && mode == kSrcU32Twist && !mul_tab && G_.onewg && G_.onewg64 >= 2 && grid64 >= 16 &&
             (G_.onewg == 2 || 2L * batch >= 2L * grid64) && ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0) {
             OwTab &ot = D.ow[3];
-            CHK(ensure_onewg_twist64(ot));
+            CHK(ensure_onewg_twist(ot, 15));
             OwArgs a{dst, src, ot.TW1g, ot.TW2, src_stride, dst_stride, batch, nstore, wa, nullptr, D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, nullptr};
             if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, 128 * sizeof(unsigned)));
-            hipError_t he = ow_launch_stream(kSrcU32Twist, kOutU64, a, grid64, D.pair_cnt, ot.c128, ot.i4neg, st);
+            if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, kOwPairCounters * sizeof(unsigned)));
+            hipError_t he = ow_launch_stream_15(kSrcU32Twist, kOutU64, a, grid64, D.pair_cnt, ot.c128, ot.i4neg, st);
             if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (negacyclic rows): %s", hipGetErrorString(he));
             if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
             return CUHE_OK;
+        }
+        // inverse negacyclic rows of 32K points (the ciphertext domain of x^32768 + 1), calls that fill the chip: SPLIT into the two
+        // 16K-point transforms of their even and odd outputs -- two workgroups per CU overlap where the 32K-point one-workgroup
+        // form runs alone: 366 / 440 us against 419 / 507 us per 1536 rows / product rows (profiles/r03_split_rows.txt).
+        // onewg_split = 2 (tests, A/B): also the forward rows of 32K points (measured equal: 519 vs 512 us per 2304 rows -- the
+        // pre-add and the sample twist cost what the overlap wins) and the inverse rows of 64K points (slower than the two passes)
+        const bool split_inv = mode == kSrcU64Neg || mode == kSrcU64NegMul;
+        if (G_.onewg && !half && !(ep && ep->kind) &&
+            ((LG == 15 && ((split_inv && G_.onewg_split >= 1) || (mode == kSrcU32Twist && G_.onewg_split == 2))) || (LG == 16 && split_inv && G_.onewg_split == 2)) &&
+            (G_.onewg == 2 || 2L * batch >= (long)D.cus * (1 << (16 - LG)))) {
+            int out = -1; const u64 *xt = nullptr;
+            if (mode == kSrcU32Twist) { out = mul_tab ? kOutU64Mul : kOutU64; xt = mul_tab; }
+            else if (nstore == kNcInverse) { out = kOutModPNc; xt = tab.twinv; }
+            if (out >= 0 && ow_split_supported(mode, out)) {
+                OwTab &ot = D.ow[LG - 1 - 12];
+                if (mode == kSrcU32Twist) CHK(ensure_onewg_twist(ot, LG - 1)); else CHK(ensure_onewg(ot, LG - 1));
+                if (mode == kSrcU64NegMul && !mul_tab) return fail(CUHE_EINVAL, "second operand missing");
+                if (out == kOutModPNc && !xt) return fail(CUHE_EINVAL, "negacyclic untwist table missing");
+                OwArgs a{dst, src, mode == kSrcU32Twist ? ot.TW1g : ot.TW1hi, ot.TW2, src_stride, dst_stride, batch, L, wa, mode == kSrcU64NegMul ? mul_tab : nullptr,
+                         D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, xt, ot.c128, ot.i4neg};
+                if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+                CHK(onewg_launch(LG - 1, mode, out, true, a, st));
+                if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+                return CUHE_OK;
+            }
         }
         if ((G_.onewg || LG == 13) && lgh <= 15 && fills && (!rows64 || rows64_onewg)) {
             int out, nst = nstore; const u64 *xt = nullptr; Epilogue e;
@@ -244,14 +277,14 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 OwArgs a{dst, src, half ? ot.TW1h : inv ? ot.TW1i : ot.TW1f, ot.TW2, mode == kSrcWindow ? 0 : src_stride, dst_stride, batch, nst, wa, tw,
                          D.p, D.pinv, prime0, np_mod, e.aux, e.aux_stride, e.fg, xt};
                 if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-                // 64K-point rows: one workgroup per CU walks over its share of the halves, the next half's samples arriving by
-                // LDS-DMA beside stage 3 of the current one (16-byte aligned rows, at least two halves per workgroup)
-                const int grid = grid64;
-                const bool stream = G_.onewg64 == 2 && stream_ok;
+                // resident workgroups walk over their share of the halves, the next half's samples arriving by LDS-DMA beside stage 3
+                // of the current one, the two halves of a row meeting before their interleaved stores
+                const bool stream = G_.onewg64 >= 2 && stream_ok;
                 if (stream) {
-                    if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, 128 * sizeof(unsigned)));
-                    hipError_t he = ow_launch_stream(kSrcU32Ext, out, a, grid, D.pair_cnt, 0, 0, st);
-                    if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform: %s", hipGetErrorString(he));
+                    if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, kOwPairCounters * sizeof(unsigned)));
+                    hipError_t he = lgh == 15 ? ow_launch_stream_15(kSrcU32Ext, out, a, gridp, D.pair_cnt, 0, 0, st)
+                                              : ow_launch_stream_14(kSrcU32Ext, out, a, gridp, D.pair_cnt, 0, 0, st);
+                    if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (2^%d-point halves): %s", lgh, hipGetErrorString(he));
                 } else CHK(onewg_launch(lgh, mode, out, half, a, st));
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 return CUHE_OK;
@@ -647,8 +680,13 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     G_.ntt_chunk = chunk;
     return CUHE_OK;
 }
+int cuhe_hip_set_onewg_split(int mode) {
+    if (mode < 0 || mode > 2) return fail(CUHE_EINVAL, "split mode %d", mode);
+    G_.onewg_split = mode;
+    return CUHE_OK;
+}
 int cuhe_hip_set_onewg(int mode, int rows64k) {
-    if (mode < 0 || mode > 2 || rows64k < 0 || rows64k > 2) return fail(CUHE_EINVAL, "mode %d, rows64k %d", mode, rows64k);
+    if (mode < 0 || mode > 2 || rows64k < 0 || rows64k > 3) return fail(CUHE_EINVAL, "mode %d, rows64k %d", mode, rows64k);
     G_.onewg = mode; G_.onewg64 = rows64k;
     return CUHE_OK;
 }

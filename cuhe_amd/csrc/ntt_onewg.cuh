@@ -37,8 +37,10 @@ template <int R>
 struct OwGeom {
     static constexpr int T = 32 * R, Lh = 32 * T, NP = 32 / R;
     static constexpr int X1W = 16 * 32 * (R + 1), X2W = (R / 2) * 32 * 33;
-    static constexpr int XW = R == 32 ? 32 * 545 : (X1W > X2W ? X1W : X2W);      // exchange buffer (u64 words); R = 32: the balanced layouts below
+    static constexpr int XWB = 32 * (32 * (R / 2 + 1) + 1) > R * 544 ? 32 * (32 * (R / 2 + 1) + 1) : R * 544;   // the balanced layouts (owb_*)
+    static constexpr int XW = R == 32 ? XWB : (X1W > X2W ? X1W : X2W);            // exchange buffer (u64 words); R = 32: balanced
     static constexpr size_t bytes = (size_t)(XW + T) * sizeof(u64);   // + the stage-2 twiddle table
+    static constexpr size_t bytes_stream = (size_t)(XWB + T) * sizeof(u64);       // persistent kernels: balanced at every size
 };
 
 // x * 2^K mod P for a sample below 2^32 (compile-time K < 96): nothing to reduce up to K = 32
@@ -166,44 +168,61 @@ __device__ __forceinline__ void ow_stage2_x2(u64 (&y)[32], u64 (&z)[32], u64 *bu
     }
 }
 
-// ---- R = 32 (32K points, one workgroup of 1024 threads per CU): exchanges whose READ side is unconditional and balanced
-// (tests/onewg_model.py: simulate32).  Stage-2 thread t2 = kq + 32 c.
-//   X1, half h: the waves with b in [16 h, 16 h + 16) (t = 32 b + c) store all 32 A[ka] -> buf[c 545 + ka 17 + (b - 16 h)];
-//               every reader (kq, c) takes its 16 values b
-//   X2, half h: the waves with c in [16 h, 16 h + 16) (t2 = kq + 32 c) store all 32 B[kb] -> buf[kb 544 + ka 17 + (c - 16 h)];
-//               every reader (ka, kb) takes its 16 values c
+// ---- exchanges whose READ side is unconditional and balanced (tests/onewg_model.py: simulate_balanced), R = 16 or 32: what
+// the 32K-point transform (one workgroup of 1024 threads per CU) and the persistent kernels use.  Stage-2 thread t2 = kq + R c.
+//   X1, round h: the waves with b in [h R/2, (h + 1) R/2) (t = 32 b + c) store all 32 A[ka] -> buf[c S1 + ka RW + (b - h R/2)],
+//                RW = R/2 + 1, S1 = 32 RW + 1; every reader (kq, c) takes its R/2 values b of each of its 32/R values ka
+//   X2, round h: the waves with c in [16 h, 16 h + 16) (t2 = kq + R c) store all 32 B[i][kb] -> buf[kb 544 + ka 17 + (c - 16 h)];
+//                every reader (ka, kb) takes its 16 values c
 // Every thread's y / z are assigned on every path, which also keeps them out of the loop-carried state of the persistent kernel.
-__device__ __forceinline__ void ow32_stage1_x1(u64 (&x)[32], u64 (&y)[32], u64 *buf, const u64 *__restrict__ t1, bool row0, int t) {
-    ow_dft_twiddle<1024>(x, t1, row0);
-    const int lo = t & 31, hi = t >> 5;                   // writer (b, c) = (hi, lo); reader (kq, c) = (lo, hi)
+template <int R>
+__device__ __forceinline__ void owb_stage1_x1(u64 (&x)[32], u64 (&y)[32], u64 *buf, const u64 *__restrict__ t1, bool row0, int t) {
+    static_assert(R == 16 || R == 32, "balanced exchanges: 16K / 32K points");
+    constexpr int T = 32 * R, NP = 32 / R, HB = R / 2, RW = HB + 1, S1 = 32 * RW + 1;
+    ow_dft_twiddle<T>(x, t1, row0);
+    const int c1 = t & 31, b1 = t >> 5;                   // writer (b, c)
+    const int kq = t % R, c2 = t / R;                     // reader (kq, c)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-        if ((hi >> 4) == hh) {                            // whole waves
-            u64 *wr = buf + lo * 545 + (hi & 15);
+        if ((b1 / HB) == hh) {                            // whole waves
+            u64 *wr = buf + c1 * S1 + (b1 % HB);
 #pragma unroll
-            for (int ka = 0; ka < 32; ++ka) wr[ka * 17] = x[bitrev<32>(ka)];
+            for (int ka = 0; ka < 32; ++ka) wr[ka * RW] = x[bitrev<32>(ka)];
         }
         __syncthreads();
-        const u64 *rd = buf + hi * 545 + lo * 17;
 #pragma unroll
-        for (int bl = 0; bl < 16; ++bl) y[16 * hh + bl] = rd[bl];
+        for (int i = 0; i < NP; ++i) {
+            const u64 *rd = buf + c2 * S1 + (kq + R * i) * RW;
+#pragma unroll
+            for (int bl = 0; bl < HB; ++bl) y[i * R + HB * hh + bl] = rd[bl];
+        }
         __syncthreads();
     }
 }
-__device__ __forceinline__ void ow32_stage2_x2(u64 (&y)[32], u64 (&z)[32], u64 *buf, const u64 *tw2, int t, bool last_sync) {
-    const int lo = t & 31, hi = t >> 5;                   // stage 2: (kq, c) = (lo, hi); stage 3: (ka, kb) = (lo, hi)
-    dft_regs<32, false>(y);
+template <int R>
+__device__ __forceinline__ void owb_stage2_x2(u64 (&y)[32], u64 (&z)[32], u64 *buf, const u64 *tw2, int t, bool last_sync) {
+    static_assert(R == 16 || R == 32, "balanced exchanges: 16K / 32K points");
+    constexpr int NP = 32 / R;
+    const int kq = t % R, c = t / R;                      // stage 2: (kq, c); stage 3: (ka, kb) = (t & 31, t >> 5)
 #pragma unroll
-    for (int kb = 1; kb < 32; ++kb) y[bitrev<32>(kb)] = mulp(y[bitrev<32>(kb)], tw2[32 * kb + hi]);
+    for (int i = 0; i < NP; ++i) {
+        u64 (&sub)[R] = *reinterpret_cast<u64(*)[R]>(&y[i * R]);
+        dft_regs<R, false>(sub);
+#pragma unroll
+        for (int kb = 1; kb < R; ++kb) sub[bitrev<R>(kb)] = mulp(sub[bitrev<R>(kb)], tw2[32 * kb + c]);
+    }
+    const int ka3 = t & 31, kb3 = t >> 5;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-        if ((hi >> 4) == hh) {                            // whole waves
-            u64 *wr = buf + lo * 17 + (hi & 15);
+        if ((c >> 4) == hh) {                             // whole waves
+            u64 *wr = buf + kq * 17 + (c & 15);
 #pragma unroll
-            for (int kb = 0; kb < 32; ++kb) wr[kb * 544] = y[bitrev<32>(kb)];
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int kb = 0; kb < R; ++kb) wr[kb * 544 + (R * i) * 17] = y[i * R + bitrev<R>(kb)];
         }
         __syncthreads();
-        const u64 *rd = buf + hi * 544 + lo * 17;
+        const u64 *rd = buf + kb3 * 544 + ka3 * 17;
 #pragma unroll
         for (int cl = 0; cl < 16; ++cl) z[16 * hh + cl] = rd[cl];
         if (hh == 0 || last_sync) __syncthreads();
@@ -229,71 +248,17 @@ __device__ __forceinline__ void ow_store_half(const u64 (&z)[32], void *dst_, lo
     }
 }
 
-// LGH: log2 of the sub-transform; HALF: the transform has 2^(LGH+1) points with a zero upper input half and this
-// workgroup produces the outputs of one parity.  TW1: HALF ? u64[2][Lh] (parity h at + h Lh) : u64[Lh].
-template <int LGH, int MODE, int OUT, bool HALF>
-__global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
-void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
-               long src_stride, long dst_stride, int nbatch, int nstore, WindowArgs wa, const u64 *__restrict__ tw,
-               const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
-               const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab) {
-    constexpr int R = (1 << LGH) / 1024;
-    using G = OwGeom<R>;
-    constexpr int T = G::T, Lh = G::Lh;
-    constexpr int LGF = HALF ? LGH + 1 : LGH;             // log2 of the transform the caller sees
-    constexpr bool INV = out_is_inverse(OUT);
-    static_assert(!HALF || (src_is_ext(MODE) && !INV), "HALF mode is the zero-padded forward transform");
-    static_assert(HALF || !src_is_ext(MODE), "a zero-padded source goes through HALF mode");
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64 *buf = lds;
-    u64 *tw2 = lds + G::XW;
-
-    int batch, h = 0;
-    if constexpr (HALF) {
-        const int g = blockIdx.x, r = g >> 3;             // blocks g and g + 8: the two halves of one transform, same XCD
-        h = r & 1;
-        batch = (r >> 1) * 8 + (g & 7);
-    } else batch = blockIdx.x;
-    if (batch >= nbatch) return;
-    const int t = threadIdx.x;
-    tw2[t] = TW2[t];
-
-    u64 x[32], y[32], z[32];
-#pragma unroll
-    for (int a = 0; a < 32; ++a) x[a] = load_sample<LGF, MODE>(src_, src_stride, batch, a * T + t, wa, tw);
-    if constexpr (HALF) { if (h) HalfShift<0>::run(x); }
-    if constexpr (R == 32) {
-        ow32_stage1_x1(x, y, buf, TW1 + (HALF ? (long)h * Lh : 0) + t, INV || (HALF && h), t);
-        ow32_stage2_x2(y, z, buf, tw2, t, false);
-    } else {
-        ow_stage1_x1<R>(x, y, buf, TW1 + (HALF ? (long)h * Lh : 0) + t, INV || (HALF && h), t);
-        ow_stage2_x2<R>(y, z, buf, tw2, t, false);
-    }
-    dft_regs<32, false>(z);
-    if constexpr (HALF) {
-        ow_store_half<R, OUT>(z, dst_, dst_stride, batch, h, t, xtab, prime0, np_mod);
-    } else {
-        // the pass-2 epilogues take the four outputs X[k1 + N1 (b + 16 cc)], N1 = Lh / 64 = T / 2:  t3 = k1 + N1 hi,
-        // kc = b' + 8 cc  <=>  b = hi + 2 b'
-        constexpr int N1 = T / 2;
-        const int k1 = t & (N1 - 1), hi = t / N1;
-        const P2Store A = pass2_store_args<LGH, OUT>(dst_, dst_stride, nstore, primes, pinv, prime0, np_mod, aux, aux_stride, fg, xtab, batch);
-#pragma unroll
-        for (int bp = 0; bp < 8; ++bp) {
-            u64 y4[4];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) y4[bitrev<4>(cc)] = z[bitrev<32>(bp + 8 * cc)];
-            pass2_store<LGH, OUT>(y4, hi + 2 * bp, k1, batch, A);
-        }
-    }
-}
-
-// ---- full-length NEGACYCLIC forward transform of 64K points (the ciphertext domain of x^65536 + 1) as two 32K-point halves:
-//   X[2k + h] = sum_{j < 32K} u_h[j] w_32K^(j k),   u_h[j] = (x[j] + (-1)^h i4 x[j + 32K]) psi^((1 + 2h) j),
-// psi the primitive 2^17-th root (psi^2 = w_64K), i4 = psi^32768 = +-2^48.  With j = 1024 a + m:
-// psi^((1 + 2h) 1024 a) = c^((1 + 2h) a), c = psi^1024 a 128-th root with c^2 = 8 -- a shift, times c when the exponent is odd
-// (16 of the 32 samples of a thread, in BOTH halves: equal work) -- and psi^((1 + 2h) m) joins the stage-1 table,
-// TW1g[h][ka 1024 + m] = psi^(m (1 + 2h + 4 ka)).
+// ---- SPLIT transforms: a full-length row of L = 2 Lh points done as the two Lh-point transforms of its even and odd outputs,
+// one workgroup each (decimation in frequency, like the zero-padded form, but both input halves are there).
+// Forward NEGACYCLIC (the ciphertext domain of x^L + 1; psi the primitive 2L-th root, psi^2 = w_L, i4 = psi^Lh = +-2^48):
+//   X[2k + h] = sum_{j < Lh} u_h[j] w_Lh^(j k),   u_h[j] = (x[j] + (-1)^h i4 x[j + Lh]) psi^((1 + 2h) j).
+// With j = T a + m: psi^((1 + 2h) T a) = c^((1 + 2h) a), c = psi^T a 128-th root with c^2 = 8 -- a shift, times c when the
+// exponent is odd (16 of the 32 samples of a thread, in BOTH halves: equal work) -- and psi^((1 + 2h) m) joins the stage-1
+// table, TW1g[h][ka T + m] = psi^(m (1 + 2h + 4 ka)).
+// Inverse negacyclic (u64 rows Xs, or the products of two rows, -> u32 coefficients): with Y[k] = Xs[(L - k) mod L]
+//   x[2j + h] = psi^-(2j + h) / L * sum_{k < Lh} v_h[k] w_Lh^(j k),   v_h[k] = (Y[k] + (-1)^h Y[k + Lh]) W^(h k),  W = w_L:
+// W^(T a) = 2^(3a) is a shift, W^m and 1 / L join the stage-1 table (TW1hi = the parity tables of the zero-padded form / L),
+// psi^-(2j + h), the centred lift and the reduction modulo p_i are the store epilogue of kOutModPNc at index 2j + h.
 template <int K>
 __device__ __forceinline__ u64 mulpow2(u64 v) {           // v * 2^K, K in [0, 192)
     if constexpr (K >= 96) return negp(shlp<K - 96>(v));
@@ -311,6 +276,138 @@ struct StreamTwist {                                      // x[a] *= c^((1 + 2H)
 };
 struct StreamTwistArgs { u64 c128; int i4neg; };            // c = psi^1024; i4neg: psi^32768 = -2^48 (else +2^48)
 
+template <int A>
+struct SplitShift {                                      // x[a] *= 2^(3a) for full-width values: the W^(a T) factor of the odd half
+    static __device__ __forceinline__ void run(u64 (&x)[32]) {
+        if constexpr (A > 0) x[A] = shlp<3 * A>(x[A]);
+        if constexpr (A + 1 < 32) SplitShift<A + 1>::run(x);
+    }
+};
+// the outputs of parity h of the inverse negacyclic transform: Y[j] -> coefficient 2 j + h (kOutModPNc, see pass2_store)
+template <int R>
+__device__ __forceinline__ void ow_store_half_nc(const u64 (&z)[32], void *dst_, long dst_stride, int batch, int h, int t,
+                                                 const u64 *__restrict__ xtab, u32 p, u64 m) {
+    constexpr int T = OwGeom<R>::T;
+    u32 *dst = (u32 *)dst_ + (long)batch * dst_stride + h;
+    const u64 *ti = xtab + h;
+#pragma unroll
+    for (int kc = 0; kc < 32; ++kc) {
+        const long o = 2L * (t + T * kc);
+        const u64 v = mulp(z[bitrev<32>(kc)], ti[o]);
+        const bool neg = v > (kP >> 1);                       // centred lift: v - P < 0
+        const u32 rr = mod_small(neg ? kP - v : v, p, m);
+        dst[o] = (neg && rr) ? p - rr : rr;
+    }
+}
+
+// LGH: log2 of the sub-transform; HALF: the transform has 2^(LGH+1) points and this workgroup produces the outputs of one
+// parity -- of the zero-padded forward transform (a source with a zero upper half) or of a SPLIT full-length row (above).
+// TW1: HALF ? u64[2][Lh] (parity h at + h Lh) : u64[Lh].
+template <int LGH, int MODE, int OUT, bool HALF>
+__global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
+void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
+               long src_stride, long dst_stride, int nbatch, int nstore, WindowArgs wa, const u64 *__restrict__ tw,
+               const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
+               const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab, StreamTwistArgs ta) {
+    constexpr int R = (1 << LGH) / 1024;
+    using G = OwGeom<R>;
+    constexpr int T = G::T, Lh = G::Lh;
+    constexpr int LGF = HALF ? LGH + 1 : LGH;             // log2 of the transform the caller sees
+    constexpr bool INV = out_is_inverse(OUT);
+    constexpr bool SPLIT = HALF && !src_is_ext(MODE);
+    constexpr bool SPLIT_FWD = SPLIT && MODE == kSrcU32Twist, SPLIT_INV = SPLIT && (MODE == kSrcU64Neg || MODE == kSrcU64NegMul);
+    static_assert(!HALF || SPLIT || (src_is_ext(MODE) && !INV), "HALF mode of a zero-padded source is the forward transform");
+    static_assert(!SPLIT || (SPLIT_FWD && (OUT == kOutU64 || OUT == kOutU64Mul)) || (SPLIT_INV && OUT == kOutModPNc), "split rows: the negacyclic pair");
+    static_assert(HALF || !src_is_ext(MODE), "a zero-padded source goes through HALF mode");
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 *buf = lds;
+    u64 *tw2 = lds + G::XW;
+
+    int batch, h = 0;
+    if constexpr (HALF) {
+        const int g = blockIdx.x, r = g >> 3;             // blocks g and g + 8: the two halves of one transform, same XCD
+        h = r & 1;
+        batch = (r >> 1) * 8 + (g & 7);
+    } else batch = blockIdx.x;
+    if (batch >= nbatch) return;
+    const int t = threadIdx.x;
+    tw2[t] = TW2[t];
+
+    u64 x[32], y[32], z[32];
+    if constexpr (SPLIT_FWD) {
+        const u32 *row = (const u32 *)src_ + (long)batch * src_stride + t;
+        const bool neg = ((h ^ ta.i4neg) & 1) != 0;       // the sign of (-1)^h i4 / 2^48
+#pragma unroll
+        for (int a0 = 0; a0 < 32; a0 += 8) {
+            u32 xl[8], xh[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { xl[a] = row[(a0 + a) * T]; xh[a] = row[(a0 + a) * T + Lh]; }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                u64 sft = shlp32<48>(xh[a]);
+                if (neg) sft = negp(sft);
+                x[a0 + a] = addp((u64)xl[a], sft);
+            }
+        }
+        if (h) StreamTwist<1, 0>::run(x, ta.c128); else StreamTwist<0, 0>::run(x, ta.c128);
+    } else if constexpr (SPLIT_INV) {
+        constexpr int L = 2 * Lh;
+        const long ro = (long)batch * src_stride;
+        const u64 *row = (const u64 *)src_ + ro;
+#pragma unroll
+        for (int a0 = 0; a0 < 32; a0 += 4) {
+            u64 y0[4], y1[4], w0[4], w1[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int k = (a0 + a) * T + t;
+                y0[a] = row[(L - k) & (L - 1)]; y1[a] = row[Lh - k];
+                if constexpr (MODE == kSrcU64NegMul) { w0[a] = tw[ro + ((L - k) & (L - 1))]; w1[a] = tw[ro + Lh - k]; }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if constexpr (MODE == kSrcU64NegMul) { y0[a] = mulp(y0[a], w0[a]); y1[a] = mulp(y1[a], w1[a]); }
+                x[a0 + a] = h ? subp(y0[a], y1[a]) : addp(y0[a], y1[a]);
+            }
+        }
+        if (h) SplitShift<0>::run(x);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) x[a] = load_sample<LGF, MODE>(src_, src_stride, batch, a * T + t, wa, tw);
+        if constexpr (HALF) { if (h) HalfShift<0>::run(x); }
+    }
+    if constexpr (SPLIT) {
+        // (both parity tables carry a factor on every row: psi^((1 + 2h) m) or W^(h m) / L)
+        if constexpr (R == 32) { owb_stage1_x1<32>(x, y, buf, TW1 + (long)h * Lh + t, true, t); owb_stage2_x2<32>(y, z, buf, tw2, t, false); }
+        else { ow_stage1_x1<R>(x, y, buf, TW1 + (long)h * Lh + t, true, t); ow_stage2_x2<R>(y, z, buf, tw2, t, false); }
+    } else if constexpr (R == 32) {
+        owb_stage1_x1<32>(x, y, buf, TW1 + (HALF ? (long)h * Lh : 0) + t, INV || (HALF && h), t);
+        owb_stage2_x2<32>(y, z, buf, tw2, t, false);
+    } else {
+        ow_stage1_x1<R>(x, y, buf, TW1 + (HALF ? (long)h * Lh : 0) + t, INV || (HALF && h), t);
+        ow_stage2_x2<R>(y, z, buf, tw2, t, false);
+    }
+    dft_regs<32, false>(z);
+    if constexpr (SPLIT_INV) {
+        const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
+        ow_store_half_nc<R>(z, dst_, dst_stride, batch, h, t, xtab, primes[pidx], pinv[pidx]);
+    } else if constexpr (HALF) {
+        ow_store_half<R, OUT>(z, dst_, dst_stride, batch, h, t, xtab, prime0, np_mod);
+    } else {
+        // the pass-2 epilogues take the four outputs X[k1 + N1 (b + 16 cc)], N1 = Lh / 64 = T / 2:  t3 = k1 + N1 hi,
+        // kc = b' + 8 cc  <=>  b = hi + 2 b'
+        constexpr int N1 = T / 2;
+        const int k1 = t & (N1 - 1), hi = t / N1;
+        const P2Store A = pass2_store_args<LGH, OUT>(dst_, dst_stride, nstore, primes, pinv, prime0, np_mod, aux, aux_stride, fg, xtab, batch);
+#pragma unroll
+        for (int bp = 0; bp < 8; ++bp) {
+            u64 y4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) y4[bitrev<4>(cc)] = z[bitrev<32>(bp + 8 * cc)];
+            pass2_store<LGH, OUT>(y4, hi + 2 * bp, k1, batch, A);
+        }
+    }
+}
+
 // ---- persistent form for the 32K-point halves of the 64K-point zero-padded forward transform (u32 rows).
 // Work item i = 2 * transform + parity, in the order of ntt_onewg's blocks; workgroup g takes items g, g + grid, ...
 // The u32 samples of an item (128 KB) arrive by LDS-DMA in the exchange buffer, which is idle from the last read of
@@ -325,12 +422,12 @@ __device__ __forceinline__ void glds16(const void *gsrc, u32 lds_byte_addr) {   
 // SRC = kSrcU32Ext: the zero-padded transform (32K samples per row); kSrcU32Twist: the negacyclic transform of a full row of 64K
 // samples -- the lower 32K by LDS-DMA like the zero-padded form, the upper 32K straight from global memory, requested before
 // the wait for the DMA.
-template <int SRC, int OUT, int H>
+template <int R, int SRC, int OUT, int H>
 __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, u64 *buf, const u64 *tw2,
                                                long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod,
                                                unsigned *pair_cnt, int *give_up, StreamTwistArgs ta) {
     static_assert(SRC == kSrcU32Ext || SRC == kSrcU32Twist, "row sources of the persistent form");
-    constexpr int R = 32;
+    static_assert(R == 16 || R == 32, "sub-transforms of 16K / 32K points");
     using G = OwGeom<R>;
     constexpr int T = G::T, Lh = G::Lh;
     const int t = threadIdx.x;
@@ -382,8 +479,8 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
             }
             StreamTwist<H, 0>::run(x, ta.c128);
         } else if constexpr (H) HalfShift<0>::run(x);
-        ow32_stage1_x1(x, y, lb, TW1 + (long)H * Lh + t + opaque, H != 0 || SRC == kSrcU32Twist, t);
-        ow32_stage2_x2(y, z, lb, tw2 + opaque, t, true);
+        owb_stage1_x1<R>(x, y, lb, TW1 + (long)H * Lh + t + opaque, H != 0 || SRC == kSrcU32Twist, t);
+        owb_stage2_x2<R>(y, z, lb, tw2 + opaque, t, true);
         if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);      // the buffer is idle until exchange 1 of the next item
         // Rendezvous with the workgroup that computes the OTHER parity of this row (block ^ 8: same XCD, same round): the two
         // write alternate 8-byte words of the same lines, and only stores issued within a few microseconds of each other meet in
@@ -410,20 +507,21 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
         ++round;
     }
 }
-template <int SRC, int OUT>
-__global__ __launch_bounds__(1024, 4)
+template <int LGH, int SRC, int OUT>
+__global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
 void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
                       long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, int prime0, int np_mod, unsigned *pair_cnt,
                       StreamTwistArgs ta) {
-    using G = OwGeom<32>;
+    constexpr int R = (1 << LGH) / 1024;
+    using G = OwGeom<R>;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     u64 *buf = lds;
-    u64 *tw2 = lds + G::XW;
+    u64 *tw2 = lds + G::XWB;
     __shared__ int give_up;
     tw2[threadIdx.x] = TW2[threadIdx.x];
     if (threadIdx.x == 0) give_up = 0;
-    if ((blockIdx.x >> 3) & 1) ow_stream_loop<SRC, OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
-    else ow_stream_loop<SRC, OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
+    if ((blockIdx.x >> 3) & 1) ow_stream_loop<R, SRC, OUT, 1>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
+    else ow_stream_loop<R, SRC, OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
 }
 
 }  // namespace cuhe

@@ -15,16 +15,22 @@ struct OwArgs {
     WindowArgs wa; const u64 *tw;         // kSrcWindow geometry; twist table (kSrcU32Twist) or second operand rows (kSrcU64NegMul)
     const u32 *primes; const u64 *pinv; int prime0, np_mod;
     const u32 *aux; long aux_stride; FoldGeom fg; const u64 *xtab;
+    u64 c128 = 0; int i4neg = 0;          // split negacyclic forward rows: psi^T and the sign of psi^Lh = +-2^48 (ntt_onewg.cuh)
 };
 // hipErrorInvalidValue: this (sub-transform size, source, epilogue, half) combination is not instantiated
 hipError_t ow_launch_12(int mode, int out, bool half, const OwArgs &a, hipStream_t st);        // 4K-point halves of the zero-padded 8K-point transform only
 hipError_t ow_launch_13(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_14(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
 hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream_t st);
-// persistent form for rows of 64K points: kSrcU32Ext (zero-padded forward, a.TW1 = the parity tables) or kSrcU32Twist
-// (negacyclic forward of full rows, a.TW1 = the twisted tables, c128 = psi^1024, i4neg: psi^32768 = -2^48);
-// pair_cnt: grid / 2 counters for the rendezvous of the two halves of a row (or null)
-hipError_t ow_launch_stream(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
+// persistent form for the halves of rows of 32K / 64K points (sub-transforms of 2^14 / 2^15 points): kSrcU32Ext
+// (zero-padded forward, a.TW1 = the parity tables) or, 64K-point rows only, kSrcU32Twist (negacyclic forward of full rows,
+// a.TW1 = the twisted tables, c128 = psi^1024, i4neg: psi^32768 = -2^48); `grid`: resident workgroups, a multiple of 16;
+// pair_cnt: grid / 2 <= kOwPairCounters counters for the rendezvous of the two halves of a row (or null)
+constexpr int kOwPairCounters = 512;
+hipError_t ow_launch_stream_14(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
+hipError_t ow_launch_stream_15(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
 bool ow_supported(int mode, int out, bool half);
+// half = true with a full-length source: the SPLIT form (two half-length transforms per row), 32K / 64K-point rows
+bool ow_split_supported(int mode, int out);
 
 }  // namespace cuhe

@@ -37,7 +37,7 @@ hipError_t launch(const OwArgs &a, hipStream_t st) {
     const int nb8 = (a.nbatch + 7) & ~7;
     const int grid = HALF ? 2 * nb8 : a.nbatch;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
-                       a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab);
+                       a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab, StreamTwistArgs{a.c128, a.i4neg});
     return hipGetLastError();
 }
 
@@ -64,16 +64,23 @@ hipError_t OW_CONCAT(ow_launch_, CUHE_OW_LGH)(int mode, int out, bool half, cons
     OW_CASE(kSrcU64NegMul, kOutModPFoldXn1, false)
     OW_CASE(kSrcU64NegMul, kOutModPNc, false)
 #endif
+#if CUHE_OW_LGH >= 14
+    // SPLIT rows of 2^(LGH+1) points (negacyclic forward / inverse), one parity per workgroup
+    OW_CASE(kSrcU32Twist, kOutU64, true)
+    OW_CASE(kSrcU32Twist, kOutU64Mul, true)
+    OW_CASE(kSrcU64Neg, kOutModPNc, true)
+    OW_CASE(kSrcU64NegMul, kOutModPNc, true)
+#endif
     return hipErrorInvalidValue;
 }
-#if CUHE_OW_LGH == 15
-// persistent form of the 32K-point halves of a 64K-point row (ntt_onewg_stream): `grid` workgroups (a multiple of 16, at most
-// one per CU) walk over the 2 * batch halves.  mode kSrcU32Ext: the zero-padded forward transform (a.TW1 = u64[2][32768], the
-// parity tables of the half mode); kSrcU32Twist: the negacyclic forward transform of full rows (a.TW1 = the twisted tables,
-// c128 / i4neg the two constants of the twist).
+#if CUHE_OW_LGH >= 14
+// persistent form of the halves of a row of 2^(LGH+1) points (ntt_onewg_stream): `grid` workgroups (a multiple of 16, every one
+// resident: 1 / 2 per CU at 32K / 16K points) walk over the 2 * batch halves.  mode kSrcU32Ext: the zero-padded forward
+// transform (a.TW1 = u64[2][Lh], the parity tables of the half mode); kSrcU32Twist: the negacyclic forward transform of
+// full rows (a.TW1 = the twisted tables, c128 / i4neg the two constants of the twist).
 template <int SRC, int OUT>
 static hipError_t launch_stream(const OwArgs &a, int grid, unsigned *pair_cnt, StreamTwistArgs ta, hipStream_t st) {
-    auto kern = ntt_onewg_stream<SRC, OUT>;
+    auto kern = ntt_onewg_stream<kLgh, SRC, OUT>;
     static std::mutex mu; static std::atomic<uint64_t> done{0};
     int cur = 0;
     hipError_t e = hipGetDevice(&cur);
@@ -82,7 +89,7 @@ static hipError_t launch_stream(const OwArgs &a, int grid, unsigned *pair_cnt, S
     if (!(done.load(std::memory_order_acquire) & bit)) {
         std::lock_guard<std::mutex> lk(mu);
         if (!(done.load(std::memory_order_relaxed) & bit)) {
-            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes);
+            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes_stream);
             if (e != hipSuccess) return e;
             done.fetch_or(bit, std::memory_order_release);
         }
@@ -91,24 +98,32 @@ static hipError_t launch_stream(const OwArgs &a, int grid, unsigned *pair_cnt, S
         e = hipMemsetAsync(pair_cnt, 0, (size_t)(grid / 2) * sizeof(unsigned), st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes_stream, st, a.dst, (const u32 *)a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
                        a.xtab, a.prime0, a.np_mod, pair_cnt, ta);
     return hipGetLastError();
 }
-hipError_t ow_launch_stream(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st) {
-    if (grid < 16 || (grid & 15)) return hipErrorInvalidValue;
+hipError_t OW_CONCAT(ow_launch_stream_, CUHE_OW_LGH)(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st) {
+    if (grid < 16 || (grid & 15) || grid / 2 > kOwPairCounters) return hipErrorInvalidValue;
     const StreamTwistArgs ta{c128, i4neg};
     if (mode == kSrcU32Ext && out == kOutU64) return launch_stream<kSrcU32Ext, kOutU64>(a, grid, pair_cnt, ta, st);
     if (mode == kSrcU32Ext && out == kOutU64Mul) return launch_stream<kSrcU32Ext, kOutU64Mul>(a, grid, pair_cnt, ta, st);
+#if CUHE_OW_LGH == 15
     if (mode == kSrcU32Twist && out == kOutU64) return launch_stream<kSrcU32Twist, kOutU64>(a, grid, pair_cnt, ta, st);
+#endif
     return hipErrorInvalidValue;
 }
+#endif
+#if CUHE_OW_LGH == 15
 bool ow_supported(int mode, int out, bool half) {
     if (half) return (mode == kSrcU32Ext && (out == kOutU64 || out == kOutU64Mul)) || (mode == kSrcWindow && out == kOutU64);
     if (mode == kSrcU32Twist) return out == kOutU64 || out == kOutU64Mul;
     if (mode == kSrcU64Neg) return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPRevQ || out == kOutFoldFinal || out == kOutModPNc;
     if (mode == kSrcU64NegMul) return out == kOutModP || out == kOutModPFoldXn1 || out == kOutModPNc;
     return false;
+}
+bool ow_split_supported(int mode, int out) {
+    if (mode == kSrcU32Twist) return out == kOutU64 || out == kOutU64Mul;
+    return (mode == kSrcU64Neg || mode == kSrcU64NegMul) && out == kOutModPNc;
 }
 #endif
 

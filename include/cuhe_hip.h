@@ -304,10 +304,16 @@ int cuhe_hip_set_ll_rows(int rows);
  * CU: 0 the two-pass kernels, 1 one workgroup per half, 2 (default) persistent workgroups (one per CU, the next half's
  * samples prefetched into LDS by DMA, the two halves of a row meeting before their interleaved stores) for calls that
  * give every workgroup at least two halves and 16-byte aligned rows, the two-pass kernels otherwise (2.71 vs 2.56 M
- * transforms/s, profiles/r03_onewg_ab.txt).  Same results in every form.
+ * transforms/s, profiles/r03_onewg_ab.txt); 3: the persistent form for zero-padded rows of 32K points too (measured 3 %
+ * slower than one workgroup per half there: two workgroups per CU already overlap).  Same results in every form.
+ * cuhe_hip_set_onewg_split: full-length INVERSE negacyclic rows of 32K points (the ciphertext domain of x^32768 + 1) run,
+ * when the call fills the chip, SPLIT into the two 16K-point transforms of their even and odd outputs, two workgroups per
+ * CU (mode 1, default: 13 % faster than one 32K-point workgroup per row); 0: never; 2: also the forward rows of 32K points
+ * and the inverse rows of 64K points (no gain measured: parity tests and A/B runs).  Environment CUHE_ONEWG_SPLIT.
  * Environment CUHE_ONEWG / CUHE_ONEWG64 override the defaults for A/B runs of whole programs.  Replaces the same
  * reference code as the two-pass kernels (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398). */
 int cuhe_hip_set_onewg(int mode, int rows64k);
+int cuhe_hip_set_onewg_split(int mode);
 /* name / average duration bookkeeping for bench.py: time the dominant kernel with hipEvents on `stream`.
  * Runs `iters` forward batched transforms and returns total milliseconds in *ms_pass1 / *ms_pass2 / *ms_total. */
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,

@@ -134,24 +134,36 @@ def simulate(R, u, half=False, h=0):
     return Y
 
 
-def x1_addr32(c, ka, b_l):
-    return c * 545 + ka * 17 + b_l
+def x1_addr_bal(R, c, ka, b_l):
+    RW = R // 2 + 1
+    return c * (32 * RW + 1) + ka * RW + b_l
 
 
-def x2_addr32(kb, ka, c_l):
+def x2_addr_bal(kb, ka, c_l):
     return kb * 544 + ka * 17 + c_l
 
 
-LDS_WORDS32 = 32 * 545
+def lds_words_bal(R):
+    return max(32 * (32 * (R // 2 + 1) + 1), R * 544)
 
 
-def simulate32(u, half=False, h=0):
-    """R = 32 with the balanced exchanges (see the module docstring); same contract as simulate(32, ...)."""
-    R, T, Lh = 32, 1024, 32768
+LDS_WORDS32 = lds_words_bal(32)
+
+
+def simulate_balanced(R, u, half=False, h=0):
+    """The exchanges of the persistent kernels (ntt_onewg.cuh: owb_*), R = 16 or 32: the read side is unconditional and balanced.
+    Stage-2 thread t2 = kq + R c.
+      X1, round hh: the waves with b in [hh R/2, (hh + 1) R/2) (t = 32 b + c) store all 32 A[ka] -> buf[c S1 + ka RW + (b - hh R/2)],
+                    RW = R/2 + 1, S1 = 32 RW + 1; every reader (kq, c) takes its R/2 values b for each of its 32/R values ka = kq + R i
+      X2, round hh: the waves with c in [16 hh, 16 hh + 16) store all 32 B[i][kb] -> buf[kb 544 + ka 17 + (c - 16 hh)];
+                    every reader (ka, kb) takes its 16 values c
+    Same contract as simulate(R, ...)."""
+    T, Lh, NP, HB = 32 * R, 1024 * R, 32 // R, R // 2
     w, W = root(Lh), root(2 * Lh)
-    w32 = pow(2, 6, P)
+    w32, wR = pow(2, 6, P), pow(2, 192 // R, P)
     tw1 = lambda ka, m: pow(W, m * (2 * ka + 1), P) if (half and h) else pow(w, m * ka, P)
     tw2 = lambda kb, c: pow(w, 32 * c * kb, P)
+    words = lds_words_bal(R)
     A = []
     for m in range(T):
         x = [u[a * T + m] for a in range(32)]
@@ -161,42 +173,51 @@ def simulate32(u, half=False, h=0):
         A.append([a_[ka] * tw1(ka, m) % P for ka in range(32)])
     y = [[None] * 32 for _ in range(T)]
     for hh in range(2):
-        buf = [None] * LDS_WORDS32
+        buf = [None] * words
         for m in range(T):
             b, c = m // 32, m % 32
-            if b // 16 != hh:
+            if b // HB != hh:
                 continue
             for ka in range(32):
-                ad = x1_addr32(c, ka, b - 16 * hh)
+                ad = x1_addr_bal(R, c, ka, b - HB * hh)
                 assert buf[ad] is None
                 buf[ad] = A[m][ka]
         for t2 in range(T):
-            kq, c = t2 % 32, t2 // 32
-            for bl in range(16):
-                y[t2][16 * hh + bl] = buf[x1_addr32(c, kq, bl)]
+            kq, c = t2 % R, t2 // R
+            for i in range(NP):
+                for bl in range(HB):
+                    y[t2][i * R + HB * hh + bl] = buf[x1_addr_bal(R, c, kq + R * i, bl)]
     Bv = []
     for t2 in range(T):
-        c = t2 // 32
-        d = dft(y[t2], w32)
-        Bv.append([d[kb] * tw2(kb, c) % P for kb in range(32)])
+        c = t2 // R
+        row = []
+        for i in range(NP):
+            d = dft(y[t2][i * R:(i + 1) * R], wR)
+            row.append([d[kb] * tw2(kb, c) % P for kb in range(R)])
+        Bv.append(row)
     z = [[None] * 32 for _ in range(T)]
     for hh in range(2):
-        buf = [None] * LDS_WORDS32
+        buf = [None] * words
         for t2 in range(T):
-            kq, c = t2 % 32, t2 // 32
+            kq, c = t2 % R, t2 // R
             if c // 16 != hh:
                 continue
-            for kb in range(32):
-                ad = x2_addr32(kb, kq, c - 16 * hh)
-                assert buf[ad] is None
-                buf[ad] = Bv[t2][kb]
+            for i in range(NP):
+                for kb in range(R):
+                    ad = x2_addr_bal(kb, kq + R * i, c - 16 * hh)
+                    assert buf[ad] is None
+                    buf[ad] = Bv[t2][i][kb]
         for t3 in range(T):
             ka, kb = t3 % 32, t3 // 32
             for cl in range(16):
-                z[t3][16 * hh + cl] = buf[x2_addr32(kb, ka, cl)]
+                z[t3][16 * hh + cl] = buf[x2_addr_bal(kb, ka, cl)]
     Y = [None] * Lh
     for t3 in range(T):
         d = dft(z[t3], w32)
         for kc in range(32):
             Y[t3 + T * kc] = d[kc]
     return Y
+
+
+def simulate32(u, half=False, h=0):
+    return simulate_balanced(32, u, half, h)

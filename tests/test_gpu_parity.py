@@ -1095,10 +1095,16 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
     res = {}
     try:
         # (rows64k = 2 with the one-workgroup form forced: the persistent kernels also take the negacyclic 64K-point rows of x^65536 + 1)
-        for form, onewg, r64 in ((NONE, 0, 0), (ALL, 0, 0), (NONE, 2, 1)) + (((NONE, 2, 2),) if name in ("n65536", "c3_65536") else ()):
+        # split: negacyclic rows as two half-length sub-transforms (cuhe_hip_set_onewg_split; 1 = the default, inverse rows of 32K points;
+        # 2 with the one-workgroup form forced: every split kernel -- forward rows of 32K, inverse rows of 32K and 64K points)
+        forms = [(NONE, 0, 0, 0), (ALL, 0, 0, 0), (NONE, 2, 1, 0), (NONE, 2, 1, 1)]
+        if name in ("n65536", "c3_65536"): forms.append((NONE, 2, 2, 1))
+        if name in ("n65536", "c3_65536"): forms.append((NONE, 2, 1, 2))           # (rings whose ciphertext domain has 32K / 64K points)
+        for form, onewg, r64, split in forms:
             g = gu.GpuCtx(*args)
             ck(lib.cuhe_hip_set_ll_rows(form))
             ck(lib.cuhe_hip_set_onewg(onewg, r64))
+            ck(lib.cuhe_hip_set_onewg_split(split))
             try:
                 q = g.prm
                 K, W0, M0 = q.numEvalKey, g.words(0), g.coeff_modulus(0)
@@ -1149,6 +1155,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
             finally:
                 ck(lib.cuhe_hip_set_ll_rows(24))
                 ck(lib.cuhe_hip_set_onewg(1, 2))
+                ck(lib.cuhe_hip_set_onewg_split(1))
                 g.close()
         # the standalone batched forward entry point at all three lengths, odd batch
         for length in (16384, 32768, 65536):

@@ -40,6 +40,19 @@ def test_32k_balanced_exchanges_equal_zero_padded_transform():
     assert (M.LDS_WORDS32 + 1024) * 8 <= 160 * 1024
 
 
+def test_16k_balanced_exchanges_equal_zero_padded_transform():
+    """the persistent form of the 32K-point rows: two workgroups of this geometry per CU"""
+    Lh = 16384
+    x = O.splitmix_u32_below(Lh, (1 << 32) - 1, 6)
+    want = O.ntt_ext(x, 2 * Lh)
+    u = [int(v) for v in x]
+    for h in (0, 1):
+        got = M.simulate_balanced(16, u, half=True, h=h)
+        assert all(int(want[2 * k + h]) == got[k] for k in range(Lh)), "half %d" % h
+    assert 2 * ((M.lds_words_bal(16) + 512) * 8 + 16) <= 160 * 1024
+    assert M.lds_words_bal(16) * 8 >= 4 * Lh                  # the exchange buffer takes the u32 samples of the next half (LDS-DMA)
+
+
 def test_lds_budget():
     # bytes of the exchange buffer + the stage-2 twiddle table: 4 / 2 / 1 workgroups per CU inside 160 KiB
     for R, per_cu in ((4, 7), (8, 4), (16, 2)):

@@ -20,9 +20,9 @@ int main(int argc, char **argv) {
     const int big = argc > 1 ? atoi(argv[1]) : 4096;          // transforms per timed call at 64K points
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
     // equality against the two-pass kernels: every length at a small odd batch (mode 3: one-workgroup form whatever the row
-    // count), and 64K points at a batch that takes the persistent form (mode 1; 301 rows: padding items in the last group of 8)
+    // count), and 64K / 32K points at batches that take the persistent form (mode 1; 301 / 1101 rows: padding items in the last group of 8)
     struct Case { int len, batch, mode, r64; };
-    for (Case cs : {Case{16384, 37, 2, 0}, Case{32768, 37, 2, 0}, Case{65536, 37, 2, 1}, Case{65536, 301, 1, 2}, Case{65536, 301, 1, 1}, Case{32768, 600, 1, 0}, Case{16384, 1100, 1, 0}}) {
+    for (Case cs : {Case{16384, 37, 2, 0}, Case{32768, 37, 2, 0}, Case{65536, 37, 2, 1}, Case{65536, 301, 1, 2}, Case{65536, 301, 1, 1}, Case{32768, 600, 1, 1}, Case{32768, 1101, 1, 3}, Case{32768, 1101, 1, 1}, Case{16384, 1100, 1, 0}}) {
         const int len = cs.len, batch = cs.batch;
         CK(cuhe_hip_ntt_prepare(len, 0));
         std::vector<uint32_t> h((size_t)batch * len / 2);
@@ -55,14 +55,14 @@ int main(int argc, char **argv) {
         for (auto &v : h) v = (uint32_t)sm(s);
         HK(hipMemcpy(dx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         for (int mode : {0, 2, 1, 0, 2, 1}) {
-            if (len != 65536 && mode >= 2) continue;              // (the forms differ at 64K points only)
-            CK(cuhe_hip_set_onewg(mode ? 1 : 0, mode == 2 ? 1 : mode == 1 ? 2 : mode == 3 ? 3 : 0));
+            if (len == 16384 && mode >= 2) continue;              // (the forms differ at 32K and 64K points only)
+            CK(cuhe_hip_set_onewg(mode ? 1 : 0, mode == 2 ? 1 : mode == 1 ? (len == 32768 ? 3 : 2) : 0));
             float p1 = 0, p2 = 0, tot = 0;
             CK(cuhe_hip_time_ntt_fwd(dA, dx, len, batch, 2, 0, nullptr, &p1, &p2, &tot));       // warm
             CK(cuhe_hip_time_ntt_fwd(dA, dx, len, batch, iters, 0, nullptr, &p1, &p2, &tot));
             const double per = tot / iters * 1e-3 / batch;
             printf("len %d batch %d %s: %.4f ms per call, %.3f M transforms/s, HBM-roofline frac %.4f  (passes %.4f + %.4f ms)\n", len, batch,
-                   mode == 0 ? "two-pass" : mode == 2 ? "one-wg  " : len == 65536 ? "one-wg persistent" : "one-wg  ", tot / iters, 1e-6 / per, 10.0 * len / per / 8e12, p1 / iters, p2 / iters);
+                   mode == 0 ? "two-pass" : mode == 2 ? "one-wg  " : len >= 32768 ? "one-wg persistent" : "one-wg  ", tot / iters, 1e-6 / per, 10.0 * len / per / 8e12, p1 / iters, p2 / iters);
         }
         hipFree(dx); hipFree(dA);
     }
