@@ -84,9 +84,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     single_dev = os.environ.get("CUHE_BENCH_SINGLE_DEVICE") == "1"
-    if os.environ.get("CUHE_BENCH_WATCHDOG"):      # a stuck rank prints every thread's stack and exits (the launcher then stops the others)
+    # a stuck rank prints every thread's stack and exits (the launcher then stops the others): on request, and by default
+    # after 15 minutes in a multi-rank run (a collective that never completes would otherwise hold the node until the caller's limit)
+    watchdog = int(os.environ.get("CUHE_BENCH_WATCHDOG", "900" if world > 1 else "0"))
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["CUHE_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     if single_dev:
         local_rank = 0                      # test hook: every rank on device 0 (use with --dist-backend gloo)
     if world > 1:
