@@ -15,7 +15,7 @@ def pmc(counter):
     """{kernel: (n, avg)} of the forward-transform kernels of the timed loop"""
     res = {}
     for line in open(os.path.join(d, "pmc_%s.txt" % counter)):
-        m = re.match(r"void cuhe::(ntt_pass[12]w<16, 0>|ntt_onewg_stream<0, 0>).*?%s\s+n=(\d+)\s+avg=\s*([0-9.]+)" % counter, line)
+        m = re.match(r"void cuhe::(ntt_pass[12]w<16, 0>|ntt_onewg_stream<15, 0, 0>).*?%s\s+n=(\d+)\s+avg=\s*([0-9.]+)" % counter, line)
         if m:
             res[m.group(1)] = (int(m.group(2)), float(m.group(3)))
     return res
@@ -31,7 +31,7 @@ common = {"source": "profiles/%s_ntt64k_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WR
           "kernel_sha16": h.hexdigest()[:16], "transform_len": L,
           # issue rate of dense streams of the instructions the field arithmetic lowers to (tools/ubench_rates.hip, 4 waves per SIMD)
           "dense_stream_ceiling_T_per_s": 36.5, "dense_stream_ceiling_source": "profiles/r02_valu_cost_model.txt"}
-ow = "ntt_onewg_stream<0, 0>"            # <row source = zero-padded u32, output = u64>
+ow = "ntt_onewg_stream<15, 0, 0>"        # <32K-point halves, row source = zero-padded u32, output = u64>
 if ow in fetch and ow in write and ow in valu:
     # the persistent one-workgroup transform: ONE launch per call of BATCH transforms (bench.py default: 8192)
     BATCH = 8192
