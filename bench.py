@@ -675,6 +675,24 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
                    "algorithmic_bytes_per_ciphertext": int(alg), "frac_hbm": round(alg / bdt / 1e9 / HBM_PEAK_GBS, 4),
                    "checked": "%d distinct ciphertext pairs, every result equal to the single chain" % B,
                    "note": "B independent chains per call on one stream; products formed on load by the inverse transforms; key-switch inner product on the matrix cores (int8 MFMA over signed base-256 digits) in tiles of 16 ciphertexts"}
+        # twice the batch (the keys are amortised over more ciphertexts): the same operands twice, the two halves of the result equal
+        try:
+            B2 = 2 * B
+            nab2, nbb2 = torch.cat((nab, nab)), torch.cat((nbb, nbb))
+            out2 = torch.empty((B2 * npn, q.crtLen), dtype=torch.int32, device=dev)
+            for _ in range(2):
+                ck(lib.cuhe_hip_mul_relin_batch(out2.data_ptr(), nab2.data_ptr(), nbb2.data_ptr(), 0, B2, 0, None))
+            torch.cuda.synchronize()
+            assert torch.equal(out2[:B * npn], out) and torch.equal(out2[B * npn:], out), "batch of %d differs from the batch of %d" % (B2, B)
+            t0 = time.perf_counter()
+            for _ in range(max(4, breps // 2)):
+                ck(lib.cuhe_hip_mul_relin_batch(out2.data_ptr(), nab2.data_ptr(), nbb2.data_ptr(), 0, B2, 0, None))
+            torch.cuda.synchronize()
+            b2dt = (time.perf_counter() - t0) / max(4, breps // 2) / B2
+            batched["twice_the_batch"] = {"batch": B2, "ms_per_ciphertext": round(b2dt * 1e3, 4), "value": round(1.0 / b2dt, 2), "checked": "both halves equal the batch of %d" % B}
+            del nab2, nbb2, out2
+        except Exception as ex:
+            batched["twice_the_batch"] = {"error": repr(ex)[:200]}
     except Exception as ex:
         batched = {"error": repr(ex)[:300]}
     # ---- the batched call from several host threads at once (own stream and own scratch each: the library is

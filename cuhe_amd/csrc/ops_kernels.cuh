@@ -522,9 +522,9 @@ __device__ __forceinline__ void mac_load_keys(MacFrag<NFULL, TAIL> &B, const uns
     for (int lb = 0; lb < 8; ++lb) {
         const unsigned char *q = p + (long)lb * lb_bytes;
 #pragma unroll
-        for (int s = 0; s < NFULL; ++s) B.f[lb][s] = __builtin_nontemporal_load((const v4i *)(q + s * 1024 + lane * 16));
-        if (TAIL == 32) B.t32[lb] = (lane >> 4) < tail_groups ? __builtin_nontemporal_load((const long *)(q + NFULL * 1024 + lane * 8)) : 0l;
-        if (TAIL == 64) B.t64[lb] = (lane >> 4) < tail_groups ? __builtin_nontemporal_load((const v4i *)(q + NFULL * 1024 + lane * 16)) : v4i{0, 0, 0, 0};
+        for (int s = 0; s < NFULL; ++s) B.f[lb][s] = *(const v4i *)(q + s * 1024 + lane * 16);
+        if (TAIL == 32) B.t32[lb] = (lane >> 4) < tail_groups ? *(const long *)(q + NFULL * 1024 + lane * 8) : 0l;
+        if (TAIL == 64) B.t64[lb] = (lane >> 4) < tail_groups ? *(const v4i *)(q + NFULL * 1024 + lane * 16) : v4i{0, 0, 0, 0};
     }
 }
 __device__ __forceinline__ u32 pack_digit(u64 w0, u64 w1, u64 w2, u64 w3, int la) {
