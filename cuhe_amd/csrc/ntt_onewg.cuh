@@ -27,7 +27,11 @@
 // CU: a persistent workgroup walks over its share of the batch, the u32 samples of the NEXT half arrive in the idle
 // exchange buffer by LDS-DMA while stage 3 of the current one computes and stores, and the two workgroups of a row meet
 // before their stores: 2.71-2.78 M transforms/s against 2.54-2.64 for the two-pass pair, 0.81 MB instead of 1.71 MB per
-// transform at the L2/fabric boundary; profiles/r03_onewg_ab.txt).
+// transform at the L2/fabric boundary; profiles/r03_onewg_ab.txt).  The persistent kernel is generic in the sub-transform
+// size (16K / 32K points) and also takes the full negacyclic rows of 64K points; with two workgroups per CU it loses to
+// ntt_onewg (profiles/r03_split_rows.txt), so it serves the 64K-point rows only.
+// Full-length negacyclic rows (the ciphertext domain) can run SPLIT the same way -- two half-length sub-transforms per row,
+// both input halves present (see "SPLIT transforms" below): the default for the inverse rows of 32K points.
 #pragma once
 #include "ntt_kernels.cuh"
 
