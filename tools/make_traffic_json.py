@@ -21,14 +21,13 @@ def pmc(counter):
     return res
 
 
-h = hashlib.sha256()
-for f in ("modp.cuh", "ntt_kernels.cuh", "ntt_onewg.cuh"):
-    h.update(open(os.path.join(ROOT, "cuhe_amd", "csrc", f), "rb").read())
+sys.path.insert(0, ROOT)
+import bench                                   # the hash bench.py checks: code of the kernel headers, comments removed
 fetch, write, valu = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), pmc("SQ_INSTS_VALU")
 common = {"source": "profiles/%s_ntt64k_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes with --kernel-trace only; "
                     "FETCH_SIZE x2: gfx950 counts wide streaming reads at half their bytes)" % tag,
           "command": "python bench.py --steps 2 --warmup 1 --no-mulrelin --no-cpu --no-prince",
-          "kernel_sha16": h.hexdigest()[:16], "transform_len": L,
+          "kernel_sha16": bench.kernel_sha16(), "transform_len": L,
           # issue rate of dense streams of the instructions the field arithmetic lowers to (tools/ubench_rates.hip, 4 waves per SIMD)
           "dense_stream_ceiling_T_per_s": 36.5, "dense_stream_ceiling_source": "profiles/r02_valu_cost_model.txt"}
 ow = "ntt_onewg_stream<15, 0, 0>"        # <32K-point halves, row source = zero-padded u32, output = u64>
