@@ -118,7 +118,7 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
     void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->mr_ntt, w->mr_crt,
-                    w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out};
+                    w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out, w->pair_cnt};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     if (w->ev_lane) hipEventDestroy(w->ev_lane);
@@ -368,7 +368,7 @@ int cuhe_hip_shutdown(void) {
         for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); hipFree(t.Wn1); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         if (D.sh_stream) { hipStreamDestroy(D.sh_stream); hipEventDestroy(D.sh_e1); hipEventDestroy(D.sh_e2); }
-        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek, D.ekd, D.pair_cnt};
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek, D.ekd};
         for (auto &t : D.ow) { hipFree(t.TW1f); hipFree(t.TW1i); hipFree(t.TW1h); hipFree(t.TW2); hipFree(t.TW1g); hipFree(t.TW1hi); }
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);

@@ -72,6 +72,8 @@ struct Workspace {
     u32 *win = nullptr;                  // u32[numEvalKey][crtLen] window rows
     // scratch of the CRT-prime-sharded multiply + relinearise (own operand rows, gathered CRT rows, raw, own result rows)
     u64 *sh_a = nullptr, *sh_b = nullptr; u32 *sh_rows = nullptr, *sh_raw = nullptr, *sh_out = nullptr; bool sh_ready = false;
+    unsigned *pair_cnt = nullptr;        // rendezvous counters of the persistent one-workgroup transforms (one per pair of workgroups): per host
+                                         // thread like every scratch, so that launches of different threads on one device never share them
     hipStream_t last = nullptr; bool used = false;
     hipEvent_t ev = nullptr;             // orders this thread's work when it moves to another stream
     // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
@@ -94,7 +96,6 @@ struct DevCtx {
     NttTab ntt[4];                       // LG 13 (one-workgroup form only: twist tables), 14, 15, 16
     OwTab ow[4];                         // sub-transforms of 4K, 8K, 16K, 32K points
     int cus = 0;                         // compute units (policy of the one-workgroup transforms)
-    unsigned *pair_cnt = nullptr;        // rendezvous counters of the persistent one-workgroup transform (one per pair of workgroups)
     // prime tables
     u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
     u64 *pinv = nullptr;

@@ -227,8 +227,8 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             CHK(ensure_onewg_twist(ot, 15));
             OwArgs a{dst, src, ot.TW1g, ot.TW2, src_stride, dst_stride, batch, nstore, wa, nullptr, D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, nullptr};
             if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, kOwPairCounters * sizeof(unsigned)));
-            hipError_t he = ow_launch_stream_15(kSrcU32Twist, kOutU64, a, grid64, D.pair_cnt, ot.c128, ot.i4neg, st);
+            CHK(ws_buffer(&W.pair_cnt, kOwPairCounters));
+            hipError_t he = ow_launch_stream_15(kSrcU32Twist, kOutU64, a, grid64, W.pair_cnt, ot.c128, ot.i4neg, st);
             if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (negacyclic rows): %s", hipGetErrorString(he));
             if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
             return CUHE_OK;
@@ -281,9 +281,9 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 // of the current one, the two halves of a row meeting before their interleaved stores
                 const bool stream = G_.onewg64 >= 2 && stream_ok;
                 if (stream) {
-                    if (!D.pair_cnt) HIPCHK(hipMalloc((void **)&D.pair_cnt, kOwPairCounters * sizeof(unsigned)));
-                    hipError_t he = lgh == 15 ? ow_launch_stream_15(kSrcU32Ext, out, a, gridp, D.pair_cnt, 0, 0, st)
-                                              : ow_launch_stream_14(kSrcU32Ext, out, a, gridp, D.pair_cnt, 0, 0, st);
+                    CHK(ws_buffer(&W.pair_cnt, kOwPairCounters));
+                    hipError_t he = lgh == 15 ? ow_launch_stream_15(kSrcU32Ext, out, a, gridp, W.pair_cnt, 0, 0, st)
+                                              : ow_launch_stream_14(kSrcU32Ext, out, a, gridp, W.pair_cnt, 0, 0, st);
                     if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (2^%d-point halves): %s", lgh, hipGetErrorString(he));
                 } else CHK(onewg_launch(lgh, mode, out, half, a, st));
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
