@@ -7,9 +7,13 @@
 
 namespace cuhe_impl {
 
+int g_icrt_acc64 = getenv("CUHE_ICRT_ACC64") ? atoi(getenv("CUHE_ICRT_ACC64")) : 1;      // (environment override: A/B runs)
 int icrt_lds_attr(size_t lds) {                 // k_icrt needs the large-LDS attribute for many primes
     static AttrOnce once;
-    return lds > 64 * 1024 ? once.set(k_icrt, 160 * 1024) : CUHE_OK;
+    if (lds <= 64 * 1024) return CUHE_OK;
+    CHK(once.set(k_icrt<false>, 160 * 1024));
+    static AttrOnce once64;
+    return once64.set(k_icrt<true>, 160 * 1024);
 }
 
 // ICRT of `batch` ciphertexts of level lvl (np primes, W words)
@@ -21,7 +25,13 @@ int launch_icrt(u32 *dst, const u32 *src, const DevCtx &D, int lvl, int np, int 
     const dim3 grid((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), block(kIcrtCoef * kIcrtGroups);
     const size_t lds = icrt_lds_bytes(np, W);
     CHK(icrt_lds_attr(lds));
-    hipLaunchKernelGGL(k_icrt, grid, block, lds, st, dst, src, prime_tab(D), it, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride, wo);
+    // 64-bit column sums where they cannot overflow (see icrt_mac4_64): sum_i t_i m_i[k] + q M[k] < np pmax 2^32 + np 2^32 with
+    // t_i < p_i <= pmax, every word below 2^32, q < np
+    unsigned long long pmax = 0;
+    for (int i = 0; i < np && i < (int)G_.primes.size(); ++i) pmax = std::max<unsigned long long>(pmax, G_.primes[i]);
+    const bool acc64 = g_icrt_acc64 && pmax > 0 && (unsigned long long)(np + 1) * (pmax + 1) < (1ull << 32);
+    if (acc64) hipLaunchKernelGGL(k_icrt<true>, grid, block, lds, st, dst, src, prime_tab(D), it, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride, wo);
+    else hipLaunchKernelGGL(k_icrt<false>, grid, block, lds, st, dst, src, prime_tab(D), it, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride, wo);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }

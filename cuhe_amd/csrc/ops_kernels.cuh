@@ -805,6 +805,18 @@ __device__ __forceinline__ void icrt_mac4(u32 t, u32 c0, u32 c1, u32 c2, u32 c3,
         : [t] "v"(t), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2), [c3] "s"(c3)
         : "vcc");
 }
+// the same with 64-bit accumulators, for levels where a whole column sum fits them -- np (2^logCrtPrime + 1) < 2^32: every
+// t_i < p_i < 2^logCrtPrime, every word below 2^32, q < np -- which is every parameter set of the reference's examples (24- and
+// 25-bit primes): ONE instruction per multiply-add, the carry-out is dead
+__device__ __forceinline__ void icrt_mac4_64(u32 t, u32 c0, u32 c1, u32 c2, u32 c3, u64 (&lo)[4]) {
+    asm("v_mad_u64_u32 %[l0], vcc, %[t], %[c0], %[l0]\n\t"
+        "v_mad_u64_u32 %[l1], vcc, %[t], %[c1], %[l1]\n\t"
+        "v_mad_u64_u32 %[l2], vcc, %[t], %[c2], %[l2]\n\t"
+        "v_mad_u64_u32 %[l3], vcc, %[t], %[c3], %[l3]"
+        : [l0] "+v"(lo[0]), [l1] "+v"(lo[1]), [l2] "+v"(lo[2]), [l3] "+v"(lo[3])
+        : [t] "v"(t), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2), [c3] "s"(c3)
+        : "vcc");
+}
 // optional second output of k_icrt: the relinearisation windows of the coefficients (what k_extract_windows makes of the
 // raw words), written straight from the result words in LDS -- the batched chain then needs neither the raw rows nor
 // the extraction kernel (151 + 151 MB of traffic per 32 ciphertexts at config 4)
@@ -867,7 +879,8 @@ __device__ __forceinline__ void icrt_finish(u32 *__restrict__ dst, uint4 *blk, c
         if (k >= W) { k -= W; ++c2; }
     }
 }
-static __global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
+template <bool ACC64>
+__global__ __launch_bounds__(kIcrtCoef * kIcrtGroups)
 void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, IcrtTab it,
             int np, int W, int mlen, int clen, long src_ct_stride, long dst_ct_stride, IcrtWindows wo) {
     src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: ciphertext of a batched call (strides in words)
@@ -925,7 +938,8 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
                 const u32 t = tt[(i0 + ii) * CB + ci];
-                icrt_mac4(t, c[ii][0], c[ii][1], c[ii][2], c[ii][3], lo, hi);
+                if constexpr (ACC64) icrt_mac4_64(t, c[ii][0], c[ii][1], c[ii][2], c[ii][3], lo);
+                else icrt_mac4(t, c[ii][0], c[ii][1], c[ii][2], c[ii][3], lo, hi);
             }
         }
         // the four columns, 32 bits apart, minus q * M: four words and a signed carry (column < 2^71, so the carry fits)
