@@ -384,10 +384,35 @@ def bench_prince(world, single_dev):
         if r.returncode != 0 or not line:
             return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
         rec = json.loads(line[-1])
-        return {"value": rec["prince_seconds"], "unit": "s per PRINCE block (64 ciphertext bits, 1920 cAnd, 1152 relin, 24 levels)", "n_gpus": rec["devices"],
-                "virtual_devices": rec["virtual"], "known_answer": rec["kat"], "known_answer_ok": rec["kat_ok"],
-                "params": "CuDHS(25,2,16,25,25,21845): n=16384, 32K-point transforms, 25 -> 1 primes, 40 keys",
-                "mode": "CuCtxtArray gates, asynchronous, one host thread per GPU (Prince.cu:194-200)"}
+        out = {"value": rec["prince_seconds"], "unit": "s per PRINCE block (64 ciphertext bits, 1920 cAnd, 1152 relin, 24 levels)", "n_gpus": rec["devices"],
+               "virtual_devices": rec["virtual"], "known_answer": rec["kat"], "known_answer_ok": rec["kat_ok"],
+               "params": "CuDHS(25,2,16,25,25,21845): n=16384, 32K-point transforms, 25 -> 1 primes, 40 keys",
+               "client": "CuCtxtArray (not the reference's call pattern)",
+               "mode": "CuCtxtArray gates, asynchronous, one host thread per GPU (Prince.cu:194-200)"}
+        out["gate_by_gate"] = bench_prince_gate_by_gate()
+        return out
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
+
+
+def bench_prince_gate_by_gate():
+    """The reference client's call pattern (examples/Prince/Prince.cu:204-322: ONE host thread, the default stream, one
+    CuCtxt gate per call) on one GPU, same block and known answer: with the reference's synchronise-per-gate semantics
+    (cuhe/CuHE.cu:98,121,139,157) and with the library's scheduled gates (CuHE.h setScheduled / CUHE_SCHED=1: the same
+    client code, independent gates issued concurrently by the library's worker threads)."""
+    try:
+        exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_flow")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cuhe_amd", "cxx"), "-s", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        r = subprocess.run([exe, "--threads", "1", "--no-round-checks", "--compare"], capture_output=True, text=True, timeout=900)
+        secs = {}
+        for l in r.stdout.splitlines():
+            if l.startswith("Prince Encryption:"):
+                secs["scheduled_1thread" if "scheduled gates" in l else "sync_1thread"] = float(l.split()[2])
+        ok = r.returncode == 0 and r.stdout.count("9fb51935fc3df524   expected 9fb51935fc3df524   right") == 2 and len(secs) == 2
+        if not ok:
+            return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}
+        secs.update({"unit": "s per PRINCE block, CuCtxt gates one per call from one host thread (the reference client's pattern)", "known_answer_ok": True})
+        return secs
     except Exception as ex:
         return {"error": repr(ex)[:300]}
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "cuhe_hip_malloc": (vp, [i32, sz]),
     "cuhe_hip_free": (i32, [i32, vp]),
     "cuhe_hip_set_alloc_cache": (i32, [sz]),
+    "cuhe_hip_alloc_counters": (i32, [vp]),
     "cuhe_hip_malloc_stream": (vp, [i32, sz, vp]),
     "cuhe_hip_free_stream": (i32, [i32, vp, vp]),
     "cuhe_hip_host_alloc": (vp, [sz]),
@@ -71,6 +72,12 @@ SIGNATURES = {
     "cuhe_hip_stream_destroy": (i32, [i32, vp]),
     "cuhe_hip_device_sync": (i32, [i32]),
     "cuhe_hip_stream_sync": (i32, [i32, vp]),
+    "cuhe_hip_event_create": (i32, [i32, vp]),
+    "cuhe_hip_event_destroy": (i32, [i32, vp]),
+    "cuhe_hip_event_record": (i32, [i32, vp, vp]),
+    "cuhe_hip_stream_wait_event": (i32, [i32, vp, vp]),
+    "cuhe_hip_event_sync": (i32, [i32, vp]),
+    "cuhe_hip_event_query": (i32, [i32, vp]),
     "cuhe_hip_crt": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_icrt": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_crt_add": (i32, [vp, vp, vp, i32, i32, vp]),

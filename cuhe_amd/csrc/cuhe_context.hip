@@ -433,17 +433,36 @@ int cuhe_hip_set_alloc_cache(size_t bytes) { G_.cache_cap = bytes; return CUHE_O
 // device, which is more than a whole CRT or NTT stage of a ciphertext takes, and the API allocates and frees a
 // representation on every domain change (cuhe/CuHE.cu:356-408).  Freed blocks are therefore parked and handed out
 // again for the same size: without limit while startAllocator() is in effect, up to cache_cap bytes otherwise.
+static long long g_alloc_counters[4];      // hipMalloc calls, hits in the settled pool, hits in a stream's parked blocks, idle streams settled
+int cuhe_hip_alloc_counters(long long *out4) {
+    std::lock_guard<std::mutex> lk(G_.mu);
+    for (int i = 0; i < 4; ++i) out4[i] = g_alloc_counters[i];
+    return CUHE_OK;
+}
 void *cuhe_hip_malloc(int dev, size_t bytes) {
     if (set_dev(dev) != CUHE_OK) return nullptr;
     DevCtx &D = G_.dev[dev];
     std::lock_guard<std::mutex> lk(G_.mu);
     auto it = D.freeBlocks.find(bytes);
+    if (it == D.freeBlocks.end()) {
+        // a miss: blocks of this size parked in the order of a stream that has gone idle since are free (several streams
+        // of one host thread under the gate scheduler, none of which is ever synchronised by the client)
+        for (auto sb = D.streamBlocks.begin(); sb != D.streamBlocks.end();) {
+            if (sb->second.find(bytes) != sb->second.end() && hipStreamQuery(sb->first) == hipSuccess) {
+                for (auto &kv : sb->second) D.freeBlocks.insert(kv);
+                sb = D.streamBlocks.erase(sb);
+            } else { (void)hipGetLastError(); ++sb; }
+        }
+        it = D.freeBlocks.find(bytes);
+    }
     if (it != D.freeBlocks.end()) {
         void *p = it->second;
         D.freeBlocks.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+        ++g_alloc_counters[1];
         return p;
     }
     void *p = nullptr;
+    ++g_alloc_counters[0];
     if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
         (void)hipGetLastError();
         drop_cached(D);                                   // give the parked blocks back and try once more
@@ -480,6 +499,29 @@ void *cuhe_hip_malloc_stream(int dev, size_t bytes, void *st) {
             if (it != sb->second.end()) {
                 void *p = it->second;
                 sb->second.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+                ++g_alloc_counters[2];
+                return p;
+            }
+        }
+        // Nothing parked for this stream and nothing settled: take a block parked in the order of ANOTHER stream and
+        // make this stream wait for everything enqueued there so far (the block's last use is part of it).  Several
+        // streams of one client under the gate scheduler hand blocks to each other all the time -- a task frees on its
+        // own stream what a task on another stream allocated -- and none of them is ever synchronised, so without this
+        // every such hand-over ends in hipMalloc (hundreds of microseconds, under the library's lock).
+        if (D.freeBlocks.find(bytes) == D.freeBlocks.end()) {
+            for (auto &other : D.streamBlocks) {
+                if (other.first == S(st)) continue;
+                auto it = other.second.find(bytes);
+                if (it == other.second.end()) continue;
+                hipEvent_t ev = nullptr;
+                if (!D.fenceEvents.empty()) { ev = D.fenceEvents.back(); D.fenceEvents.pop_back(); }
+                else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); break; }
+                const bool ok = hipEventRecord(ev, other.first) == hipSuccess && hipStreamWaitEvent(S(st), ev, 0) == hipSuccess;
+                D.fenceEvents.push_back(ev);           // the wait captured the record: the event can serve again at once
+                if (!ok) { (void)hipGetLastError(); break; }
+                void *p = it->second;
+                other.second.erase(it); D.cachedBytes -= bytes; D.allocated[p] = bytes;
+                ++g_alloc_counters[3];
                 return p;
             }
         }
@@ -534,6 +576,25 @@ int cuhe_hip_stream_sync(int dev, void *st) {
     HIPCHK(hipStreamSynchronize(S(st)));
     settle_stream_blocks(G_.dev[dev], S(st));
     return CUHE_OK;
+}
+
+int cuhe_hip_event_create(int dev, void **out) {
+    CHK(set_dev(dev));
+    hipEvent_t e = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = (void *)e;
+    return CUHE_OK;
+}
+int cuhe_hip_event_destroy(int dev, void *ev) { CHK(set_dev(dev)); if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev)); return CUHE_OK; }
+int cuhe_hip_event_record(int dev, void *ev, void *st) { CHK(set_dev(dev)); HIPCHK(hipEventRecord((hipEvent_t)ev, S(st))); return CUHE_OK; }
+int cuhe_hip_stream_wait_event(int dev, void *st, void *ev) { CHK(set_dev(dev)); HIPCHK(hipStreamWaitEvent(S(st), (hipEvent_t)ev, 0)); return CUHE_OK; }
+int cuhe_hip_event_sync(int dev, void *ev) { CHK(set_dev(dev)); HIPCHK(hipEventSynchronize((hipEvent_t)ev)); return CUHE_OK; }
+int cuhe_hip_event_query(int dev, void *ev) {
+    CHK(set_dev(dev));
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipSuccess) return CUHE_OK;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+    return fail(CUHE_EHIP, "hipEventQuery failed : %s", hipGetErrorString(e));
 }
 
 // waits for everything enqueued on the device; every block freed in stream order becomes an ordinary free block

@@ -122,6 +122,7 @@ struct DevCtx {
     std::map<void *, size_t> allocated;
     size_t cachedBytes = 0;              // bytes parked in freeBlocks and streamBlocks
     std::map<hipStream_t, std::multimap<size_t, void *>> streamBlocks;   // freed in stream order, not yet synchronised
+    std::vector<hipEvent_t> fenceEvents;                                  // hand-over of a parked block to another stream (cuhe_hip_malloc_stream)
 };
 
 struct Global {

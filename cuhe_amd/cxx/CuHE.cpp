@@ -8,6 +8,7 @@
 #include "DeviceManager.h"
 #include "Operations.h"
 #include "Relinearization.h"
+#include "Scheduler.h"
 
 #include <cstdio>
 #include <cstring>
@@ -85,11 +86,36 @@ bool isAsynchronous() { return asyncGates; }
 // order, exactly like asynchronous gates; the operation as a whole keeps the reference's "returns synchronised" contract.
 static thread_local int gateDepth = 0;
 struct GateScope { GateScope() { ++gateDepth; } ~GateScope() { --gateDepth; } };
-static inline bool streamOrdered() { return asyncGates || gateDepth > 0; }
+static inline bool streamOrdered() { return asyncGates || gateDepth > 0 || sched::inWorker(); }   // a scheduler task only enqueues
+
+// ---- scheduled gates (addition; Scheduler.h).  The client object mirrors the metadata, the recorded tasks run the very
+// same gates below on the scheduler-side objects (from a worker thread, where scheduled() is false).
+void setScheduled(bool on, int threads) { if (on) sched::start(threads); else sched::stop(); }
+bool isScheduled() { return sched::on(); }
+void synchronize() { if (sched::on() && !sched::inWorker()) sched::drain(); }
+static void schedFromEnvironment() {
+	const char *e = getenv("CUHE_SCHED");
+	if (e && atoi(e) > 0 && !sched::on()) sched::start(atoi(e) > 1 ? atoi(e) : 0);
+}
+static bool schedCheck() { static const bool on = getenv("CUHE_SCHED_CHECK") && atoi(getenv("CUHE_SCHED_CHECK")) > 0; return on; }
+struct SchedAccess {
+	static cudaStream_t &stream(CuPolynomial &p) { return p.stream_; }
+	static int &level(CuCtxt &c) { return c.level_; }
+	static CuCtxt &ct(sched::Node *n) { return *static_cast<CuCtxt *>(n->obj); }
+	static CuPtxt &pt(sched::Node *n) { return *static_cast<CuPtxt *>(n->obj); }
+	// `dst` becomes what a gate makes of its output when it is shaped like `like` (prepareOut, copy)
+	static void setDevice(CuPolynomial &p, int dev) { p.device_ = dev; }
+	static void setProd(CuPolynomial &p, bool prod, int terms) { p.isProd_ = prod; p.prodTerms_ = terms; }
+	static void shapeLike(CuCtxt &dst, CuCtxt &like, int domain) {
+		dst.level_ = like.level_; dst.logq_ = like.logq_; dst.device_ = like.device_; dst.domain_ = domain;
+		dst.isProd_ = false; dst.prodTerms_ = 0; clear(dst.zRep_);
+	}
+};
+typedef std::vector<sched::Node *> Nodes;
 #define GATE_SYNC(dev, st) do { if (!streamOrdered()) CSC(cuhe_hip_stream_sync(dev, st)); } while (0)
 
 static void *devAlloc(int dev, size_t bytes, cudaStream_t st = 0) {
-	void *p = streamOrdered() ? cuhe_hip_malloc_stream(dev, bytes, st) : cuhe_hip_malloc(dev, bytes);
+	void *p = sched::inWorker() ? sched::taskAlloc(dev, bytes) : streamOrdered() ? cuhe_hip_malloc_stream(dev, bytes, st) : cuhe_hip_malloc(dev, bytes);
 	if (!p) CSC(CUHE_EHIP);
 	return p;
 }
@@ -220,11 +246,13 @@ void setParameters(int d, int p, int w, int min, int cut, int m) { setParam(d, p
 void resetParameters() { resetParam(); }
 void multiGPUs(int num) { setNumDevices(num); }
 int numGPUs() { return numDevices(); }
-void startAllocator() { bootDeviceAllocator((size_t)param.numCrtPrime * param.nttLen * sizeof(uint64)); }
-void stopAllocator() { haltDeviceAllocator(); }
-void initRelinearization(ZZX *evalkey) { initRelin(evalkey); }
+void startAllocator() { synchronize(); bootDeviceAllocator((size_t)param.numCrtPrime * param.nttLen * sizeof(uint64)); }
+void stopAllocator() { synchronize(); haltDeviceAllocator(); }
+void initRelinearization(ZZX *evalkey) { synchronize(); initRelin(evalkey); }
 
 void initCuHE(ZZ *coeffMod_, ZZX modulus) {
+	synchronize();
+	schedFromEnvironment();
 	initNtt();
 	installModulus(modulus);
 	initialisedByParts = false;
@@ -234,33 +262,84 @@ void initCuHE(ZZ *coeffMod_, ZZX modulus) {
 // ------------------------------------------------------------------ CuPolynomial
 static void misuse(const char *msg) { cout << msg << endl; terminate(); }
 
-CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), prodTerms_(0), rRep_(NULL), cRep_(NULL), nRep_(NULL), stream_(0) { clear(zRep_); }
+CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), prodTerms_(0), rRep_(NULL), cRep_(NULL), nRep_(NULL), stream_(0), node_(NULL), exposed_(false) { clear(zRep_); }
 CuPolynomial::~CuPolynomial() { reset(); }
+// ---- attached / detached (scheduled mode)
+bool CuPolynomial::scheduled() {
+	if (sched::inWorker()) return false;                        // a recorded gate running on the scheduler-side objects
+	if (sched::on()) return true;
+	if (node_) schedDetach();                                   // the mode was switched off: back to a plain object
+	return false;
+}
+void CuPolynomial::moveStateFrom(CuPolynomial &o) {
+	logq_ = o.logq_; domain_ = o.domain_; device_ = o.device_; isProd_ = o.isProd_; prodTerms_ = o.prodTerms_;
+	{ using std::swap; clear(zRep_); swap(zRep_, o.zRep_); }
+	rRep_ = o.rRep_; cRep_ = o.cRep_; nRep_ = o.nRep_; stream_ = o.stream_;
+	o.rRep_ = NULL; o.cRep_ = NULL; o.nRep_ = NULL;
+}
+void CuCtxt::moveStateFrom(CuPolynomial &o) { CuPolynomial::moveStateFrom(o); level_ = static_cast<CuCtxt &>(o).level_; }
+sched::Node *CuPolynomial::schedAttach() {
+	if (node_) return node_;
+	// work enqueued by asynchronous gates on this object's stream is not known to the scheduler
+	if (asyncGates && device_ >= 0 && (rRep_ || cRep_ || nRep_)) CSC(cuhe_hip_stream_sync(device_, stream_));
+	if (exposed_ && device_ >= 0) { CSC(cuhe_hip_device_sync(device_)); exposed_ = false; }
+	CuPolynomial *obj = newSameKind();
+	obj->moveStateFrom(*this);                                  // the metadata stays here as well: the mirror
+	node_ = sched::newNode(obj);
+	return node_;
+}
+void CuPolynomial::schedDetach() {
+	if (!node_) return;
+	sched::waitNode(node_);                                     // this object's thread is the only one that records on the node
+	CuPolynomial *obj = node_->obj;
+	if (schedCheck() && (obj->logq_ != logq_ || obj->domain_ != domain_ || obj->device_ != device_ || obj->isProd_ != isProd_ || obj->prodTerms_ != prodTerms_)) {
+		printf("Error: scheduler mirror out of step: logq %d/%d domain %d/%d device %d/%d isProd %d/%d terms %d/%d\n", obj->logq_, logq_, obj->domain_, domain_,
+		       obj->device_, device_, (int)obj->isProd_, (int)isProd_, obj->prodTerms_, prodTerms_);
+		terminate();
+	}
+	moveStateFrom(*obj);
+	sched::Node *n = node_; node_ = NULL;
+	sched::releaseNode(n);
+}
+void CuPolynomial::schedRelease() {
+	if (!node_) return;
+	sched::Node *n = node_; node_ = NULL;
+	sched::submit(device_ >= 0 ? device_ : 0, Nodes(), Nodes(1, n), [n](void *s) { n->obj->stream_ = s; n->obj->reset(); });
+	sched::releaseNode(n);
+}
 void CuPolynomial::reset() {
+	if (node_ && !sched::inWorker()) { if (sched::on()) schedRelease(); else schedDetach(); }
 	clear(zRep_);
 	if (rRep_ != NULL) rRepFree();
 	if (cRep_ != NULL) cRepFree();
 	if (nRep_ != NULL) nRepFree();
 	isProd_ = false; prodTerms_ = 0; logq_ = -1; domain_ = -1; device_ = -1;
 }
-void CuPolynomial::logq(int val) { logq_ = val; }
-void CuPolynomial::domain(int val) { domain_ = val; }
-void CuPolynomial::device(int val) { device_ = val; }
-void CuPolynomial::isProd(bool val) { isProd_ = val; prodTerms_ = val ? (prodTerms_ > 0 ? prodTerms_ : 1) : 0; }
-void CuPolynomial::zRep(ZZX val) { zRep_ = std::move(val); }
-void CuPolynomial::rRep(uint32 *val) { rRep_ = val; }
-void CuPolynomial::cRep(uint32 *val) { cRep_ = val; }
-void CuPolynomial::nRep(uint64 *val) { nRep_ = val; }
+// the setters and the raw-pointer getters act on the state itself: an attached object is taken back first
+#define DETACHED() do { if (node_ && !sched::inWorker()) schedDetach(); } while (0)
+void CuPolynomial::logq(int val) { DETACHED(); logq_ = val; }
+void CuPolynomial::domain(int val) { DETACHED(); domain_ = val; }
+void CuPolynomial::device(int val) { DETACHED(); device_ = val; }
+void CuPolynomial::isProd(bool val) { DETACHED(); isProd_ = val; prodTerms_ = val ? (prodTerms_ > 0 ? prodTerms_ : 1) : 0; }
+void CuPolynomial::zRep(ZZX val) { DETACHED(); zRep_ = std::move(val); }
+void CuPolynomial::rRep(uint32 *val) { DETACHED(); rRep_ = val; }
+void CuPolynomial::cRep(uint32 *val) { DETACHED(); cRep_ = val; }
+void CuPolynomial::nRep(uint64 *val) { DETACHED(); nRep_ = val; }
 int CuPolynomial::logq() { return logq_; }
 int CuPolynomial::domain() { return domain_; }
 int CuPolynomial::device() { return device_; }
 bool CuPolynomial::isProd() { return isProd_; }
 ZZX CuPolynomial::zRep() { return zRep_; }
-void CuPolynomial::swapZRep(ZZX &other) { using std::swap; swap(zRep_, other); }
-uint32 *CuPolynomial::rRep() { return rRep_; }
-uint32 *CuPolynomial::cRep() { return cRep_; }
-uint64 *CuPolynomial::nRep() { return nRep_; }
-void CuPolynomial::stream(cudaStream_t st) { stream_ = st; }
+void CuPolynomial::swapZRep(ZZX &other) { DETACHED(); using std::swap; swap(zRep_, other); }
+// a raw pointer handed to the client in scheduled mode may be written through the Operations.h drivers on any stream:
+// the object is marked, and recording on it again first waits for the device (schedAttach)
+#define EXPOSED() do { if (!sched::inWorker()) { if (node_) schedDetach(); if (sched::on()) exposed_ = true; } } while (0)
+uint32 *CuPolynomial::rRep() { EXPOSED(); return rRep_; }
+uint32 *CuPolynomial::cRep() { EXPOSED(); return cRep_; }
+uint64 *CuPolynomial::nRep() { EXPOSED(); return nRep_; }
+// (inside a recorded gate the operands that are only read may be shared with gates running on other workers: their
+// buffers are ordered by the tasks' events, not by this field; written operands get the task's stream from the task)
+void CuPolynomial::stream(cudaStream_t st) { if (sched::inWorker()) return; DETACHED(); stream_ = st; }
 cudaStream_t CuPolynomial::stream() { return stream_; }
 int CuPolynomial::coeffWords() { return (logq_ + 31) / 32; }
 size_t CuPolynomial::rRepSize() { return (size_t)param.rawLen * coeffWords() * sizeof(uint32); }
@@ -293,7 +372,11 @@ void CuPolynomial::cRepAlloc(cudaStream_t st) {
 void CuPolynomial::nRepAlloc(cudaStream_t st) {
 	nRep_ = (uint64 *)devAlloc(device_, deviceAllocatorIsOn() ? poolBlock() : nRepSize(), stream_ = st);
 }
-static void devFree(int dev, void *p, cudaStream_t st) { CSC(streamOrdered() ? cuhe_hip_free_stream(dev, p, st) : cuhe_hip_free(dev, p)); }
+static void devFree(int dev, void *p, cudaStream_t st) {
+	if (sched::inWorker()) { if (sched::taskFree(dev, p)) return; }
+	else sched::forgetBlock(p);
+	CSC(streamOrdered() ? cuhe_hip_free_stream(dev, p, st) : cuhe_hip_free(dev, p));
+}
 void CuPolynomial::rRepFree() { devFree(device_, rRep_, stream_); rRep_ = NULL; }
 void CuPolynomial::cRepFree() { devFree(device_, cRep_, stream_); cRep_ = NULL; }
 void CuPolynomial::nRepFree() { devFree(device_, nRep_, stream_); nRep_ = NULL; }
@@ -394,27 +477,60 @@ void CuPolynomial::n2c(cudaStream_t st) {
 	cRepAlloc(st);
 	CSC(cuhe_hip_ct_intt(cRep_, U64P(nRep_), logq_, isProd_ ? 1 : 0, device_, st));    // inttMod for products, intt otherwise
 	GATE_SYNC(device_, st);
-	isProd_ = false;
+	isProd_ = false; prodTerms_ = 0;
 	nRepFree();
 	domain_ = 2;
 }
+// In scheduled mode a conversion is recorded as ONE task that writes this polynomial; the mirror takes the domain the
+// conversion ends in (and loses the product mark wherever the chain passes through n2c).
+#define RECORD_SELF(call) do { sched::Node *n_ = schedAttach(); \
+	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }); } while (0)
 void CuPolynomial::x2z(cudaStream_t st) {
+	if (scheduled()) {
+		if (domain_ < 1) return;
+		sched::Node *n = schedAttach();
+		sched::wait(sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { n->obj->stream_ = s; n->obj->x2z(s); }, true));
+		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
+		domain_ = 0;
+		schedDetach();                                             // a host value lives in the client's object
+		return;
+	}
 	GateScope chain;                                           // r2z ends with the copy to the host and its own synchronise
 	if (domain_ == 3) n2c(st);
 	if (domain_ == 2) c2r(st);
 	if (domain_ == 1) r2z(st);
 }
 void CuPolynomial::x2r(cudaStream_t st) {
+	if (scheduled()) {
+		if (domain_ == 1 || domain_ < 0) return;
+		RECORD_SELF(x2r(s));
+		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
+		domain_ = 1;
+		return;
+	}
 	if (domain_ == 0) { z2r(st); return; }
 	{ GateScope chain; if (domain_ == 3) n2c(st); if (domain_ == 2) c2r(st); }
 	GATE_SYNC(device_, st);
 }
 void CuPolynomial::x2c(cudaStream_t st) {
+	if (scheduled()) {
+		if (domain_ == 2 || domain_ < 0) return;
+		RECORD_SELF(x2c(s));
+		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
+		domain_ = 2;
+		return;
+	}
 	if (domain_ == 3) { n2c(st); return; }
 	{ GateScope chain; if (domain_ == 0) z2r(st); if (domain_ == 1) r2c(st); }
 	GATE_SYNC(device_, st);
 }
 void CuPolynomial::x2n(cudaStream_t st) {
+	if (scheduled()) {
+		if (domain_ == 3 || domain_ < 0) return;
+		RECORD_SELF(x2n(s));
+		domain_ = 3;
+		return;
+	}
 	{ GateScope chain; if (domain_ == 0) z2r(st); if (domain_ == 1) r2c(st); if (domain_ == 2) c2n(st); }
 	GATE_SYNC(device_, st);
 }
@@ -426,10 +542,26 @@ static void createRep(CuPolynomial &p, int domain, cudaStream_t st) {
 	else if (domain == 3) p.nRepCreate(st);
 }
 void CuCtxt::setLevel(int lvl, int domain, int device, cudaStream_t st) {
+	if (scheduled()) {
+		schedRelease();                                            // (the reference overwrites the pointers; here the old buffers are released)
+		level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
+		if (domain_ == 0) { clear(zRep_); return; }
+		sched::Node *n = schedAttach();
+		sched::submit(device_, Nodes(), Nodes(1, n), [n, lvl, domain, device](void *s) { SchedAccess::ct(n).setLevel(lvl, domain, device, s); });
+		return;
+	}
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
 void CuCtxt::setLevelForOutput(int lvl, int domain, int device, cudaStream_t st) {
+	if (scheduled()) {
+		schedRelease();
+		level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
+		if (domain_ == 0) { clear(zRep_); return; }
+		sched::Node *n = schedAttach();
+		sched::submit(device_, Nodes(), Nodes(1, n), [n, lvl, domain, device](void *s) { SchedAccess::ct(n).setLevelForOutput(lvl, domain, device, s); });
+		return;
+	}
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_);
 	else if (domain_ == 1) rRepAlloc(st);
@@ -437,6 +569,7 @@ void CuCtxt::setLevelForOutput(int lvl, int domain, int device, cudaStream_t st)
 	else if (domain_ == 3) nRepAlloc(st);
 }
 void CuCtxt::setLevel(int lvl, int device, ZZX val) {
+	if (scheduled()) schedRelease();
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = 0; device_ = device; zRep_ = std::move(val);
 }
 int CuCtxt::level() { return level_; }
@@ -444,6 +577,13 @@ size_t CuCtxt::cRepSize() { return (size_t)param._numCrtPrime(level_) * param.cr
 size_t CuCtxt::nRepSize() { return (size_t)param._numCrtPrime(level_) * cuhe_hip_ct_len() * sizeof(uint64); }   // ct rows: nttLen, or modLen on x^n + 1 rings
 void CuCtxt::modSwitch(cudaStream_t st) {
 	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
+	if (scheduled()) {
+		sched::Node *n = schedAttach();
+		sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { SchedAccess::stream(*n->obj) = s; SchedAccess::ct(n).modSwitch(s); });
+		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
+		domain_ = 2; logq_ -= param.logCoeffCut; level_++;
+		return;
+	}
 	{ GateScope chain; x2c(st); stream_ = st; crtModSwitch(cRep_, cRep_, logq_, device_, st); }
 	GATE_SYNC(device_, st);
 	logq_ -= param.logCoeffCut;
@@ -454,6 +594,12 @@ void CuCtxt::modSwitch(int lvl, cudaStream_t st) {
 	while (level_ < lvl) modSwitch(st);       // (the reference's loop never advances level_: SURVEY A.7)
 }
 void CuCtxt::relin(cudaStream_t st) {
+	if (scheduled()) {
+		sched::Node *n = schedAttach();
+		sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { SchedAccess::stream(*n->obj) = s; SchedAccess::ct(n).relin(s); });
+		domain_ = 2; isProd_ = false; prodTerms_ = 0;
+		return;
+	}
 	{
 		GateScope chain;
 		x2r(st);
@@ -467,16 +613,37 @@ void CuCtxt::relin(cudaStream_t st) {
 	GATE_SYNC(device_, st);
 }
 void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
+	if (scheduled()) {
+		schedRelease();
+		logq_ = logq; domain_ = domain; device_ = device;
+		if (domain_ == 0) { clear(zRep_); return; }
+		sched::Node *n = schedAttach();
+		sched::submit(device_, Nodes(), Nodes(1, n), [n, logq, domain, device](void *s) { SchedAccess::pt(n).setLogq(logq, domain, device, s); });
+		return;
+	}
 	logq_ = logq; domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
-void CuPtxt::setLogq(int logq, int device, ZZX val) { logq_ = logq; domain_ = 0; device_ = device; zRep_ = std::move(val); }
+void CuPtxt::setLogq(int logq, int device, ZZX val) { if (scheduled()) schedRelease(); logq_ = logq; domain_ = 0; device_ = device; zRep_ = std::move(val); }
 size_t CuPtxt::cRepSize() { return (size_t)param.crtLen * sizeof(uint32); }
 size_t CuPtxt::nRepSize() { return (size_t)cuhe_hip_ct_len() * sizeof(uint64); }
 
 // ------------------------------------------------------------------ gates
+// scheduled mode on for this call?  (every operand is asked: an object left attached after the mode was switched off is
+// taken back by scheduled())
+static bool recordGate(CuPolynomial &a, CuPolynomial &b) { const bool x = a.scheduled(), y = b.scheduled(); return x || y; }
+static bool recordGate(CuPolynomial &a, CuPolynomial &b, CuPolynomial &c) { const bool x = recordGate(a, b), y = c.scheduled(); return x || y; }
+#define OBJ(n) SchedAccess::ct(n)
 void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	if (&dst == &src) return;
+	if (recordGate(dst, src) && src.domain() > 0) {
+		sched::Node *ns = src.schedAttach(), *nd = dst.schedAttach();
+		sched::submit(src.device(), Nodes(1, ns), Nodes(1, nd), [ns, nd](void *s) { SchedAccess::stream(*nd->obj) = s; copy(OBJ(nd), OBJ(ns), s); });
+		const bool prod = src.isProd(); const int terms = src.prodTerms();
+		SchedAccess::shapeLike(dst, src, src.domain());
+		SchedAccess::setProd(dst, prod, terms);
+		return;
+	}
 	src.stream(st);
 	dst.reset();
 	dst.setLevelForOutput(src.level(), src.domain(), src.device(), st);
@@ -495,23 +662,50 @@ void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.device() != in1.device()) misuse("Error: Multiplication of different devices!");
 	if (in0.domain() != 3 || in1.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
 	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
+	if (recordGate(out, in0, in1)) {
+		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
+		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cAnd(OBJ(no), OBJ(n0), OBJ(n1), s); });
+		if (&out != &in0) SchedAccess::shapeLike(out, in0, 3);
+		SchedAccess::setProd(out, true, 1);
+		return;
+	}
 	prepareOut(out, in0, 3, st);
 	in0.stream(st); in1.stream(st); out.stream(st);
 	CSC(cuhe_hip_ct_mul(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
-	out.isProd(true);
+	out.isProd(true); out.prodTerms(1);
 	GATE_SYNC(out.device(), st);
 }
 void cAnd(CuCtxt &out, CuCtxt &inc, CuPtxt &inp, cudaStream_t st) {
 	if (inc.device() != inp.device()) misuse("Error: Multiplication of different devices!");
 	if (inc.domain() != 3 || inp.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
+	if (recordGate(out, inc, inp)) {
+		sched::Node *nc = inc.schedAttach(), *np = inp.schedAttach(), *no = out.schedAttach();
+		sched::submit(inc.device(), Nodes{nc, np}, Nodes(1, no), [nc, np, no](void *s) { SchedAccess::stream(*no->obj) = s; cAnd(OBJ(no), OBJ(nc), SchedAccess::pt(np), s); });
+		if (&out != &inc) SchedAccess::shapeLike(out, inc, 3);
+		SchedAccess::setProd(out, true, 1);
+		return;
+	}
 	prepareOut(out, inc, 3, st);
 	inc.stream(st); inp.stream(st); out.stream(st);
 	CSC(cuhe_hip_ct_mul_nx1(U64P(out.nRep()), U64P(inc.nRep()), U64P(inp.nRep()), out.logq(), out.device(), st));
-	out.isProd(true);
+	out.isProd(true); out.prodTerms(1);
 	GATE_SYNC(out.device(), st);
 }
 void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
+	if (recordGate(out, in0, in1)) {
+		if (in0.logq() != in1.logq()) misuse("Error: Addition of different levels!");
+		const int dom = in0.domain();
+		if (!((dom == 2 || dom == 3) && in1.domain() == dom)) misuse("Error: Addition of non-CRT-nor-NTT domain!");
+		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
+		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cXor(OBJ(no), OBJ(n0), OBJ(n1), s); });
+		// the mirror of what the gate below leaves in `out`
+		const int terms = in0.prodTerms() + in1.prodTerms();
+		const bool prod = in0.isProd() || in1.isProd(), reduced = dom == 3 && in0.isProd() && in1.isProd() && terms > cuhe_hip_ct_prod_headroom();
+		if (&out != &in0) SchedAccess::shapeLike(out, in0, dom);
+		if (dom == 3) SchedAccess::setProd(out, !reduced && prod, !reduced && prod ? (terms > 0 ? terms : 1) : 0);
+		return;
+	}
 	in0.stream(st); in1.stream(st);
 	if (in0.logq() != in1.logq()) misuse("Error: Addition of different levels!");
 	if (in0.domain() == 2 && in1.domain() == 2) {
@@ -543,19 +737,38 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 }
 void cXor(CuCtxt &out, CuCtxt &in0, CuPtxt &in1, cudaStream_t st) {
 	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
+	// the products summed into the result: those of the ciphertext plus those of the plaintext (the count must
+	// survive the sum with a plaintext, or a later cXor adds more products than the NTT domain holds exactly)
+	const bool prodSum = in0.isProd() || in1.isProd();
+	const int termSum = prodSum ? (in0.prodTerms() + in1.prodTerms() > 0 ? in0.prodTerms() + in1.prodTerms() : 1) : 0;
+	if (recordGate(out, in0, in1)) {
+		const int dom = in0.domain();
+		if (!((dom == 2 || dom == 3) && in1.domain() == dom)) misuse("Error: Addition of non-CRT-nor-NTT domain!");
+		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
+		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cXor(OBJ(no), OBJ(n0), SchedAccess::pt(n1), s); });
+		if (&out != &in0) SchedAccess::shapeLike(out, in0, dom);
+		if (dom == 3) SchedAccess::setProd(out, prodSum, termSum);
+		return;
+	}
 	in0.stream(st); in1.stream(st);
 	if (in0.domain() == 2 && in1.domain() == 2) {
 		prepareOut(out, in0, 2, st);
 		crtAddNX1(out.cRep(), in0.cRep(), in1.cRep(), out.logq(), out.device(), st);
 	} else if (in0.domain() == 3 && in1.domain() == 3) {
-		const bool prod = in0.isProd() || in1.isProd();
-		if (&out != &in0) { prepareOut(out, in0, 3, st); out.isProd(prod); }
+		if (&out != &in0) prepareOut(out, in0, 3, st);
 		CSC(cuhe_hip_ct_add_nx1(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
+		out.isProd(prodSum); out.prodTerms(termSum);
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
 	GATE_SYNC(out.device(), st);
 }
 void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
 	if (in.domain() != 2) misuse("Error: cNot of non-CRT domain!");
+	if (recordGate(out, in)) {
+		sched::Node *ni = in.schedAttach(), *no = out.schedAttach();
+		sched::submit(in.device(), Nodes(1, ni), Nodes(1, no), [ni, no](void *s) { SchedAccess::stream(*no->obj) = s; cNot(OBJ(no), OBJ(ni), s); });
+		if (&out != &in) { const bool prod = in.isProd(); const int terms = in.prodTerms(); SchedAccess::shapeLike(out, in, 2); SchedAccess::setProd(out, prod, terms); }
+		return;
+	}
 	in.stream(st);
 	if (&out != &in) {
 		// the reference allocates a zeroed result and only writes the constant term (crt_add_int,
@@ -571,6 +784,14 @@ void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
 static void *peerAlloc(int dev, size_t bytes) { void *p = cuhe_hip_malloc(dev, bytes); if (!p) CSC(CUHE_EHIP); return p; }
 void moveTo(CuCtxt &tar, int dstDev, cudaStream_t st) {
 	if (dstDev == tar.device()) return;
+	if (tar.scheduled() && tar.domain() > 0) {
+		// recorded on a stream of the SOURCE device, like the copy itself; the eager code below synchronises that stream
+		// before it returns, so tasks on the destination device find the data in place
+		sched::Node *n = tar.schedAttach();
+		sched::submit(tar.device(), Nodes(), Nodes(1, n), [n, dstDev](void *s) { SchedAccess::stream(*n->obj) = s; moveTo(OBJ(n), dstDev, s); });
+		SchedAccess::setDevice(tar, dstDev);
+		return;
+	}
 	const int srcDev = tar.device();
 	if (tar.domain() == 1) {
 		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.rRepSize());
@@ -685,12 +906,12 @@ void CuCtxtArray::release() {
 	// until s has been synchronised; releasing on another stream could hand it out while kernels still touch it)
 	if (cRep_) { devFree(device_, cRep_, stream_); cRep_ = NULL; }
 	if (nRep_) { devFree(device_, nRep_, stream_); nRep_ = NULL; }
-	count_ = 0; level_ = -1; domain_ = -1; isProd_ = false;
+	count_ = 0; level_ = -1; domain_ = -1; isProd_ = false; prodTerms_ = 0;
 }
 void CuCtxtArray::create(int count, int lvl, int domain, int device, cudaStream_t st) {
 	if (count < 1 || lvl < 0 || lvl >= param.depth || (domain != 2 && domain != 3)) arrayMisuse("CuCtxtArray::create: bad count, level or domain");
 	release();
-	count_ = count; level_ = lvl; domain_ = domain; device_ = device; isProd_ = false; stream_ = st;
+	count_ = count; level_ = lvl; domain_ = domain; device_ = device; isProd_ = false; prodTerms_ = 0; stream_ = st;
 	// storage is sized for level 0 whatever the level: a circuit walks down the levels with arrays of the same few
 	// counts, and blocks of the same size come back from the library's block cache instead of hipMalloc / hipFree
 	if (domain == 2) cRep_ = (uint32 *)devAlloc(device, count * arrayCtWords(0) * sizeof(uint32), st);
@@ -704,7 +925,11 @@ void CuCtxtArray::put(int i, CuCtxt &src, cudaStream_t st) {
 		arrayMisuse("CuCtxtArray::put: index, level, domain or device mismatch");
 	touch(st);
 	if (domain_ == 2) CSC(cuhe_hip_memcpy_d2d(device_, cRep(i), src.cRep(), src.cRepSize(), st));
-	else { CSC(cuhe_hip_memcpy_d2d(device_, nRep(i), src.nRep(), src.nRepSize(), st)); isProd_ = isProd_ || src.isProd(); }
+	else {
+		CSC(cuhe_hip_memcpy_d2d(device_, nRep(i), src.nRep(), src.nRepSize(), st));
+		isProd_ = isProd_ || src.isProd();
+		if (src.prodTerms() > prodTerms_) prodTerms_ = src.prodTerms();      // the array remembers its largest sum of products
+	}
 	GATE_SYNC(device_, st);
 }
 void CuCtxtArray::get(CuCtxt &dst, int i, cudaStream_t st) {
@@ -713,7 +938,7 @@ void CuCtxtArray::get(CuCtxt &dst, int i, cudaStream_t st) {
 	dst.reset();
 	dst.setLevelForOutput(level_, domain_, device_, st);
 	if (domain_ == 2) CSC(cuhe_hip_memcpy_d2d(device_, dst.cRep(), cRep(i), dst.cRepSize(), st));
-	else { CSC(cuhe_hip_memcpy_d2d(device_, dst.nRep(), nRep(i), dst.nRepSize(), st)); dst.isProd(isProd_); }
+	else { CSC(cuhe_hip_memcpy_d2d(device_, dst.nRep(), nRep(i), dst.nRepSize(), st)); dst.isProd(isProd_); dst.prodTerms(isProd_ ? (prodTerms_ > 0 ? prodTerms_ : 1) : 0); }
 	GATE_SYNC(device_, st);
 }
 void CuCtxtArray::x2n(cudaStream_t st) {
@@ -726,7 +951,7 @@ void CuCtxtArray::x2n(cudaStream_t st) {
 		CSC(cuhe_hip_ntt_rows(U64P(nRep_), cRep_, count_ * param._numCrtPrime(level_), device_, st));
 		devFree(device_, cRep_, st); cRep_ = NULL;
 	}
-	domain_ = 3; isProd_ = false;
+	domain_ = 3; isProd_ = false; prodTerms_ = 0;
 	GATE_SYNC(device_, st);
 }
 void CuCtxtArray::x2c(cudaStream_t st) {
@@ -740,7 +965,7 @@ void CuCtxtArray::x2c(cudaStream_t st) {
 		else for (int i = 0; i < count_; ++i) CSC(cuhe_hip_ct_intt(cRep(i), U64P(nRep(i)), param._logCoeff(level_), 0, device_, st));
 		devFree(device_, nRep_, st); nRep_ = NULL;
 	}
-	domain_ = 2; isProd_ = false;
+	domain_ = 2; isProd_ = false; prodTerms_ = 0;
 	GATE_SYNC(device_, st);
 }
 void CuCtxtArray::relin(cudaStream_t st) {
@@ -769,10 +994,10 @@ void CuCtxtArray::modSwitch(cudaStream_t st) {
 void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStream_t st) {
 	if (parts.empty() || !parts[0]) arrayMisuse("concat: no parts");
 	const int lvl = parts[0]->level(), dom = parts[0]->domain(), dev = parts[0]->device();
-	int total = 0; bool prod = false;
+	int total = 0, terms = 0; bool prod = false;
 	for (CuCtxtArray *p : parts) {
 		if (!p || p == &dst || p->level() != lvl || p->domain() != dom || p->device() != dev) arrayMisuse("concat: parts must share level, domain and device");
-		total += p->count(); prod = prod || p->isProd();
+		total += p->count(); prod = prod || p->isProd(); if (p->prodTerms_ > terms) terms = p->prodTerms_;
 	}
 	{
 		GateScope chain;
@@ -784,7 +1009,7 @@ void concat(CuCtxtArray &dst, const std::vector<CuCtxtArray *> &parts, cudaStrea
 			else CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(at), p->nRep_, p->count() * arrayCtElems(lvl) * sizeof(uint64), st));
 			at += p->count();
 		}
-		dst.isProd_ = prod;
+		dst.isProd_ = prod; dst.prodTerms_ = terms;
 	}
 	GATE_SYNC(dev, st);
 }
@@ -797,7 +1022,7 @@ void slice(CuCtxtArray &dst, CuCtxtArray &src, int first, int count, cudaStream_
 		src.touch(st);
 		if (src.domain() == 2) CSC(cuhe_hip_memcpy_d2d(src.device(), dst.cRep_, src.cRep(first), count * arrayCtWords(src.level()) * sizeof(uint32), st));
 		else CSC(cuhe_hip_memcpy_d2d(src.device(), dst.nRep_, src.nRep(first), count * arrayCtElems(src.level()) * sizeof(uint64), st));
-		dst.isProd_ = src.isProd_;
+		dst.isProd_ = src.isProd_; dst.prodTerms_ = src.prodTerms_;
 	}
 	GATE_SYNC(src.device(), st);
 }
@@ -823,7 +1048,7 @@ void cAnd(CuCtxtArray &out, CuCtxtArray &in, const CuIndexTable &a, const CuInde
 		out.create((int)a.size(), in.level(), 3, in.device(), st);
 		in.touch(st);
 		CSC(cuhe_hip_ntt_mul_pairs(U64P(out.nRep_), U64P(in.nRep_), a.data(), b.data(), (int)a.size(), param._numCrtPrime(in.level()), in.device(), st));
-		out.isProd_ = true;
+		out.isProd_ = true; out.prodTerms_ = 1;
 	}
 	GATE_SYNC(in.device(), st);
 }

@@ -19,6 +19,8 @@ typedef unsigned int uint32;
 typedef unsigned long int uint64;
 
 namespace cuHE {
+namespace sched { struct Node; }
+struct SchedAccess;
 
 // A polynomial living in exactly one of four domains:
 //   0 = ZZX (host), 1 = RAW (device, big coefficients), 2 = CRT (device,
@@ -28,7 +30,7 @@ namespace cuHE {
 class CuPolynomial {
 public:
 	CuPolynomial();
-	~CuPolynomial();
+	virtual ~CuPolynomial();
 	void reset();                    // idempotent; safe after an explicit destructor call
 	// setters (pointer setters copy the pointer, not the data)
 	void logq(int val);
@@ -74,7 +76,17 @@ public:
 	void rRepAlloc(cudaStream_t st = 0);
 	void cRepAlloc(cudaStream_t st = 0);
 	void nRepAlloc(cudaStream_t st = 0);
+	// (additions) scheduled mode (setScheduled, Scheduler.h): while a polynomial is ATTACHED its device buffers and host
+	// value live in a scheduler-side object (node_->obj) that the recorded gates work on; this object only mirrors the
+	// metadata (domain, level, logq, device, isProd).  schedDetach waits for the gates recorded on it and takes the state back.
+	sched::Node *schedAttach();
+	void schedDetach();
+	bool scheduled();                // true: record the operation instead of running it (detaches first when the mode is off)
 protected:
+	friend struct SchedAccess;
+	virtual CuPolynomial *newSameKind() const = 0;
+	virtual void moveStateFrom(CuPolynomial &other);
+	void schedRelease();             // let go of the node: its buffers are released by a recorded task
 	void z2r(cudaStream_t st = 0);   // ZZX -> RAW
 	void r2z(cudaStream_t st = 0);   // RAW -> ZZX
 	void r2c(cudaStream_t st = 0);   // CRT
@@ -91,6 +103,8 @@ protected:
 	uint32 *cRep_;
 	uint64 *nRep_;
 	cudaStream_t stream_;
+	sched::Node *node_;
+	bool exposed_;                   // a raw device pointer was handed out in scheduled mode
 };
 
 // ciphertext: a polynomial per CRT prime of its level
@@ -107,6 +121,9 @@ public:
 	size_t cRepSize();
 	size_t nRepSize();
 protected:
+	friend struct SchedAccess;
+	CuPolynomial *newSameKind() const { return new CuCtxt; }
+	void moveStateFrom(CuPolynomial &other);
 	int level_;
 };
 
@@ -117,6 +134,8 @@ public:
 	void setLogq(int logq, int dev, ZZX val);
 	size_t cRepSize();
 	size_t nRepSize();
+protected:
+	CuPolynomial *newSameKind() const { return new CuPtxt; }
 };
 
 // initialisation: setParameters first, then (optionally) multiGPUs, then initCuHE.
@@ -132,6 +151,15 @@ void setParameters(int d, int p, int w, int min, int cut, int m);
 // or any x2z() -- before it reads a result on the host or hands a ciphertext to work on another stream.  Default: off.
 void setAsynchronous(bool on);
 bool isAsynchronous();
+// (addition) scheduled gates: the SAME client code -- one host thread, default stream, a gate per call -- with the
+// independent gates running concurrently.  Every public gate and conversion records a task (what it reads, what it
+// writes); worker threads of the library issue the tasks on their own streams as their inputs become available, ordered
+// on the GPU by events.  The client blocks only in x2z(), in the raw-pointer getters, and in synchronize().  Results are
+// those of the synchronous gates, bit for bit.  Also switched on by CUHE_SCHED=1 (CUHE_SCHED_THREADS=n workers) in the
+// environment at initCuHE, so that an unchanged client gets it.  Default: off (the reference's semantics).
+void setScheduled(bool on, int threads = 0);
+bool isScheduled();
+void synchronize();               // everything recorded so far has finished on the device (no-op when not scheduled)
 void resetParameters();
 void initRelinearization(ZZX *evalkey);
 

@@ -27,7 +27,7 @@ private:
 
 class CuCtxtArray {
 public:
-	CuCtxtArray() : count_(0), level_(-1), domain_(-1), device_(0), isProd_(false), cRep_(NULL), nRep_(NULL), stream_(0) {}
+	CuCtxtArray() : count_(0), level_(-1), domain_(-1), device_(0), isProd_(false), prodTerms_(0), cRep_(NULL), nRep_(NULL), stream_(0) {}
 	~CuCtxtArray() { release(); }
 	// `count` ciphertexts of level `lvl` in `domain` (2 = CRT, 3 = NTT), contents undefined
 	void create(int count, int lvl, int domain, int device = 0, cudaStream_t st = 0);
@@ -37,6 +37,7 @@ public:
 	int domain() const { return domain_; }
 	int device() const { return device_; }
 	bool isProd() const { return isProd_; }
+	int prodTerms() const { return prodTerms_; }      // the largest number of products summed into one of its ciphertexts (NTT domain)
 	uint32 *cRep(int i = 0);          // ciphertext i, CRT domain
 	uint64 *nRep(int i = 0);          // ciphertext i, NTT domain
 	// copy one ciphertext in / out; the CuCtxt must be in this array's domain, level and device
@@ -57,6 +58,7 @@ private:
 	friend void cXor(CuCtxtArray &, CuCtxtArray &, CuCtxtArray *, const CuIndexTable &, const CuIndexTable &, const CuIndexTable &, cudaStream_t);
 	int count_, level_, domain_, device_;
 	bool isProd_;
+	int prodTerms_;
 	uint32 *cRep_;
 	uint64 *nRep_;
 	cudaStream_t stream_;             // the stream that last produced or consumed the storage: blocks are released in its order

@@ -1,0 +1,56 @@
+// Scheduler.h -- dependency-tracked gate scheduling under the reference's API (addition; internal to libcuHE.so).
+//
+// The reference ends every public operation with cudaStreamSynchronize (cuhe/CuHE.cu:98,121,139,157) and its clients
+// issue one gate at a time from one host thread per device (examples/Prince/Prince.cu:194-322): the GPU runs one small
+// kernel at a time although, e.g., the six products and sixteen S-boxes of a PRINCE layer are independent.  In scheduled
+// mode (setScheduled(true) or CUHE_SCHED=1 in the environment) a public gate only RECORDS a task: which polynomials it
+// reads, which it writes, and the gate itself as a closure over their scheduler-side objects.  A small pool of worker
+// threads owned by the library issues the tasks, each worker on its own stream per device (and, like every host thread of
+// this library, with its own scratch): a task is issued as soon as the tasks it depends on have been issued, ordered on
+// the GPU by events (stream-wait on the event of every dependency that ran on another stream).  The client thread blocks
+// only where it needs a value on the host (x2z), a raw device pointer, or calls synchronize().
+//
+// This header is the graph half: tasks, nodes, workers.  CuHE.cpp binds the gates to it.
+#pragma once
+#include <functional>
+#include <vector>
+
+namespace cuHE {
+class CuPolynomial;
+namespace sched {
+
+struct Task;
+// scheduler-side state of one client polynomial: the real object (device buffers, host value) lives here while the client
+// object only mirrors the metadata.  `obj` is touched by one task at a time (writes are ordered after every earlier task
+// on the node, reads after the last write).
+struct Node {
+	CuPolynomial *obj = nullptr;
+	Task *lastWrite = nullptr;             // graph state, guarded by the scheduler's mutex
+	std::vector<Task *> readers;
+	int refs = 1;                          // the client object + every task that has not run yet (same mutex)
+};
+
+bool on();                                 // scheduled mode is in effect
+bool inWorker();                           // the calling thread is one of the scheduler's workers
+void *workerStream();                      // inside a task: the stream the task runs on
+void start(int threads);                   // idempotent; threads <= 0: CUHE_SCHED_THREADS or the default
+void stop();                               // drains, joins the workers, leaves scheduled mode
+int threads();
+
+Node *newNode(CuPolynomial *obj);
+void releaseNode(Node *n);                 // the client object lets go (tasks may still hold the node)
+// record a gate: fn(stream) runs on a worker once every dependency has been issued
+Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep = false);
+void wait(Task *t);                        // until t has run on its worker and its device work has finished; drops the reference `keep` took
+void waitNode(Node *n);                    // until everything recorded on the node so far has finished on the device
+void drain();                              // until everything recorded so far has finished on the device
+// device blocks inside a task: taskAlloc returns a block some task released (ordered behind its last use) or a fresh one
+// from the library; taskFree keeps a block taskAlloc handed out for the next taker (false: not one of those)
+void *taskAlloc(int dev, size_t bytes);
+bool taskFree(int dev, void *ptr);
+void forgetBlock(void *ptr);               // a block released outside any task
+struct Stats { long tasks, crossStreamWaits, maxQueued; };
+Stats stats();
+
+} // namespace sched
+} // namespace cuHE

@@ -97,6 +97,9 @@ int cuhe_hip_free(int dev, void *ptr);
 /* freed blocks are parked for reuse (hipMalloc/hipFree cost more than a CRT or NTT stage): without limit between
    start/stopAllocator, up to this many bytes per device otherwise (default 4 GiB; 0 = plain hipMalloc/hipFree) */
 int cuhe_hip_set_alloc_cache(size_t bytes);
+/* diagnostics: out4 = { hipMalloc calls, allocations served from the settled pool, from the caller stream's parked blocks,
+   blocks handed over from another stream's parked set behind an event } since the library was loaded */
+int cuhe_hip_alloc_counters(long long *out4);
 /* stream-ordered variants: a block freed with free_stream is reused only by malloc_stream calls for the same stream
    until cuhe_hip_stream_sync(stream) has returned; callers can then enqueue chains of operations without a host
    synchronisation between them */
@@ -119,6 +122,16 @@ int cuhe_hip_stream_destroy(int dev, void *stream);
 int cuhe_hip_stream_sync(int dev, void *stream);
 /* waits for all work on the device (every stream); blocks freed in stream order become reusable by any stream */
 int cuhe_hip_device_sync(int dev);
+/* Events (hipEvent_t as void*, timing disabled): the ordering primitive of the C++ layer's gate scheduler
+   (cuhe_amd/cxx/Scheduler.h), which runs independent gates of one client thread on several streams.  The reference has
+   one stream per device and a cudaStreamSynchronize after every gate instead (cuhe/CuHE.cu:98,121,139,157).
+   event_query returns CUHE_OK when the recorded work has finished and 1 while it is pending. */
+int cuhe_hip_event_create(int dev, void **event_out);
+int cuhe_hip_event_destroy(int dev, void *event);
+int cuhe_hip_event_record(int dev, void *event, void *stream);
+int cuhe_hip_stream_wait_event(int dev, void *stream, void *event);
+int cuhe_hip_event_sync(int dev, void *event);
+int cuhe_hip_event_query(int dev, void *event);
 
 /* ---- operation drivers (cuhe/Operations.h:60-108), same argument order */
 int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *stream);            /* Operations.cu:245 */

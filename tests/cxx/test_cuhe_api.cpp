@@ -295,6 +295,33 @@ int main() {
 			ZZX aa = hostMul(a, a, xn1, q2[0], n2);
 			CHECK(s123.zRep() == reduceCoeffs(aa + aa + aa, q2[0], n2), "a*a + a*a + a*a added in the NTT domain (three products: beyond the headroom)");
 		}
+		{
+			//  the count of summed products survives a sum with a PLAINTEXT and a trip through an array: p1 + p2
+			// (two products), + plaintext (still two), + a third product has to take the reducing path
+			ZZX one; SetCoeff(one, 0, 1);
+			CuPtxt pt; pt.setLogq(param._logCoeff(0), 0, one); pt.x2n();
+			CuCtxt q1, q2c, q3, s12, t, u;
+			cAnd(q1, ca, ca); cAnd(q2c, ca, ca); cAnd(q3, ca, ca);
+			cXor(s12, q1, q2c);
+			cXor(t, s12, pt);
+			CHECK(t.isProd() && t.prodTerms() == 2, "a sum of two products plus a plaintext still counts two products");
+			cXor(u, t, q3);
+			u.x2z();
+			ZZX aa = hostMul(a, a, xn1, q2[0], n2);
+			CHECK(u.zRep() == reduceCoeffs(aa + aa + aa + one, q2[0], n2), "(a*a + a*a + 1) + a*a: exact although the plaintext sum sat in between");
+			CuCtxt v, w, q4;
+			cXor(v, q1, q2c);
+			cXor(v, v, pt);                                      // in place
+			CHECK(v.prodTerms() == 2, "in-place sum with a plaintext keeps the count");
+			CuCtxtArray arr; arr.create(1, 0, 3, 0);
+			arr.put(0, v);
+			arr.get(w, 0);
+			CHECK(w.isProd() && w.prodTerms() == 2, "the count survives CuCtxtArray put / get");
+			cAnd(q4, ca, ca);
+			cXor(w, w, q4);
+			w.x2z();
+			CHECK(w.zRep() == reduceCoeffs(aa + aa + aa + one, q2[0], n2), "array round trip, then a third product: exact");
+		}
 		ZZX ra = randomPoly(n2, q2[0]), rb = randomPoly(n2, q2[0]);
 		CuCtxt cra, crb, s2;
 		cra.setLevel(0, 0, ra); crb.setLevel(0, 0, rb); cra.x2n(); crb.x2n();

@@ -22,7 +22,12 @@
 // --async switches the library to asynchronous gates (setAsynchronous, an addition to the reference API): the ~100
 // gates and conversions of an S-box are enqueued back to back and synchronised once.
 //
-// usage: test_prince_flow [--no-round-checks] [--threads T] [--async] [--devices N [--virtual]]
+// --sched [W] switches the library to SCHEDULED gates (setScheduled, an addition to the reference API; CUHE_SCHED=1 in the
+// environment does the same for an unchanged client): the client code is the reference's pattern -- one host thread, the
+// default stream, one gate per call -- and the library runs the independent gates concurrently (W worker threads, each on
+// its own stream, ordered by events).  Meant for --threads 1.
+//
+// usage: test_prince_flow [--no-round-checks] [--threads T] [--async | --sched [W] | --compare] [--devices N [--virtual]]
 #include "dhs_client.hpp"
 #include "prince_common.hpp"
 #include <atomic>
@@ -163,6 +168,7 @@ struct Evaluator {
 	}
 	void check() {
 		if (checkRounds) {
+			synchronize();                              // scheduled gates: the layer's work belongs to the encryption time, not to the check
 			const auto t0 = clk::now();
 			bool constant; const u64x got = decryptState(constant);
 			const bool ok = constant && got == expect[layer];
@@ -233,11 +239,13 @@ struct Evaluator {
 };
 
 int main(int argc, char **argv) {
-	bool checkRounds = true, async = false, virtualDevices = false; int threads = 8, devices = 1;
+	bool checkRounds = true, async = false, virtualDevices = false, scheduledGates = false, compare = false; int threads = 8, devices = 1, schedWorkers = 0;
 	for (int i = 1; i < argc; ++i) {
 		if (std::string(argv[i]) == "--no-round-checks") checkRounds = false;
 		else if (std::string(argv[i]) == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (std::string(argv[i]) == "--async") async = true;
+		else if (std::string(argv[i]) == "--compare") compare = true;
+		else if (std::string(argv[i]) == "--sched") { scheduledGates = true; if (i + 1 < argc && argv[i + 1][0] != '-') schedWorkers = atoi(argv[++i]); }
 		else if (std::string(argv[i]) == "--devices" && i + 1 < argc) devices = atoi(argv[++i]);
 		else if (std::string(argv[i]) == "--virtual") virtualDevices = true;      // logical devices on one physical GPU
 	}
@@ -256,11 +264,16 @@ int main(int argc, char **argv) {
 	Dhs dhs;
 	dhs.setup(25, 2, 16, 25, 25, 21845);                    // Prince.cu:49
 	startAllocator();
-	const auto t1 = clk::now();
+	const auto t1k = clk::now();
 	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d   key generation %.2f s\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey,
-	       std::chrono::duration<double>(t1 - t0).count());
+	       std::chrono::duration<double>(t1k - t0).count());
 
 	Pool pool(threads, devices);
+	// --compare: the same block twice in one process (one key generation): first with the reference's synchronous gates,
+	// then with scheduled gates; bench.py reads the two "Prince Encryption" lines
+	for (int pass = 0; pass < (compare ? 2 : 1); ++pass) {
+	if (compare) { scheduledGates = pass == 1; numAnd = 0; numRelin = 0; numModSwitch = 0; }
+	const auto t1 = clk::now();
 	Evaluator ev(dhs, checkRounds, pool);
 	plainPrince(pt, key0, key1, &ev.expect);
 	std::vector<Ct> k0(64);
@@ -271,11 +284,15 @@ int main(int argc, char **argv) {
 		ev.k1[i] = Evaluator::upload(dhs.encryptBit((int)((key1 >> (63 - i)) & 1), 0), 0);
 	}
 	setAsynchronous(async);
+	if (scheduledGates) setScheduled(true, schedWorkers);
 	const auto t2 = clk::now();
 	printf("encrypted 192 bits in %.2f s\n", std::chrono::duration<double>(t2 - t1).count());
 
 	ev.encrypt(k0);
+	const auto t2b = clk::now();
+	synchronize();                                          // (scheduled gates: everything recorded has run)
 	const auto t3 = clk::now();
+	if (isScheduled()) printf("the client thread recorded the circuit in %.3f s\n", std::chrono::duration<double>(t2b - t2).count() - ev.paused);
 	const double encSeconds = std::chrono::duration<double>(t3 - t2).count() - ev.paused;
 
 	bool constant; const u64x got = ev.decryptState(constant);
@@ -284,7 +301,10 @@ int main(int argc, char **argv) {
 	if (!(constant && got == want && want == 0x9fb51935fc3df524ULL)) ++failures;
 	printf("circuit: %ld cAnd, %ld relin, %ld modSwitch, final level %d\n", numAnd.load(), numRelin.load(), numModSwitch.load(), ev.level);
 	if (numAnd != 1920 || numRelin != 1152 || ev.level != 24) { printf("unexpected operation counts\n"); ++failures; }
-	printf("Prince Encryption: %.3f s on %d %sdevice(s) with %d host thread(s), %s gates (round checks excluded)\n", encSeconds, devices, virtualDevices ? "virtual " : "", threads, async ? "asynchronous" : "synchronous");
+	printf("Prince Encryption: %.3f s on %d %sdevice(s) with %d host thread(s), %s gates (round checks excluded)\n", encSeconds, devices, virtualDevices ? "virtual " : "", threads,
+	       isScheduled() ? "scheduled" : async ? "asynchronous" : "synchronous");
+	if (isScheduled()) { setScheduled(false); }
+	}
 	stopAllocator();
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;

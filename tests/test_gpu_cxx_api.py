@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cxx_api_program():
+@pytest.mark.parametrize("sched", [False, True], ids=["synchronous", "scheduled"])
+def test_cxx_api_program(sched):
+    """(scheduled: the same program with CUHE_SCHED=1 in the environment -- every CuCtxt gate and conversion goes through
+    the gate scheduler of cuhe_amd/cxx/Scheduler.h, CUHE_SCHED_CHECK=1 verifies the client-side metadata mirror)"""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
@@ -18,15 +21,17 @@ def test_cxx_api_program():
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_cuhe_api")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, CUHE_SCHED="1", CUHE_SCHED_CHECK="1") if sched else dict(os.environ)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout
 
 
+@pytest.mark.parametrize("sched", [False, True], ids=["synchronous", "scheduled"])
 @pytest.mark.parametrize("params", [(3, 2, 8, 40, 20, 1155), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
                          ids=["toy1155", "dhs_simple", "pow2_32768-negacyclic"])
-def test_dhs_scheme_flow(params):
+def test_dhs_scheme_flow(params, sched):
     """keygen / encrypt / XOR / NOT / AND + relin + modSwitch (two levels) / decrypt through CuHE.h -- the checks of
     examples/DHS/simple_DHS.cu:49-170, with the reference example's own parameter set as the second case"""
     import torch
@@ -37,15 +42,18 @@ def test_dhs_scheme_flow(params):
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_dhs_flow")
-    r = subprocess.run([exe] + [str(v) for v in params], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, CUHE_SCHED="1", CUHE_SCHED_CHECK="1") if sched else dict(os.environ)
+    r = subprocess.run([exe] + [str(v) for v in params], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
 
 
 @pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"],
-                                   ["--threads", "6", "--async", "--devices", "3", "--virtual"]],
-                         ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices"])
+                                   ["--threads", "6", "--async", "--devices", "3", "--virtual"],
+                                   ["--threads", "1", "--sched"], ["--threads", "1", "--sched", "3", "--devices", "3", "--virtual"]],
+                         ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices",
+                              "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices"])
 def test_prince_known_answer(flags):
     """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
     reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
@@ -62,12 +70,14 @@ def test_prince_known_answer(flags):
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_flow")
-    r = subprocess.run([exe] + flags, capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([exe] + flags, capture_output=True, text=True, timeout=1200, env=dict(os.environ, CUHE_SCHED_CHECK="1"))
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
     assert r.stdout.count("right") == (1 if "--no-round-checks" in flags else 13)
+    if "--sched" in flags:
+        assert "scheduled gates" in r.stdout
 
 
 def test_prince_known_answer_on_arrays():
