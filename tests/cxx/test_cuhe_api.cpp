@@ -299,7 +299,7 @@ int main() {
 			//  the count of summed products survives a sum with a PLAINTEXT and a trip through an array: p1 + p2
 			// (two products), + plaintext (still two), + a third product has to take the reducing path
 			ZZX one; SetCoeff(one, 0, 1);
-			CuPtxt pt; pt.setLogq(param._logCoeff(0), 0, one); pt.x2n();
+			CuPtxt pt; pt.setLogq(param.logMsg, 0, one); pt.x2n();
 			CuCtxt q1, q2c, q3, s12, t, u;
 			cAnd(q1, ca, ca); cAnd(q2c, ca, ca); cAnd(q3, ca, ca);
 			cXor(s12, q1, q2c);
