@@ -225,12 +225,13 @@ def main():
                 if rec.get("kernel_sha16") == kernel_sha16() and bool(rec.get("one_launch")) == one_launch:
                     traffic = rec["bytes_per_transform"] * per_launch
                     lane_instr = rec.get("valu_lane_instructions_per_transform")
-                    pmc_note = "HBM-side bytes per launch (%d transforms) from %s; algorithmic = %d" % (per_launch, os.path.basename(tf[-1]), per_launch * alg_bytes)
+                    pmc_note = ("from committed rocprofv3 --pmc passes of this command (%s), NOT measured in this run: HBM-side bytes per launch (%d transforms); "
+                                "algorithmic = %d" % (os.path.basename(tf[-1]), per_launch, per_launch * alg_bytes))
                 else:
                     pmc_note = "%s was measured on other kernel sources (%s, now %s): re-run tools/profile_final.sh" % (os.path.basename(tf[-1]), rec.get("kernel_sha16"), kernel_sha16())
         except Exception as ex:
             pmc_note = "traffic file unreadable: %r" % (ex,)
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "dispatch": dispatch_info(lib),
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": pmc_note,
                     "kernel": ("ntt_onewg_stream<kOutU64> (persistent one-workgroup transform: two 32K-point halves per row, one launch per call)" if one_launch
                                else "ntt_pass1w<16,0> + ntt_pass2w<16,0> (one transform = one launch pair)"), "kernel_sha16": kernel_sha16(),
@@ -260,7 +261,7 @@ def main():
                     ck(lib.cuhe_hip_time_ntt_fwd(d2.data_ptr(), s2.data_ptr(), L2, B2, 3, 0, None, C.byref(a1), C.byref(a2), C.byref(at)))
                     per = at.value * 1e-3 / (3 * B2)
                     other_lengths[str(L2)] = {"value": round(1.0 / per, 1), "unit": "NTT/s", "batch": B2, "frac": round(10 * L2 / per / 1e9 / HBM_PEAK_GBS, 4),
-                                              "kernel": "ntt_onewg<%d, zero-padded halves> (one launch)" % (13 if L2 == 16384 else 14)}
+                                              "kernel": "ntt_onewg<%d, zero-padded halves> (one launch)" % (13 if L2 == 16384 else 14), "dispatch": dispatch_info(lib)}
                 except Exception as ex:
                     other_lengths[str(L2)] = {"error": repr(ex)[:200]}
         roofline["other_lengths"] = other_lengths
@@ -324,6 +325,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
                                          "source": "doc/Perf_NTT.txt:14 (bundle 512)"},
+            "mul_relin_single_frac_hbm": {(r or {}).get("params", {}).get("transform", "?"): (r or {}).get("frac_hbm") for r in (mulrelin, mulrelin2) if r},
             "mul_relin": mulrelin, "mul_relin_other_ring": mulrelin2, "mul_relin_sharded": sharded, "mul_relin_replicated": replicated,
             "mul_full": mulfull, "prince": prince,
         }
@@ -369,6 +371,12 @@ def perf_table(lib, ck, torch, dev, path):
         for r in rows:
             f.write("%-6d %-14.7f %-14.7f %-14.7f\n" % tuple(r))
     print(open(path).read())
+
+
+def dispatch_info(lib):
+    """which kernel form the last transform call of this thread took, and the rendezvous give-up count (cuhe_hip_last_dispatch_info)"""
+    buf = C.create_string_buffer(256)
+    return buf.value.decode() if lib.cuhe_hip_last_dispatch_info(0, buf, 256) == 0 else None
 
 
 def bench_prince(world, single_dev):
@@ -477,17 +485,47 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, sin
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     in_library = int(flag.item()) == 1
+    # what RCCL itself says on every rank (version, ncclCommCount, ncclCommUserRank) next to the library's view: gathered to
+    # every rank so that rank 0 can print it -- the first thing to read if the first N > 1 contact misbehaves
+    cbuf = C.create_string_buffer(512)
+    lib.cuhe_hip_comm_info(cbuf, 512)
+    my_info = "rank %d: comm_init %s; %s" % (rank, "ok" if ok else "FAILED (%s)" % comm_err, cbuf.value.decode())
+    per_rank = [None] * world
+    try:
+        dist.all_gather_object(per_rank, my_info)
+    except Exception as ex:
+        per_rank = [my_info, "all_gather_object failed: %r" % (ex,)]
     if not in_library:
         lib.cuhe_hip_comm_destroy()
+        if comm_err is None:
+            comm_err = "comm_init failed on another rank"
 
     def one():
         if in_library:
             ck(lib.cuhe_hip_mul_relin_sharded(outc.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, 0, None))
             return outc
         return sh.mul_relin(na, nb)
-    first = one().clone()
+    if in_library:
+        # the first call through RCCL is allowed to fail (the exact failing call and RCCL's message arrive in the error
+        # string): every rank then falls back to the torch.distributed exchange together, and the leg still delivers
+        lib_err = None
+        try:
+            first = one().clone()
+            torch.cuda.synchronize()
+        except Exception as ex:
+            lib_err = repr(ex)[:300]
+        flag = torch.tensor([0 if lib_err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            in_library = False
+            comm_err = "first cuhe_hip_mul_relin_sharded failed: " + (lib_err or "on another rank")
+            lib.cuhe_hip_comm_destroy()
     if in_library:                                     # same rows through the torch.distributed exchange: must agree
         assert torch.equal(first, sh.mul_relin(na, nb)), "in-library all-gather differs from the torch.distributed path"
+        lib.cuhe_hip_comm_info(cbuf, 512)
+        per_rank[rank] = per_rank[rank] + " | after the first call: " + cbuf.value.decode()
+    else:
+        first = one().clone()
     for _ in range(3):
         one()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
@@ -516,6 +554,7 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, sin
         replicated()
     torch.cuda.synchronize()
     t_rep = (time.perf_counter() - t0) / reps
+    lib_comm_size = lib.cuhe_hip_comm_size() if in_library else None
     lib.cuhe_hip_comm_destroy()
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s (one ciphertext, primes sharded)", "ms": round(dt * 1e3, 3),
@@ -525,6 +564,7 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, sin
                            "would move k*n*8 = %d B per multiply against %d B of CRT rows); the key-switch inner product, both inverse transforms and the "
                            "key memory divide by the number of ranks" % (K * lib_ct_len * 8, q.numCrtPrime * q.crtLen * 4),
             "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "ring_degree": q.modLen,
+            "comm_size": lib_comm_size, "rccl_per_rank": per_rank,
             "exchange": "RCCL group of broadcasts inside cuhe_hip_mul_relin_sharded, on the compute stream" if in_library
                         else "torch.distributed all-gather around the C-ABI stages (in-library communicator unavailable: %s)" % comm_err,
             "collective": "1 all-gather of %d B per rank per multiply" % (sh.count * q.crtLen * 4)}
@@ -675,6 +715,7 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
         one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    single_dispatch = dispatch_info(lib)              # (of the chain's last transform call: the inverse rows of the result)
     key_bytes = 8 * K * npn * L
     # ---- the same chain for B independent ciphertexts per call (cuhe_hip_mul_relin_batch): every stage runs over
     # B*np rows and a key value fetched from HBM serves four ciphertexts; results are bit-identical (checked below)
@@ -774,7 +815,7 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s", "ms": round(dt * 1e3, 3),
             "params": {"setParameters": [d, p, w, mn, cut, m], "ring_degree": q.modLen, "numCrtPrime": npn, "numEvalKey": K, "transform": rep},
             "algorithmic_bytes": key_bytes, "achieved_GBs": round(key_bytes / dt / 1e9, 1),
-            "frac_hbm": round(key_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "key_upload_s": round(init_s, 2),
+            "frac_hbm": round(key_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "key_upload_s": round(init_s, 2), "dispatch_last_transform": single_dispatch,
             "batched": batched, "concurrent": concurrent}
 
 

@@ -92,6 +92,8 @@ SIGNATURES = {
     "cuhe_hip_intt_double_deg": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_intt_mod": (i32, [vp, vp, i32, i32, vp]),
     "cuhe_hip_intt_result": (vp, [i32]),
+    "cuhe_hip_ntt_swap": (vp, [i32]),
+    "cuhe_hip_last_dispatch_info": (i32, [i32, vp, sz]),
     "cuhe_hip_ntt_mul": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_ntt_mul_nx1": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_ntt_add": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -142,6 +144,8 @@ SIGNATURES = {
     "cuhe_hip_comm_destroy": (i32, []),
     "cuhe_hip_comm_size": (i32, []),
     "cuhe_hip_comm_rank": (i32, []),
+    "cuhe_hip_comm_info": (i32, [vp, sz]),
+    "cuhe_hip_comm_force_exchange": (i32, [i32]),
     "cuhe_hip_allgather_rows": (i32, [vp, i32, i32, vp]),
     "cuhe_hip_mul_relin_sharded": (i32, [vp, vp, vp, i32, i32, vp]),
     "cuhe_hip_mul_relin_sharded_inproc": (i32, [vp, vp, vp, i32, i32, vp]),

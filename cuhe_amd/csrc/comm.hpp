@@ -27,6 +27,10 @@ struct Api {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (diagnostics: what RCCL itself says about the communicator)
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *error = nullptr;
 };
 
@@ -42,10 +46,23 @@ inline Api &api() {
     CUHE_SYM(GroupStart, "ncclGroupStart") CUHE_SYM(GroupEnd, "ncclGroupEnd") CUHE_SYM(Broadcast, "ncclBroadcast")
     CUHE_SYM(AllGather, "ncclAllGather") CUHE_SYM(GetErrorString, "ncclGetErrorString")
 #undef CUHE_SYM
+    *(void **)(&a.CommCount) = dlsym(a.handle, "ncclCommCount");
+    *(void **)(&a.CommUserRank) = dlsym(a.handle, "ncclCommUserRank");
+    *(void **)(&a.GetVersion) = dlsym(a.handle, "ncclGetVersion");
     return a;
 }
 
-struct State { ncclComm_t comm = nullptr; int nranks = 1, rank = 0; };
+// the symbols api() needs from librccl (tests/test_capi_symbols.py resolves the same list against the librccl of the image)
+inline const char *const *required_symbols() {
+    static const char *const names[] = {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclBroadcast",
+                                        "ncclAllGather", "ncclGetErrorString", nullptr};
+    return names;
+}
+struct State {
+    ncclComm_t comm = nullptr; int nranks = 1, rank = 0;
+    bool force_exchange = false;          // tests: issue the grouped broadcast on a communicator of ONE rank too
+    const char *last_path = "none yet"; long exchanges = 0;
+};
 inline State &state() { static State s; return s; }
 
 // contiguous, balanced blocks: the first (np % nranks) ranks own one prime more (== cuhe_amd/sharded.py: shard_bounds)

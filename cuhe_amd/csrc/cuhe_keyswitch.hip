@@ -742,11 +742,27 @@ int cuhe_hip_comm_init(int nranks, int rank, const void *id128) {
 int cuhe_hip_comm_destroy(void) {
     comm::State &C = comm::state();
     if (C.comm) { comm::api().CommDestroy(C.comm); C.comm = nullptr; }
-    C.nranks = 1; C.rank = 0;
+    C.nranks = 1; C.rank = 0; C.force_exchange = false;
     return CUHE_OK;
 }
 int cuhe_hip_comm_size(void) { return comm::state().nranks; }
 int cuhe_hip_comm_rank(void) { return comm::state().rank; }
+int cuhe_hip_comm_force_exchange(int on) { comm::state().force_exchange = on != 0; return CUHE_OK; }
+// what RCCL itself reports about the communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion) and which path the
+// last exchange of CRT rows took: the first thing to read when a multi-GPU run misbehaves
+int cuhe_hip_comm_info(char *buf, size_t cap) {
+    if (!buf || cap == 0) return fail(CUHE_EINVAL, "no buffer");
+    comm::Api &A = comm::api();
+    comm::State &C = comm::state();
+    if (A.error) { snprintf(buf, cap, "RCCL unavailable: %s", A.error); return CUHE_OK; }
+    int ver = -1, cnt = -1, urank = -1;
+    if (A.GetVersion) A.GetVersion(&ver);
+    if (C.comm && A.CommCount) A.CommCount(C.comm, &cnt);
+    if (C.comm && A.CommUserRank) A.CommUserRank(C.comm, &urank);
+    snprintf(buf, cap, "rccl %d; communicator %s; ncclCommCount %d, ncclCommUserRank %d (library: %d ranks, rank %d); exchanges so far %ld, last: %s",
+             ver, C.comm ? "initialised" : "not initialised", cnt, urank, C.nranks, C.rank, C.exchanges, C.last_path);
+    return CUHE_OK;
+}
 // rows: u32[np][crtLen] of level lvl on this rank's device, the rank's own block already in place; on return (in stream
 // order) every block is.  A group of broadcasts, root r sending its block in place, because the blocks differ in size
 // when np is not a multiple of the number of ranks.
@@ -754,20 +770,25 @@ int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *st) {
     CHK(need_init(dev));
     if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     comm::State &C = comm::state();
-    if (C.nranks == 1) return CUHE_OK;
+    if (C.nranks == 1 && !(C.force_exchange && C.comm)) { C.last_path = "one rank: nothing to exchange"; return CUHE_OK; }
     if (!C.comm) return fail(CUHE_ENOTINIT, "cuhe_hip_comm_init has not been called");
     comm::Api &A = comm::api();
     const int np = G_.prm.numCrtPrimeAt(lvl), cl = G_.prm.crtLen;
+    // every failing call is named with its rank, root and RCCL's own message: the first multi-GPU contact must explain itself
     ncclResult_t r = A.GroupStart();
+    if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupStart: %s", C.rank, C.nranks, A.GetErrorString(r));
+    int bad_root = -1;
     for (int rk = 0; rk < C.nranks && r == ncclSuccess; ++rk) {
         int f, c; comm::shard_bounds(np, C.nranks, rk, &f, &c);
         if (c == 0) continue;
         u32 *blk = rows + (size_t)f * cl;
         r = A.Broadcast(blk, blk, (size_t)c * cl, ncclUint32, rk, C.comm, S(st));
+        if (r != ncclSuccess) bad_root = rk;
     }
     const ncclResult_t e = A.GroupEnd();
-    if (r == ncclSuccess) r = e;
-    if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows: %s", A.GetErrorString(r));
+    if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclBroadcast(root %d): %s", C.rank, C.nranks, bad_root, A.GetErrorString(r));
+    if (e != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupEnd: %s", C.rank, C.nranks, A.GetErrorString(e));
+    C.last_path = "RCCL: group of ncclBroadcast, one per rank's block, in place"; ++C.exchanges;
     return CUHE_OK;
 }
 // cAnd + relin with the level's primes sharded over the ranks of the communicator: a_own, b_own = ct rows of the rank's

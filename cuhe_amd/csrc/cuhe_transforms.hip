@@ -190,6 +190,18 @@ int launch_pass2(void *dst, const u64 *scratch, const NttTab &tab, long dst_stri
     return CUHE_OK;
 }
 
+// what the calling thread's last transform call was dispatched to (cuhe_hip_last_dispatch_info: bench / tests)
+struct DispatchInfo { const char *form = "none"; int len = 0, batch = 0, dev = 0; };
+static thread_local DispatchInfo tls_dispatch;
+static inline void note_dispatch(const char *form, int len, int batch) { tls_dispatch.form = form; tls_dispatch.len = len; tls_dispatch.batch = batch; }
+// rendezvous counters of the persistent kernels + one slot that counts the workgroups that gave a rendezvous up
+static int ws_pair_counters(Workspace &W) {
+    if (W.pair_cnt) return CUHE_OK;
+    CHK(ws_buffer(&W.pair_cnt, kOwPairCounters + 1));
+    HIPCHK(hipMemset(W.pair_cnt, 0, (kOwPairCounters + 1) * sizeof(unsigned)));
+    return CUHE_OK;
+}
+
 // one batched transform, chunked so that the pass-1 -> pass-2 slab stays cache resident
 template <int LG>
 int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
@@ -216,7 +228,11 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         // workgroup on, rows aligned for the LDS-DMA of their samples
         // (32K-point rows: measured 3 % slower than one workgroup per half, 6.43 vs 6.64 M/s -- taken only when onewg64 = 3)
         const int gridp = lgh == 15 || (lgh == 14 && G_.onewg64 == 3) ? (D.cus << (15 - lgh)) & ~15 : 0;
-        const bool stream_ok = half && mode == kSrcU32Ext && gridp >= 16 && gridp / 2 <= kOwPairCounters && wgs >= 2L * gridp &&
+        // (the persistent launch carries ~70 us of fill, first fetch and tail: 0.570 / 0.492 us per transform at 256 / 512 rows of
+        // 64K points against 0.407 / 0.385 for the two-pass pair, 0.362 at 8192 -- the fit a + c / rows crosses the pair at ~2400 rows;
+        // profiles/r03_perf_ntt_table.txt.  From 10 halves per workgroup on, so that time per transform never rises with the batch.)
+        const long stream_min = G_.onewg == 2 ? 2L * gridp : 20L * gridp;
+        const bool stream_ok = half && mode == kSrcU32Ext && gridp >= 16 && gridp / 2 <= kOwPairCounters && wgs >= stream_min &&
                                ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
         const bool rows64_onewg = G_.onewg64 == 1 || (G_.onewg64 >= 2 && stream_ok);
         // negacyclic forward transform of full 64K-point rows (the ciphertext domain of x^65536 + 1): the persistent form, two
@@ -227,7 +243,8 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             CHK(ensure_onewg_twist(ot, 15));
             OwArgs a{dst, src, ot.TW1g, ot.TW2, src_stride, dst_stride, batch, nstore, wa, nullptr, D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, nullptr};
             if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            CHK(ws_buffer(&W.pair_cnt, kOwPairCounters));
+            CHK(ws_pair_counters(W));
+            note_dispatch("persistent one-workgroup halves with rendezvous (negacyclic rows)", L, batch);
             hipError_t he = ow_launch_stream_15(kSrcU32Twist, kOutU64, a, grid64, W.pair_cnt, ot.c128, ot.i4neg, st);
             if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (negacyclic rows): %s", hipGetErrorString(he));
             if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
@@ -253,6 +270,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 OwArgs a{dst, src, mode == kSrcU32Twist ? ot.TW1g : ot.TW1hi, ot.TW2, src_stride, dst_stride, batch, L, wa, mode == kSrcU64NegMul ? mul_tab : nullptr,
                          D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, xt, ot.c128, ot.i4neg};
                 if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
+                note_dispatch("split row: one workgroup per half-length sub-transform", L, batch);
                 CHK(onewg_launch(LG - 1, mode, out, true, a, st));
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 return CUHE_OK;
@@ -281,11 +299,12 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 // of the current one, the two halves of a row meeting before their interleaved stores
                 const bool stream = G_.onewg64 >= 2 && stream_ok;
                 if (stream) {
-                    CHK(ws_buffer(&W.pair_cnt, kOwPairCounters));
+                    CHK(ws_pair_counters(W));
+                    note_dispatch("persistent one-workgroup halves with rendezvous (zero-padded rows)", L, batch);
                     hipError_t he = lgh == 15 ? ow_launch_stream_15(kSrcU32Ext, out, a, gridp, W.pair_cnt, 0, 0, st)
                                               : ow_launch_stream_14(kSrcU32Ext, out, a, gridp, W.pair_cnt, 0, 0, st);
                     if (he != hipSuccess) return fail(CUHE_EHIP, "persistent one-workgroup transform (2^%d-point halves): %s", lgh, hipGetErrorString(he));
-                } else CHK(onewg_launch(lgh, mode, out, half, a, st));
+                } else { note_dispatch(half ? "one workgroup per half" : "one workgroup per row", L, batch); CHK(onewg_launch(lgh, mode, out, half, a, st)); }
                 if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 return CUHE_OK;
             }
@@ -306,6 +325,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         HIPCHK(hipStreamWaitEvent(D.s2, D.ev_start, 0));
     }
     const bool ll = (long)batch * L <= (long)g_ll_rows * 32768;      // few rows: the duration of one workgroup is what counts
+    note_dispatch(ll ? "two-pass pair, low-latency kernels" : "two-pass pair", L, batch);
     // pass 2 alone keeps its low-latency form up to twice that size (profiles/r02_small_batch_latency.txt: 9.8 vs 11.2 us at 48 rows of 32K)
     const bool ll2 = (long)batch * L <= 2L * g_ll_rows * 32768;
     int c = 0, last = 0;
@@ -591,6 +611,28 @@ uint32_t *cuhe_hip_intt_result(int dev) {
     Workspace *Wp = nullptr;                      // the CALLING thread's buffer (every host thread has its own)
     if (workspace_of_thread(dev, &Wp) != CUHE_OK || ws_barrett(*Wp) != CUHE_OK) return nullptr;
     return Wp->hold;
+}
+
+// which kernel form the calling thread's last transform call took, and how many workgroups of this thread's persistent launches
+// have given a rendezvous up so far (their partner was not resident: the launch then runs on without the merged stores)
+int cuhe_hip_last_dispatch_info(int dev, char *buf, size_t cap) {
+    if (!buf || cap == 0) return fail(CUHE_EINVAL, "no buffer");
+    unsigned gave_up = 0;
+    Workspace *Wp = nullptr;
+    if (G_.inited && dev >= 0 && dev < (int)G_.dev.size() && set_dev(dev) == CUHE_OK && workspace_of_thread(dev, &Wp) == CUHE_OK && Wp->pair_cnt)
+        HIPCHK(hipMemcpy(&gave_up, Wp->pair_cnt + kOwPairCounters, sizeof(unsigned), hipMemcpyDeviceToHost));
+    snprintf(buf, cap, "%s; %d rows of %d points; rendezvous given up by %u workgroups so far", tls_dispatch.form, tls_dispatch.batch, tls_dispatch.len, gave_up);
+    return CUHE_OK;
+}
+// the u64[nttLen] transform scratch of the reference (d_swap[dev], cuhe/Operations.cu:171-190: "not called externally" but
+// public): the calling thread's slab for transforms of nttLen points, at least one transform long
+uint64_t *cuhe_hip_ntt_swap(int dev) {
+    if (!G_.inited || dev < 0 || dev >= (int)G_.dev.size() || set_dev(dev) != CUHE_OK) return nullptr;
+    const int li = lg_index(G_.prm.nttLen);
+    Workspace *Wp = nullptr; u64 *slab = nullptr;
+    if (li < 0 || workspace_of_thread(dev, &Wp) != CUHE_OK) return nullptr;
+    if (ws_slab(*Wp, li, 0, std::max(Wp->slab_bytes[li][0], (size_t)G_.prm.nttLen * sizeof(u64)), &slab) != CUHE_OK) return nullptr;
+    return (uint64_t *)slab;
 }
 
 static int binop(bool mul, bool nx1, uint64_t *z, const uint64_t *x, const uint64_t *y, int logq, int dev, void *st, bool ct = false) {

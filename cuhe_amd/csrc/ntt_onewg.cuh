@@ -37,6 +37,7 @@
 
 namespace cuhe {
 
+constexpr int kOwGiveUpSlot = 512;          // = kOwPairCounters (ntt_onewg.hpp): the counter behind the rendezvous counters
 template <int R>
 struct OwGeom {
     static constexpr int T = 32 * R, Lh = 32 * T, NP = 32 / R;
@@ -438,6 +439,7 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int nitems = 2 * ((nbatch + 7) & ~7);
     const u32 lds_base = (u32)(uintptr_t)buf;              // LDS byte address of the buffer (generic -> local: low 32 bits)
+    unsigned *const gave_up_total = pair_cnt ? pair_cnt + kOwGiveUpSlot : nullptr;
     // items of a padding transform (batch rounded up to 8) are computed on the last real row and not stored: no divergent
     // control flow around the barriers
     auto fetch = [&](int i) {                              // samples of item i -> buf (as u32[Lh]); wave w moves bytes [8 KB w, 8 KB (w+1))
@@ -501,7 +503,10 @@ __device__ __forceinline__ void ow_stream_loop(void *__restrict__ dst_, const u3
                     met = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
                     if (!met) __builtin_amdgcn_s_sleep(4);
                 }
-                if (!met) *give_up = 1;                     // the partner is not running beside us (another kernel holds its CU): stop waiting for it
+                if (!met) {                                 // the partner is not running beside us (another kernel holds its CU): stop waiting for it
+                    *give_up = 1;
+                    __hip_atomic_fetch_add(gave_up_total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // visible to the host: cuhe_hip_last_dispatch_info
+                }
             }
             __syncthreads();
             if (*give_up) pair_cnt = nullptr;

@@ -26,7 +26,7 @@ hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream
 // (zero-padded forward, a.TW1 = the parity tables) or, 64K-point rows only, kSrcU32Twist (negacyclic forward of full rows,
 // a.TW1 = the twisted tables, c128 = psi^1024, i4neg: psi^32768 = -2^48); `grid`: resident workgroups, a multiple of 16;
 // pair_cnt: grid / 2 <= kOwPairCounters counters for the rendezvous of the two halves of a row (or null)
-constexpr int kOwPairCounters = 512;
+constexpr int kOwPairCounters = 512;     // + 1 slot behind them: workgroups that gave a rendezvous up (never reset by a launch)
 hipError_t ow_launch_stream_14(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
 hipError_t ow_launch_stream_15(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
 bool ow_supported(int mode, int out, bool half);

@@ -73,6 +73,21 @@ void *deviceMalloc(size_t size) {
 	return p;
 }
 void deviceFree(void *ptr) { CSC(cuhe_hip_free(tlsDevice, ptr)); }
+DeviceAllocator::DeviceAllocator() : device_(tlsDevice) {}
+DeviceAllocator::~DeviceAllocator() { freeAll(); }
+char *DeviceAllocator::allocate(std::ptrdiff_t size) {
+	char *p = (char *)cuhe_hip_malloc(device_, (size_t)size);
+	if (!p) CSC(CUHE_EHIP);
+	allocatedBlocks[p] = size;
+	return p;
+}
+void DeviceAllocator::deallocate(char *ptr) {
+	if (allocatedBlocks.erase(ptr)) CSC(cuhe_hip_free(device_, ptr));
+}
+void DeviceAllocator::freeAll() {
+	for (auto &kv : allocatedBlocks) CSC(cuhe_hip_free(device_, kv.first));
+	allocatedBlocks.clear();
+}
 
 // ---- asynchronous gates (addition).  The reference ends every public operation with a stream synchronise
 // (cuhe/CuHE.cu:98,121,...).  With setAsynchronous(true) the operations only ENQUEUE work on their stream: device
@@ -181,6 +196,20 @@ void genIcrt() { requireInit("genIcrt"); }
 void setPolyModulus(ZZX) { requireInit("setPolyModulus"); }
 void createBarrettTemporySpace() { requireInit("createBarrettTemporySpace"); }
 uint32 *inttResult(int dev) { return cuhe_hip_intt_result(dev); }
+uint64 *ptrNttSwap(int dev) { return (uint64 *)cuhe_hip_ntt_swap(dev); }
+uint32 *ptrNttHold(int dev) { return cuhe_hip_intt_result(dev); }
+uint64 **ptrNttSwap() {
+	static thread_local vector<uint64 *> v;
+	v.assign(numDevices(), NULL);
+	for (int d = 0; d < (int)v.size(); d++) v[d] = ptrNttSwap(d);
+	return v.data();
+}
+uint32 **ptrNttHold() {
+	static thread_local vector<uint32 *> v;
+	v.assign(numDevices(), NULL);
+	for (int d = 0; d < (int)v.size(); d++) v[d] = ptrNttHold(d);
+	return v.data();
+}
 
 #define U64P(p) ((uint64_t *)(p))
 void crt(uint32 *dst, uint32 *src, int logq, int dev, cudaStream_t st) { CSC(cuhe_hip_crt(dst, src, logq, dev, st)); }

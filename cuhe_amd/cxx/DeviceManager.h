@@ -3,7 +3,25 @@
 #pragma once
 #include <cstddef>
 
+#include <map>
+
 namespace cuHE {
+
+// The reference's per-device block allocator type (cuhe/DeviceManager.h:36-52).  The pool itself lives behind the C ABI
+// (cuhe_hip_malloc / cuhe_hip_free: size-keyed, shared by everything on the device); an object of this class is a view of
+// it for the device that was selected when it was made, and remembers what it handed out so that freeAll() / the
+// destructor can give it back.
+class DeviceAllocator {
+public:
+	DeviceAllocator();
+	~DeviceAllocator();
+	char *allocate(std::ptrdiff_t size);
+	void deallocate(char *ptr);
+	void freeAll();
+private:
+	int device_;
+	std::map<char *, std::ptrdiff_t> allocatedBlocks;
+};
 
 void setNumDevices(int val);
 int numDevices();

@@ -63,5 +63,12 @@ void genIcrtByLevel(int lvl);
 void genIcrt();
 void setPolyModulus(ZZX m);
 void createBarrettTemporySpace();
+// "not called externally" in the reference, but public there (cuhe/Operations.h:131-134): the transform scratch and the
+// inttResult buffer per device.  Here every host thread owns its scratch on every device: these return the CALLING
+// thread's buffers (the arrays are indexed by device and belong to the calling thread as well).
+uint64 **ptrNttSwap();
+uint32 **ptrNttHold();
+uint64 *ptrNttSwap(int dev);
+uint32 *ptrNttHold(int dev);
 
 } // namespace cuHE

@@ -148,6 +148,11 @@ int cuhe_hip_intt_hold(const uint64_t *X, int logq, int dev, void *stream);     
 int cuhe_hip_intt_double_deg(uint32_t *x, const uint64_t *X, int logq, int dev, void *stream);    /* Operations.cu:412 */
 int cuhe_hip_intt_mod(uint32_t *x, const uint64_t *X, int logq, int dev, void *stream);           /* Operations.cu:429 */
 uint32_t *cuhe_hip_intt_result(int dev);                                                           /* Operations.cu:185 */
+/* diagnostics: the kernel form the calling thread's last transform call was dispatched to (two-pass pair / one workgroup per
+   half / persistent with rendezvous / split rows), its rows and length, and how many workgroups of this thread's persistent
+   launches have given their rendezvous up so far (performance only: such a launch runs on at the speed of the plain form) */
+int cuhe_hip_last_dispatch_info(int dev, char *buf, size_t cap);
+uint64_t *cuhe_hip_ntt_swap(int dev);     /* ptrNttSwap(dev), Operations.cu:190: the calling thread's u64[nttLen] transform scratch */
 int cuhe_hip_ntt_mul(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *stream);         /* :435 */
 int cuhe_hip_ntt_mul_nx1(uint64_t *z, const uint64_t *x, const uint64_t *scalar, int logq, int dev, void *stream); /* :441 */
 int cuhe_hip_ntt_add(uint64_t *z, const uint64_t *y, const uint64_t *x, int logq, int dev, void *stream);         /* :447 */
@@ -274,6 +279,11 @@ int cuhe_hip_comm_init(int nranks, int rank, const void *id_128_bytes);
 int cuhe_hip_comm_destroy(void);
 int cuhe_hip_comm_size(void);
 int cuhe_hip_comm_rank(void);
+/* diagnostics for the first contact with N > 1 GPUs: what RCCL itself reports about the communicator (version, ncclCommCount,
+   ncclCommUserRank) beside the library's view, and which path the last exchange of CRT rows took.  comm_force_exchange(1): tests --
+   issue the grouped broadcast on a communicator of ONE rank too (by default one rank has nothing to exchange). */
+int cuhe_hip_comm_info(char *buf, size_t cap);
+int cuhe_hip_comm_force_exchange(int on);
 /* rows = u32[np][crtLen] of level lvl with this rank's block in place -> every block in place (stream ordered) */
 int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *stream);
 /* a_own, b_own: ct rows of the rank's primes u64[count][ct_len]; dst_own: reduced CRT rows u32[count][crtLen] */

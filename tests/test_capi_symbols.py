@@ -109,3 +109,33 @@ def test_key_range_covers_the_owned_primes_at_every_level(capi, args):
         assert q.numCrtPrime <= total <= q.numCrtPrime + (q.depth - 1) * (n - 1), (n, total)
     assert capi.lib.cuhe_hip_key_range(0, 0, C.byref(kf), C.byref(kc)) != 0
     capi.lib.cuhe_hip_reset_parameters()
+
+
+def test_rccl_symbols_of_comm_hpp_resolve_in_the_image():
+    """cuhe_amd/csrc/comm.hpp opens librccl with dlopen and resolves a fixed list of symbols with dlsym: a missing one would
+    only show on the first multi-GPU run.  The same list (parsed from the header) is resolved here against the librccl this
+    image ships (PyTorch's copy or /opt/rocm's) -- no communicator is made, no GPU is needed."""
+    txt = open(os.path.join(ROOT, "cuhe_amd", "csrc", "comm.hpp")).read()
+    m = re.search(r"required_symbols\(\)\s*\{.*?names\[\]\s*=\s*\{(.*?)nullptr", txt, flags=re.S)
+    assert m, "required_symbols() not found in comm.hpp"
+    names = re.findall(r'"(nccl\w+)"', m.group(1))
+    used = set(re.findall(r'CUHE_SYM\(\w+,\s*"(nccl\w+)"\)', txt))
+    assert set(names) == used and len(names) >= 8, (names, used)
+    cands = ["librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"]
+    try:
+        import torch
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+        cands = [os.path.join(tl, f) for f in sorted(os.listdir(tl)) if f.startswith("librccl")] + cands
+    except ImportError:
+        pass
+    lib = None
+    for c in cands:
+        try:
+            lib = C.CDLL(c); break
+        except OSError:
+            continue
+    assert lib is not None, "no librccl in this image"
+    for n in names + ["ncclCommCount", "ncclCommUserRank", "ncclGetVersion"]:
+        assert hasattr(lib, n), "librccl lacks " + n
+    ver = C.c_int(0)
+    assert lib.ncclGetVersion(C.byref(ver)) == 0 and ver.value > 20000

@@ -163,6 +163,54 @@ def test_sharded_multiply_at_config4_size_on_2_4_5_8_virtual_devices(gu):
         lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters(); lib.cuhe_hip_set_virtual_devices(0); lib.cuhe_hip_multi_gpus(1)
 
 
+def test_sharded_multiply_through_rccl_on_one_rank_at_config4_size(gu):
+    """cuhe_hip_mul_relin_sharded (the one-process-per-GPU form) at the FULL config-4 size through a communicator of one rank
+    with the exchange FORCED (cuhe_hip_comm_force_exchange): librccl is opened, the communicator made, and the grouped
+    ncclBroadcast of the CRT rows really runs on the compute stream between the two stages -- everything the N > 1 path does
+    except a second GPU.  Result against exact integers (a * b * s with sparse b and s), two levels, twice per buffer set;
+    cuhe_hip_comm_info must report what RCCL says about the communicator and that the RCCL path was taken."""
+    lib, ck = gu.lib, gu.ck
+    g = gu.GpuCtx(*RINGS["x^32768+1"])
+    try:
+        q = g.prm
+        n, K, W0, q0 = q.modLen, q.numEvalKey, g.words(0), g.coeff_modulus(0)
+        primes = g.crt_primes()
+        terms = sparse_terms(n, q0, 13)
+        g.init_relin(structured_keys(terms, K, q.logRelin, q0, q.rawLen, W0))
+        uid = (ctypes.c_uint8 * 128)()
+        ck(lib.cuhe_hip_comm_unique_id(uid))
+        ck(lib.cuhe_hip_comm_init(1, 0, uid))
+        ck(lib.cuhe_hip_comm_force_exchange(1))
+        info = ctypes.create_string_buffer(512)
+        bterms = [(0, 3), (5, 1), (n - 2, 7)]
+        ctlen = lib.cuhe_hip_ct_len()
+        for lvl in (0, 4):
+            npr, logq = g.np_(lvl), g.logq(lvl)
+            rng = np.random.default_rng(300 + lvl)
+            a = np.zeros((npr, q.crtLen), dtype=np.uint32)
+            b = np.zeros((npr, q.crtLen), dtype=np.uint32)
+            for t in range(npr):
+                a[t, :n] = rng.integers(0, primes[t], n, dtype=np.uint32)
+                for e, v in bterms:
+                    b[t, e] = v
+            want = negacyclic_times_sparse(negacyclic_times_sparse(a, bterms, primes[:npr], n).astype(np.uint32), terms, primes[:npr], n)
+            na, nb = gu.empty_u64(npr, ctlen), gu.empty_u64(npr, ctlen)
+            ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), gu.to_dev(a).data_ptr(), logq, 0, None))
+            ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), gu.to_dev(b).data_ptr(), logq, 0, None))
+            out = gu.empty_u32(npr, q.crtLen)
+            for rep in range(2):
+                out.zero_()
+                ck(lib.cuhe_hip_mul_relin_sharded(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, 0, None))
+                ck(lib.cuhe_hip_stream_sync(0, None))
+                assert np.array_equal(gu.host_u32(out)[:, :n].astype(np.uint64), want), (lvl, rep)
+        ck(lib.cuhe_hip_comm_info(info, 512))
+        txt = info.value.decode()
+        assert "ncclCommCount 1" in txt and "ncclCommUserRank 0" in txt and "exchanges so far 4" in txt and "ncclBroadcast" in txt, txt
+    finally:
+        lib.cuhe_hip_comm_destroy()
+        g.close()
+
+
 def test_bench_two_ranks_on_one_gpu_runs_every_leg():
     """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --dist-backend gloo with both ranks on GPU 0:
     the N > 1 legs (sharded multiply with its exchange, replicated multiplies, PRINCE over two devices) complete."""

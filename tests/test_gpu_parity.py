@@ -1179,12 +1179,19 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
             x = np.stack([O.splitmix_u32_below(length // 2, 0xFFFFFFFF, 7000 + b) for b in range(batch)])
             dx = gu.to_dev(x)
             got = []
-            for onewg, r64 in ((0, 0), (1, 2), (1, 1)):
+            import ctypes as C
+            forms = []
+            for onewg, r64 in ((0, 0), (2, 2), (1, 1)):               # (2, 2): the persistent form whatever the row count (the default takes it from 2560 rows on)
                 ck(lib.cuhe_hip_set_onewg(onewg, r64))
                 dX = gu.empty_u64(batch, length)
                 for _ in range(2):                                      # twice: the second call re-uses the tables
                     ck(lib.cuhe_hip_ntt_fwd_batched(dX.data_ptr(), dx.data_ptr(), length, batch, length // 2, 0, None))
                 got.append(gu.host_u64(dX))
+                info = C.create_string_buffer(256)
+                ck(lib.cuhe_hip_last_dispatch_info(0, info, 256))
+                forms.append(info.value.decode())
+            assert forms[0].startswith("two-pass pair") and forms[1].startswith("persistent") and forms[2].startswith("one workgroup per half"), forms
+            assert "301 rows of 65536 points" in forms[1] and "given up by 0 workgroups" in forms[1], forms[1]
             ck(lib.cuhe_hip_set_onewg(1, 0))
             assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
             for b in (0, 150, 300):

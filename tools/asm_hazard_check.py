@@ -81,8 +81,12 @@ def check(lines):
 
     for func, body in funcs:
         incoming = {}                      # label -> state arriving over branches
-        for sweep in range(4):
-            last = sweep == 3
+        # ages saturate at 2 (two wait states are enough: entries that old are dropped), so the states at the labels can only
+        # move finitely often and the iteration runs until nothing changes; a function that has not settled after kMaxSweeps
+        # is reported as a finding, never passed silently
+        kMaxSweeps = 64
+        for sweep in range(kMaxSweeps):
+            last = sweep == kMaxSweeps - 1
             found, sites, reads_n = [], 0, 0
             age, in_asm, dead, changed = {}, False, False, False
             for ln, raw in body:
@@ -103,7 +107,7 @@ def check(lines):
                 args = [a.strip() for a in ops[1].split(",")] if len(ops) > 1 else []
                 if op == "s_nop":
                     n = int(args[0], 0) + 1
-                    age = {r: a + n for r, a in age.items()}
+                    age = {r: a + n for r, a in age.items() if a + n < 2}
                     continue
                 if op.startswith("v_"):
                     ndst = 2 if TWO_DST.match(op) else 1
@@ -115,11 +119,11 @@ def check(lines):
                     if hot:
                         found.append("%s line %d%s: '%s' reads s%s %d wait state(s) after a VALU write" %
                                      (func[:50], ln, " (inside asm)" if in_asm else "", t, sorted(hot), min(age[r] for r in hot)))
-                    age = {r: a + 1 for r, a in age.items()}
+                    age = {r: a + 1 for r, a in age.items() if a + 1 < 2}
                     for r in writes: age[r] = 0
                     continue
                 # SALU / memory / branch: one wait state; an SALU write to a register ends the VALU-write hazard on it
-                age = {r: a + 1 for r, a in age.items()}
+                age = {r: a + 1 for r, a in age.items() if a + 1 < 2}
                 if op.startswith("s_") and args and not op.startswith(("s_cbranch", "s_branch")):
                     for r in sregs(args[0]): age.pop(r, None)
                 if op.startswith(("s_cbranch", "s_branch")) and args:
@@ -128,6 +132,7 @@ def check(lines):
                     if new != incoming.get(tgt): incoming[tgt] = new; changed = True
                     if op == "s_branch": dead = True           # nothing falls through an unconditional branch
             if last or not changed:
+                if changed: found.append("%s: the label states did not settle in %d sweeps -- result not trusted" % (func[:50], kMaxSweeps))
                 findings += found; asm_sites += sites; valu_sgpr_reads += reads_n
                 break
     return findings, asm_sites, valu_sgpr_reads
