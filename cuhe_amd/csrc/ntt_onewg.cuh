@@ -533,4 +533,5 @@ void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, cons
     else ow_stream_loop<R, SRC, OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
 }
 
+
 }  // namespace cuhe
