@@ -83,7 +83,13 @@ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
     return subp(r, (u64)hh);           // r - hh, + P on borrow (hh < 2^32 is canonical)
 }
 
-// canonical x canonical -> canonical
+// canonical x canonical -> canonical.  Chained partial products: every 64-bit addend "upper word of the previous product,
+// zero extended" is assembled with a v_mov into a pair whose upper register holds zero -- 5 moves per product, 13.6 of the
+// 154 instructions per point of the 64K transform.  A move-free form (x = a0 b0, y = a1 b1, the 65-bit cross term on one
+// multiply-add with its carry in an SGPR pair, word sums in place: 8 instead of 10 instructions, 150.8 per point) was built in
+// round 4 and is SLOWER on the transforms that matter (2.73 vs 2.78 M/s at 64K, 6.70 vs 6.88 at 32K, same box, alternating:
+// profiles/r04_mulp_ab.txt): v_mov_b32 is one of the plain 32-bit instructions that issue at 1.5-1.7x the rate of the
+// carry / 64-bit ones that replaced it (profiles/r02_valu_cost_model.txt).  Instruction COUNT is not the cost model here.
 __device__ __forceinline__ u64 mulp(u64 a, u64 b) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 t = (u64)a0 * b0;
