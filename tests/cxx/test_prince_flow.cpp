@@ -30,6 +30,7 @@
 // usage: test_prince_flow [--no-round-checks] [--threads T] [--async | --sched [W] | --compare] [--devices N [--virtual]]
 #include "dhs_client.hpp"
 #include "prince_common.hpp"
+#include "sample_profiler.hpp"
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -239,12 +240,13 @@ struct Evaluator {
 };
 
 int main(int argc, char **argv) {
-	bool checkRounds = true, async = false, virtualDevices = false, scheduledGates = false, compare = false; int threads = 8, devices = 1, schedWorkers = 0;
+	bool checkRounds = true, async = false, virtualDevices = false, scheduledGates = false, compare = false, profile = false; int threads = 8, devices = 1, schedWorkers = 0;
 	for (int i = 1; i < argc; ++i) {
 		if (std::string(argv[i]) == "--no-round-checks") checkRounds = false;
 		else if (std::string(argv[i]) == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (std::string(argv[i]) == "--async") async = true;
 		else if (std::string(argv[i]) == "--compare") compare = true;
+		else if (std::string(argv[i]) == "--profile") profile = true;          // host-side sampling profile of the encryption (tests/cxx/sample_profiler.hpp)
 		else if (std::string(argv[i]) == "--sched") { scheduledGates = true; if (i + 1 < argc && argv[i + 1][0] != '-') schedWorkers = atoi(argv[++i]); }
 		else if (std::string(argv[i]) == "--devices" && i + 1 < argc) devices = atoi(argv[++i]);
 		else if (std::string(argv[i]) == "--virtual") virtualDevices = true;      // logical devices on one physical GPU
@@ -288,10 +290,12 @@ int main(int argc, char **argv) {
 	const auto t2 = clk::now();
 	printf("encrypted 192 bits in %.2f s\n", std::chrono::duration<double>(t2 - t1).count());
 
+	if (profile) sample_profiler::start();
 	ev.encrypt(k0);
 	const auto t2b = clk::now();
 	synchronize();                                          // (scheduled gates: everything recorded has run)
 	const auto t3 = clk::now();
+	if (profile) { sample_profiler::stop(); sample_profiler::report(stdout); }
 	if (isScheduled()) printf("the client thread recorded the circuit in %.3f s\n", std::chrono::duration<double>(t2b - t2).count() - ev.paused);
 	const double encSeconds = std::chrono::duration<double>(t3 - t2).count() - ev.paused;
 
