@@ -117,6 +117,11 @@ SIGNATURES = {
     "cuhe_hip_mul_raw_batch": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_intt_mod_batch": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_crt_mod_switch_batch": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_ct_binop_list": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_crt_add_list": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_intt_batch": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_gather_blocks": (i32, [vp, vp, i32, sz, i32, vp]),
+    "cuhe_hip_scatter_blocks": (i32, [vp, vp, i32, sz, i32, vp]),
     "cuhe_hip_ntt_mul_pairs": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_crt_combine": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_relin_batch": (i32, [vp, vp, i32, i32, i32, vp]),

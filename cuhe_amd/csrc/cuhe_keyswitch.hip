@@ -571,6 +571,80 @@ int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, i
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
+// `count` blocks of `bytes` bytes each (a multiple of 16, 16-byte aligned) between their own addresses and one contiguous
+// array: gather (blocks -> array) / scatter (array -> blocks); the pointer list is HOST memory (it travels as a kernel argument)
+static int move_blocks(bool gather, void *contig, void *const *blocks, int count, size_t bytes, int dev, void *st) {
+    CHK(need_init(dev));
+    if (count < 1 || (bytes & 15) || ((uintptr_t)contig & 15)) return fail(CUHE_EINVAL, "gather / scatter of %d blocks of %zu bytes", count, bytes);
+    for (int c0 = 0; c0 < count; c0 += kPtrListMax) {
+        const int n = std::min(kPtrListMax, count - c0);
+        PtrList L;
+        for (int i = 0; i < n; ++i) { L.p[i] = blocks[c0 + i]; if ((uintptr_t)L.p[i] & 15) return fail(CUHE_EINVAL, "block %d is not 16-byte aligned", c0 + i); }
+        for (int i = n; i < kPtrListMax; ++i) L.p[i] = nullptr;
+        const int gx = (int)std::min<size_t>((bytes / 16 + 255) / 256, 256);
+        char *base = (char *)contig + (size_t)c0 * bytes;
+        if (gather) hipLaunchKernelGGL(k_move_blocks<true>, dim3(gx, n), dim3(256), 0, S(st), base, L, (long)bytes);
+        else hipLaunchKernelGGL(k_move_blocks<false>, dim3(gx, n), dim3(256), 0, S(st), base, L, (long)bytes);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+static int fill_list(PtrList &L, const void *const *p, int c0, int n) {
+    for (int i = 0; i < kPtrListMax; ++i) {
+        L.p[i] = i < n ? (void *)p[c0 + i] : nullptr;
+        if (i < n && (!L.p[i] || ((uintptr_t)L.p[i] & 15))) return fail(CUHE_EINVAL, "list entry %d is null or not 16-byte aligned", c0 + i);
+    }
+    return CUHE_OK;
+}
+// z[i] = x[i] * y[i] (mul != 0) or x[i] + y[i], pointwise modulo P, on `count` separately owned ct-domain ciphertexts of the
+// level of logq (cAnd / cXor of CuCtxt in the NTT domain, CuHE.cu:101,545 -- one launch for the whole list); lists in HOST memory
+int cuhe_hip_ct_binop_list(int mul, void *const *z, const void *const *x, const void *const *y, int count, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (count < 1) return fail(CUHE_EINVAL, "count %d", count);
+    const long n2 = (long)np * ct_len() / 2;
+    for (int c0 = 0; c0 < count; c0 += kPtrListMax) {
+        const int n = std::min(kPtrListMax, count - c0);
+        PtrList Z, X, Y;
+        CHK(fill_list(Z, (const void *const *)z, c0, n)); CHK(fill_list(X, x, c0, n)); CHK(fill_list(Y, y, c0, n));
+        const int gx = (int)std::min<long>((n2 + 255) / 256, 512);
+        if (mul) hipLaunchKernelGGL(k_ntt_binop_list<true>, dim3(gx, n), dim3(256), 0, S(st), Z, X, Y, n2);
+        else hipLaunchKernelGGL(k_ntt_binop_list<false>, dim3(gx, n), dim3(256), 0, S(st), Z, X, Y, n2);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+// z[i] = (a[i] + b[i]) mod p_row on `count` separately owned CRT-domain ciphertexts (cXor in the CRT domain, Operations.cu:264)
+int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *const *b, int count, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (count < 1) return fail(CUHE_EINVAL, "count %d", count);
+    const Params &q = G_.prm;
+    DevCtx &D = G_.dev[dev];
+    for (int c0 = 0; c0 < count; c0 += kPtrListMax) {
+        const int n = std::min(kPtrListMax, count - c0);
+        PtrList Z, A, B;
+        CHK(fill_list(Z, (const void *const *)z, c0, n)); CHK(fill_list(A, a, c0, n)); CHK(fill_list(B, b, c0, n));
+        hipLaunchKernelGGL(k_crt_add_list, dim3((q.modLen + 255) / 256, np, n), dim3(256), 0, S(st), Z, A, B, prime_tab(D), q.modLen, q.crtLen);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+// n2c of `batch` NON-product ciphertexts in one array (cuhe_hip_intt_mod_batch is the form for products): inverse transform, % p
+int cuhe_hip_intt_batch(uint32_t *dst, const uint64_t *src, int lvl, int batch, int dev, void *st_) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < -1 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (batch < 1) return fail(CUHE_EINVAL, "batch %d", batch);
+    const int np = lvl < 0 ? 1 : q.numCrtPrimeAt(lvl);
+    return ct_inverse(dst, (const u64 *)src, batch * np, 0, np, false, dev, S(st_));
+}
+int cuhe_hip_gather_blocks(void *dst, const void *const *srcs, int count, size_t bytes, int dev, void *st) {
+    return move_blocks(true, dst, (void *const *)srcs, count, bytes, dev, st);
+}
+int cuhe_hip_scatter_blocks(void *const *dsts, const void *src, int count, size_t bytes, int dev, void *st) {
+    return move_blocks(false, (void *)src, dsts, count, bytes, dev, st);
+}
 // dst[t] = src[idx_a[t]] * src[idx_b[t]] (pointwise mod P) for t < npairs; ciphertexts of `np_rows` rows; the index
 // arrays live in device memory
 int cuhe_hip_ntt_mul_pairs(uint64_t *dst, const uint64_t *src, const int32_t *idx_a, const int32_t *idx_b, int npairs, int np_rows, int dev, void *st) {

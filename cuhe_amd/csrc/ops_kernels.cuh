@@ -960,4 +960,43 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
     icrt_finish(dst, blk, bcar, nb, W, it, ci, g, base, nvalid, wo);
 }
 
+// ---- gather / scatter of equally sized blocks through a pointer list passed BY VALUE (no table in device memory): the
+// gate scheduler of the C++ layer (cuhe_amd/cxx/Scheduler.h) runs ready gates of one kind as ONE batched call on contiguous
+// arrays, while every ciphertext of the client owns its own block.  16 bytes per lane and step; bytes is a multiple of 16.
+constexpr int kPtrListMax = 32;
+struct PtrList { void *p[kPtrListMax]; };
+// elementwise gates on LISTS of separately owned ciphertexts (blockIdx.y / z = item): z[i] = x[i] (*|+) y[i] on ct rows, z[i] = (a[i] + b[i]) mod p on CRT rows
+template <bool MUL>
+__global__ __launch_bounds__(256)
+void k_ntt_binop_list(PtrList zl, PtrList xl, PtrList yl, long n2) {
+    ulonglong2 *z = (ulonglong2 *)zl.p[blockIdx.y];
+    const ulonglong2 *x = (const ulonglong2 *)xl.p[blockIdx.y], *y = (const ulonglong2 *)yl.p[blockIdx.y];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        const ulonglong2 a = x[i], b = y[i];
+        ulonglong2 r;
+        if (MUL) { r.x = mulp(a.x, b.x); r.y = mulp(a.y, b.y); }
+        else     { r.x = addp(a.x, b.x); r.y = addp(a.y, b.y); }
+        z[i] = r;
+    }
+}
+static __global__ __launch_bounds__(256)
+void k_crt_add_list(PtrList zl, PtrList al, PtrList bl, PrimeTab pt, int mlen, int clen) {
+    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mlen) return;
+    const long o = (long)crt * clen + idx;
+    u32 *z = (u32 *)zl.p[blockIdx.z];
+    const u32 *a = (const u32 *)al.p[blockIdx.z], *b = (const u32 *)bl.p[blockIdx.z];
+    z[o] = mod_small((u64)a[o] + b[o], pt.p[crt], pt.pinv[crt]);
+}
+template <bool GATHER>
+__global__ __launch_bounds__(256)
+void k_move_blocks(char *__restrict__ contig, PtrList list, long bytes) {
+    char *blk = (char *)list.p[blockIdx.y];
+    char *row = contig + (long)blockIdx.y * bytes;
+    for (long o = ((long)blockIdx.x * 256 + threadIdx.x) * 16; o < bytes; o += (long)gridDim.x * 256 * 16) {
+        if (GATHER) *(v4i *)(row + o) = __builtin_nontemporal_load((const v4i *)(blk + o));
+        else *(v4i *)(blk + o) = __builtin_nontemporal_load((const v4i *)(row + o));
+    }
+}
+
 }  // namespace cuhe

@@ -105,12 +105,16 @@ static inline bool streamOrdered() { return asyncGates || gateDepth > 0 || sched
 
 // ---- scheduled gates (addition; Scheduler.h).  The client object mirrors the metadata, the recorded tasks run the very
 // same gates below on the scheduler-side objects (from a worker thread, where scheduled() is false).
-void setScheduled(bool on, int threads) { if (on) sched::start(threads); else sched::stop(); }
+static void runBatchedGates(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int count, void *stream);
+enum { kMaxGateBatch = 64 };                // ready gates of one kind that run as one call of the array entry points
+void setScheduled(bool on, int threads) {
+	if (on) { sched::setBatchRunner(runBatchedGates, kMaxGateBatch); sched::start(threads); } else sched::stop();
+}
 bool isScheduled() { return sched::on(); }
 void synchronize() { if (sched::on() && !sched::inWorker()) sched::drain(); }
 static void schedFromEnvironment() {
 	const char *e = getenv("CUHE_SCHED");
-	if (e && atoi(e) > 0 && !sched::on()) sched::start(atoi(e) > 1 ? atoi(e) : 0);
+	if (e && atoi(e) > 0 && !sched::on()) setScheduled(true, atoi(e) > 1 ? atoi(e) : 0);
 }
 static bool schedCheck() { static const bool on = getenv("CUHE_SCHED_CHECK") && atoi(getenv("CUHE_SCHED_CHECK")) > 0; return on; }
 struct SchedAccess {
@@ -119,6 +123,7 @@ struct SchedAccess {
 	static CuCtxt &ct(sched::Node *n) { return *static_cast<CuCtxt *>(n->obj); }
 	static CuPtxt &pt(sched::Node *n) { return *static_cast<CuPtxt *>(n->obj); }
 	// `dst` becomes what a gate makes of its output when it is shaped like `like` (prepareOut, copy)
+	static void runBatch(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int count, void *stream);
 	static void setDevice(CuPolynomial &p, int dev) { p.device_ = dev; }
 	static void setProd(CuPolynomial &p, bool prod, int terms) { p.isProd_ = prod; p.prodTerms_ = terms; }
 	static void shapeLike(CuCtxt &dst, CuCtxt &like, int domain) {
@@ -514,6 +519,12 @@ void CuPolynomial::n2c(cudaStream_t st) {
 // conversion ends in (and loses the product mark wherever the chain passes through n2c).
 #define RECORD_SELF(call) do { sched::Node *n_ = schedAttach(); \
 	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }); } while (0)
+// ... as a BATCHABLE gate (Scheduler.h): ready gates of one kind on ciphertexts of one level / domain / device run as one call of
+// the array entry points (batchRunner below).  Ciphertexts only; the key says what the closure would find in the object.
+enum { kBatchX2C = 1, kBatchX2N = 2, kBatchRelin = 3, kBatchModSwitch = 4, kBatchAnd = 5, kBatchXor = 6 };
+static long batchKey(int level, int domain, bool prod) { return (long)level | (long)domain << 8 | (long)(prod ? 1 : 0) << 12; }
+#define RECORD_SELF_BATCH(call, kind, key) do { sched::Node *n_ = schedAttach(); \
+	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }, false, kind, key, n_); } while (0)
 void CuPolynomial::x2z(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ < 1) return;
@@ -544,7 +555,9 @@ void CuPolynomial::x2r(cudaStream_t st) {
 void CuPolynomial::x2c(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ == 2 || domain_ < 0) return;
-		RECORD_SELF(x2c(s));
+		CuCtxt *ct = dynamic_cast<CuCtxt *>(this);
+		if (ct && domain_ == 3) RECORD_SELF_BATCH(x2c(s), kBatchX2C, batchKey(ct->level(), 3, isProd_));
+		else RECORD_SELF(x2c(s));
 		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
 		domain_ = 2;
 		return;
@@ -556,7 +569,9 @@ void CuPolynomial::x2c(cudaStream_t st) {
 void CuPolynomial::x2n(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ == 3 || domain_ < 0) return;
-		RECORD_SELF(x2n(s));
+		CuCtxt *ct = dynamic_cast<CuCtxt *>(this);
+		if (ct && domain_ == 2) RECORD_SELF_BATCH(x2n(s), kBatchX2N, batchKey(ct->level(), 2, false));
+		else RECORD_SELF(x2n(s));
 		domain_ = 3;
 		return;
 	}
@@ -608,7 +623,9 @@ void CuCtxt::modSwitch(cudaStream_t st) {
 	if (logq_ < param.logCoeffMin + param.logCoeffCut) { printf("Error: Cannot do modSwitch on last level!\n"); terminate(); }
 	if (scheduled()) {
 		sched::Node *n = schedAttach();
-		sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { SchedAccess::stream(*n->obj) = s; SchedAccess::ct(n).modSwitch(s); });
+		const bool batchable = domain_ == 2 || domain_ == 3;
+		sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { SchedAccess::stream(*n->obj) = s; SchedAccess::ct(n).modSwitch(s); }, false,
+		              batchable ? kBatchModSwitch : 0, batchKey(level_, domain_, isProd_), n);
 		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
 		domain_ = 2; logq_ -= param.logCoeffCut; level_++;
 		return;
@@ -625,7 +642,9 @@ void CuCtxt::modSwitch(int lvl, cudaStream_t st) {
 void CuCtxt::relin(cudaStream_t st) {
 	if (scheduled()) {
 		sched::Node *n = schedAttach();
-		sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { SchedAccess::stream(*n->obj) = s; SchedAccess::ct(n).relin(s); });
+		const bool batchable = domain_ == 2 || domain_ == 3;
+		sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { SchedAccess::stream(*n->obj) = s; SchedAccess::ct(n).relin(s); }, false,
+		              batchable ? kBatchRelin : 0, batchKey(level_, domain_, isProd_), n);
 		domain_ = 2; isProd_ = false; prodTerms_ = 0;
 		return;
 	}
@@ -693,7 +712,8 @@ void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
 	if (recordGate(out, in0, in1)) {
 		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
-		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cAnd(OBJ(no), OBJ(n0), OBJ(n1), s); });
+		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cAnd(OBJ(no), OBJ(n0), OBJ(n1), s); },
+		              false, &out != &in1 ? kBatchAnd : 0, batchKey(in0.level(), 3, false), no, n0, n1);
 		if (&out != &in0) SchedAccess::shapeLike(out, in0, 3);
 		SchedAccess::setProd(out, true, 1);
 		return;
@@ -727,10 +747,12 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 		const int dom = in0.domain();
 		if (!((dom == 2 || dom == 3) && in1.domain() == dom)) misuse("Error: Addition of non-CRT-nor-NTT domain!");
 		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
-		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cXor(OBJ(no), OBJ(n0), OBJ(n1), s); });
-		// the mirror of what the gate below leaves in `out`
 		const int terms = in0.prodTerms() + in1.prodTerms();
 		const bool prod = in0.isProd() || in1.isProd(), reduced = dom == 3 && in0.isProd() && in1.isProd() && terms > cuhe_hip_ct_prod_headroom();
+		// (a sum that has to reduce its operands first is a chain of gates: not batched; nor is an `out` that is the second operand)
+		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cXor(OBJ(no), OBJ(n0), OBJ(n1), s); },
+		              false, (!reduced && &out != &in1) ? kBatchXor : 0, batchKey(in0.level(), dom, false), no, n0, n1);
+		// the mirror of what the gate below leaves in `out`
 		if (&out != &in0) SchedAccess::shapeLike(out, in0, dom);
 		if (dom == 3) SchedAccess::setProd(out, !reduced && prod, !reduced && prod ? (terms > 0 ? terms : 1) : 0);
 		return;
@@ -855,6 +877,94 @@ void cAndRelinSharded(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	CSC(cuhe_hip_mul_relin_sharded_inproc(out.cRep(), U64P(in0.nRep()), U64P(in1.nRep()), in0.level(), in0.device(), st));
 	out.isProd(false);
 	GATE_SYNC(out.device(), st);
+}
+
+// ------------------------------------------------------------------ batched gates of the scheduler (Scheduler.h)
+// `count` >= 2 ready gates of ONE kind on ciphertexts of one level, domain and device, each owning its own blocks: their rows
+// are gathered into one array, the array entry point of the C ABI runs once over all of them (count * np rows per launch
+// instead of np), the results are scattered into the ciphertexts' blocks, and every object is left exactly as its own gate
+// would have left it (the client-side mirrors were updated when the gates were recorded).  Bit-identical to the single gates:
+// the array entry points are (tests/cxx/test_cuhe_api.cpp, the array classes' PRINCE).
+static void *batchScratch(int dev, size_t bytes) { void *p = sched::taskAlloc(dev, bytes); if (!p) CSC(CUHE_EHIP); return p; }
+static void batchRelease(int dev, void *p, void *st) { if (!sched::taskFree(dev, p)) CSC(cuhe_hip_free_stream(dev, p, st)); }
+void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int n, void *st) {
+	CuCtxt *c[kMaxGateBatch] = {NULL};
+	if (n < 2 || n > kMaxGateBatch) misuse("Error: batch of scheduled gates out of range!");
+	for (int i = 0; i < n; ++i) { c[i] = &ct(subjects[i]); c[i]->stream_ = st; }
+	void *ptr[kMaxGateBatch];
+	if (kind == kBatchAnd || kind == kBatchXor) {                // out[i] = a[i] (x) b[i]: one launch for the list
+		CuCtxt *a[kMaxGateBatch], *b[kMaxGateBatch];
+		const void *pa[kMaxGateBatch], *pb[kMaxGateBatch];
+		for (int i = 0; i < n; ++i) { a[i] = &ct(op1[i]); b[i] = &ct(op2[i]); }
+		const int dom = a[0]->domain_, dev = a[0]->device_, logq = a[0]->logq_;
+		for (int i = 0; i < n; ++i) {
+			const bool prod = a[i]->isProd_ || b[i]->isProd_; const int terms = a[i]->prodTerms_ + b[i]->prodTerms_;     // (before `out` is reshaped: it may be a[i])
+			if (c[i] != a[i]) { c[i]->reset(); c[i]->stream_ = st; c[i]->setLevelForOutput(a[i]->level_, dom, dev, st); }
+			if (kind == kBatchAnd) { c[i]->isProd_ = true; c[i]->prodTerms_ = 1; }
+			else if (dom == 3) { c[i]->isProd_ = prod; c[i]->prodTerms_ = prod ? (terms > 0 ? terms : 1) : 0; }
+			ptr[i] = dom == 3 ? (void *)c[i]->nRep_ : (void *)c[i]->cRep_;
+			pa[i] = dom == 3 ? (void *)a[i]->nRep_ : (void *)a[i]->cRep_;
+			pb[i] = dom == 3 ? (void *)b[i]->nRep_ : (void *)b[i]->cRep_;
+		}
+		if (dom == 3) CSC(cuhe_hip_ct_binop_list(kind == kBatchAnd ? 1 : 0, ptr, pa, pb, n, logq, dev, st));
+		else CSC(cuhe_hip_crt_add_list(ptr, pa, pb, n, logq, dev, st));
+		return;
+	}
+	const int dev = c[0]->device_, lvl = c[0]->level_, np = param._numCrtPrime(lvl);
+	const bool fromNtt = c[0]->domain_ == 3, prod = c[0]->isProd_;
+	int cls = 2; while (cls < n) cls *= 2;                       // few scratch sizes (the block cache is keyed by size): level-0 rows, 2 / 4 / .. / 64 ciphertexts
+	const size_t cRows = (size_t)np * param.crtLen, nRows = (size_t)np * cuhe_hip_ct_len();
+	const size_t cBytes = cRows * sizeof(uint32), nBytes = nRows * sizeof(uint64);
+	const size_t cScratch = (size_t)cls * param.numCrtPrime * param.crtLen * sizeof(uint32), nScratch = (size_t)cls * param.numCrtPrime * cuhe_hip_ct_len() * sizeof(uint64);
+	if (kind == kBatchX2N) {                                     // c2n of every ciphertext: one transform call over n * np rows
+		uint32 *cin = (uint32 *)batchScratch(dev, cScratch);
+		uint64 *nout = (uint64 *)batchScratch(dev, nScratch);
+		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
+		CSC(cuhe_hip_gather_blocks(cin, ptr, n, cBytes, dev, st));
+		CSC(cuhe_hip_ntt_rows(U64P(nout), cin, n * np, dev, st));
+		for (int i = 0; i < n; ++i) { c[i]->nRepAlloc(st); ptr[i] = c[i]->nRep_; }
+		CSC(cuhe_hip_scatter_blocks(ptr, nout, n, nBytes, dev, st));
+		for (int i = 0; i < n; ++i) { c[i]->cRepFree(); c[i]->domain_ = 3; }
+		batchRelease(dev, cin, st); batchRelease(dev, nout, st);
+		return;
+	}
+	// the other three start from reduced CRT rows of every ciphertext in one array
+	uint32 *rows = (uint32 *)batchScratch(dev, cScratch);
+	// (kernels that produce CRT rows write the modLen coefficients of the ring: on a ring shorter than the row the rest has to read as zero)
+	if (shortRing() && fromNtt) CSC(cuhe_hip_memset_async(dev, rows, 0, n * cBytes, st));
+	if (fromNtt) {                                               // n2c: inverse transform (+ reduction modulo the polynomial modulus for products)
+		uint64 *nin = (uint64 *)batchScratch(dev, nScratch);
+		for (int i = 0; i < n; ++i) ptr[i] = c[i]->nRep_;
+		CSC(cuhe_hip_gather_blocks(nin, ptr, n, nBytes, dev, st));
+		if (prod) CSC(cuhe_hip_intt_mod_batch(rows, U64P(nin), lvl, n, dev, st));
+		else CSC(cuhe_hip_intt_batch(rows, U64P(nin), lvl, n, dev, st));
+		batchRelease(dev, nin, st);
+		for (int i = 0; i < n; ++i) { c[i]->cRepAlloc(st); c[i]->nRepFree(); c[i]->domain_ = 2; c[i]->isProd_ = false; c[i]->prodTerms_ = 0; }
+	} else {
+		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
+		CSC(cuhe_hip_gather_blocks(rows, ptr, n, cBytes, dev, st));
+	}
+	size_t outBytes = cBytes;
+	uint32 *result = rows, *next = NULL;
+	if (kind == kBatchRelin) {
+		CSC(cuhe_hip_relin_batch(rows, rows, lvl, n, dev, st));
+		for (int i = 0; i < n; ++i) { c[i]->isProd_ = false; c[i]->prodTerms_ = 0; }
+	} else if (kind == kBatchModSwitch) {
+		next = (uint32 *)batchScratch(dev, cScratch);
+		if (shortRing()) CSC(cuhe_hip_memset_async(dev, next, 0, n * cBytes, st));
+		CSC(cuhe_hip_crt_mod_switch_batch(next, rows, lvl, n, dev, st));
+		result = next; outBytes = (size_t)(np - 1) * param.crtLen * sizeof(uint32);
+		for (int i = 0; i < n; ++i) { c[i]->logq_ -= param.logCoeffCut; c[i]->level_++; }
+	}
+	if (fromNtt || kind != kBatchX2C) {                           // (x2c of CRT-domain ciphertexts is never recorded)
+		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
+		CSC(cuhe_hip_scatter_blocks(ptr, result, n, outBytes, dev, st));
+	}
+	batchRelease(dev, rows, st);
+	if (next) batchRelease(dev, next, st);
+}
+static void runBatchedGates(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int count, void *stream) {
+	SchedAccess::runBatch(kind, subjects, op1, op2, count, stream);
 }
 
 // ------------------------------------------------------------------ NTL interface

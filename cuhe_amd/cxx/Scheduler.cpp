@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -41,6 +42,7 @@ struct Task {
 	int pending = 0;                       // dependencies not issued yet
 	bool issued = false;
 	StreamState *ss = nullptr; long seq = 0;     // where it ran: task #seq of that stream
+	int kind = 0; long key = 0; Node *subject = nullptr, *op1 = nullptr, *op2 = nullptr;      // batchable gate (Scheduler.h)
 	int refs = 1;                          // the graph itself until the task has run; + nodes, successors, waiters
 };
 
@@ -50,6 +52,13 @@ std::condition_variable cvReady, cvDone;
 std::deque<Task *> ready;                  // tasks that were ready when the client recorded them
 std::vector<std::deque<Task *>> local;     // per worker: tasks its own tasks made ready (newest at the back; thieves take the oldest)
 int stealing = 1;                          // CUHE_SCHED_LOCAL=0: one shared queue
+// batchable ready tasks by (kind, key, device); they run when the workers have no other ready task (the gates that FEED a
+// group -- the products before the relinearisations of a layer -- are issued first, so that the group is as large as the circuit allows)
+struct GroupKey { int kind, dev; long key; bool operator<(const GroupKey &o) const { return kind != o.kind ? kind < o.kind : dev != o.dev ? dev < o.dev : key < o.key; } };
+std::map<GroupKey, std::deque<Task *>> staged;
+long stagedCount = 0, batchesRun = 0, batchedTasks = 0;
+int busyRegular = 0;                       // workers inside a non-batch task: more members of a group may still appear
+BatchRunner batchRunner = nullptr; int maxBatch = 1;
 std::vector<std::thread> workers;
 bool active = false, stopping = false;
 long outstanding = 0, totalTasks = 0, totalWaits = 0, totalRecords = 0, maxQueued = 0;
@@ -131,6 +140,29 @@ Task *takeTask(int me) {
 	Task *t = local[from].front(); local[from].pop_front();
 	return t;
 }
+// mu held: the fullest staged group, up to maxBatch of its tasks (oldest first) -- only when it is full or no worker is inside a
+// regular task any more (what such a task makes ready may belong to the group)
+bool takeBatch(std::vector<Task *> &batch) {
+	if (stagedCount == 0) return false;
+	auto best = staged.end();
+	for (auto it = staged.begin(); it != staged.end(); ++it) if (best == staged.end() || it->second.size() > best->second.size()) best = it;
+	if (best == staged.end() || best->second.empty()) return false;
+	if ((int)best->second.size() < maxBatch && busyRegular > 0) return false;
+	while (!best->second.empty() && (int)batch.size() < maxBatch) { batch.push_back(best->second.front()); best->second.pop_front(); --stagedCount; }
+	if (best->second.empty()) staged.erase(best);
+	return true;
+}
+// mu held: a task whose dependencies have all been issued
+void makeReady(Task *t, int me, Task **next) {
+	if (t->kind && batchRunner && maxBatch > 1) {
+		staged[GroupKey{t->kind, t->dev, t->key}].push_back(t); ++stagedCount;
+		cvReady.notify_one();
+		return;
+	}
+	if (next && !*next) { *next = t; return; }            // follow the chain on this stream: no event wait, warm scratch
+	if (me >= 0 && stealing) local[me].push_back(t); else ready.push_back(t);
+	cvReady.notify_one();
+}
 StreamState *streamOf(int dev) {
 	if ((int)tlsStreams.size() <= dev) tlsStreams.resize(dev + 1, nullptr);
 	if (!tlsStreams[dev]) {
@@ -149,58 +181,72 @@ void workerMain(int me) {
 	std::unique_lock<std::mutex> lk(mu);
 	++startedWorkers; cvDone.notify_all();
 	Task *next = nullptr;
+	std::vector<Task *> batch;
 	for (;;) {
-		Task *t = next; next = nullptr;
-		if (!t) {
+		batch.clear();
+		if (next) { batch.push_back(next); next = nullptr; }
+		else {
 			const auto w0 = clk::now();
-			while (!(t = takeTask(me))) { if (stopping) return; cvReady.wait(lk); }
+			for (;;) {
+				if (Task *t = takeTask(me)) { batch.push_back(t); break; }
+				if (takeBatch(batch)) break;
+				if (stopping) return;
+				cvReady.wait(lk);
+			}
 			idleSeconds += std::chrono::duration<double>(clk::now() - w0).count();
 		}
 		const auto b0 = clk::now();
-		if ((int)devUsed.size() <= t->dev) devUsed.resize(t->dev + 1, 0);
-		devUsed[t->dev] = 1;
+		const bool regular = batch.size() == 1 && !(batch[0]->kind && batchRunner && maxBatch > 1);
+		if (regular) ++busyRegular;
+		const int dev = batch[0]->dev;
+		if ((int)devUsed.size() <= dev) devUsed.resize(dev + 1, 0);
+		devUsed[dev] = 1;
 		lk.unlock();
-		StreamState *ss = streamOf(t->dev);
+		StreamState *ss = streamOf(dev);
 		void *s = ss->stream;
 		long waits = 0, records = 0;
 		// one wait per foreign stream: behind the latest of the dependencies that ran there
-		for (size_t i = 0; i < t->deps.size(); ++i) {
-			Task *d = t->deps[i];
-			if (d->ss == ss) continue;          // same stream: already ordered
-			bool later = false;
-			for (size_t j = 0; j < t->deps.size() && !later; ++j)
-				later = j != i && t->deps[j]->ss == d->ss && (t->deps[j]->seq > d->seq || (t->deps[j]->seq == d->seq && j < i));
-			if (later) continue;
-			records += orderAfter(t->dev, s, d->ss, d->seq);
-			++waits;
-		}
+		std::vector<std::pair<StreamState *, long>> latest;
+		for (Task *t : batch)
+			for (Task *d : t->deps) {
+				if (d->ss == ss) continue;          // same stream: already ordered
+				bool found = false;
+				for (auto &e : latest) if (e.first == d->ss) { if (d->seq > e.second) e.second = d->seq; found = true; }
+				if (!found) latest.push_back({d->ss, d->seq});
+			}
+		for (auto &e : latest) { records += orderAfter(dev, s, e.first, e.second); ++waits; }
 		tlsStream = s;
 		const auto f0 = clk::now();
-		t->fn(s);
-		t->fn = nullptr;                        // the closure's captures go before the graph lock is taken again
+		if (batch.size() == 1) batch[0]->fn(s);
+		else {
+			std::vector<Node *> subjects, o1, o2;
+			for (Task *t : batch) { subjects.push_back(t->subject); o1.push_back(t->op1); o2.push_back(t->op2); }
+			batchRunner(batch[0]->kind, subjects.data(), o1.data(), o2.data(), (int)subjects.size(), s);
+		}
+		for (Task *t : batch) t->fn = nullptr;      // the closures' captures go before the graph lock is taken again
 		const auto f1 = clk::now();
 		std::vector<CuPolynomial *> dead;
 		const long seq = ss->seq.load(std::memory_order_relaxed) + 1;
 		ss->seq.store(seq, std::memory_order_release);
 		lk.lock();
-		t->ss = ss; t->seq = seq; t->issued = true;
+		if (regular) --busyRegular;
+		if (batch.size() > 1) { ++batchesRun; batchedTasks += (long)batch.size(); }
 		totalWaits += waits; totalRecords += records;
 		busySeconds += std::chrono::duration<double>(clk::now() - b0).count();
 		gateSeconds += std::chrono::duration<double>(f1 - f0).count();
 		orderSeconds += std::chrono::duration<double>(f0 - b0).count();
-		for (Task *d : t->deps) unrefTask(d);
-		t->deps.clear();
-		for (Node *n : t->nodes) unrefNode(n, dead);
-		t->nodes.clear();
-		for (Task *x : t->succ)
-			if (--x->pending == 0) {
-				if (!next) next = x;            // follow the chain on this stream: no event wait, warm scratch
-				else if (stealing) { local[me].push_back(x); cvReady.notify_one(); }
-				else { ready.push_back(x); cvReady.notify_one(); }
-			}
-		t->succ.clear();
-		--outstanding;
-		unrefTask(t);
+		for (Task *t : batch) {
+			t->ss = ss; t->seq = seq; t->issued = true;
+			for (Task *d : t->deps) unrefTask(d);
+			t->deps.clear();
+			for (Node *n : t->nodes) unrefNode(n, dead);
+			t->nodes.clear();
+			for (Task *x : t->succ) if (--x->pending == 0) makeReady(x, me, &next);
+			t->succ.clear();
+			--outstanding;
+			unrefTask(t);
+		}
+		if (stagedCount && busyRegular == 0) cvReady.notify_all();     // a group that waited for the regular work to drain
 		cvDone.notify_all();
 		if (!dead.empty()) {
 			lk.unlock();
@@ -228,7 +274,7 @@ void start(int n) {
 	std::unique_lock<std::mutex> lk(mu);
 	if (active) return;
 	if (n <= 0) { const char *e = getenv("CUHE_SCHED_THREADS"); n = e ? atoi(e) : 0; }
-	if (n <= 0) n = 5;                          // PRINCE gate by gate: 0.25 / 0.21 / 0.19 / 0.22 s with 3 / 4 / 5 / 6 workers (profiles/r04_sched_prince.txt)
+	if (n <= 0) n = 3;                          // PRINCE gate by gate: 0.114-0.121 s with 3 workers, 0.126-0.133 with 4 (ready gates in batches of up to 64; profiles/r04_sched_prince.txt)
 	stopping = false; startedWorkers = 0;
 	if (getenv("CUHE_SCHED_LOCAL")) stealing = atoi(getenv("CUHE_SCHED_LOCAL"));
 	local.assign(n, std::deque<Task *>());
@@ -295,6 +341,7 @@ void stop() {
 		cuhe_hip_alloc_counters(ac);
 		printf("allocator: %lld hipMalloc, %lld pool hits, %lld stream hits, %lld cross-stream hand-overs\n", ac[0], ac[1], ac[2], ac[3]);
 		printf("task blocks: %ld from the same stream, %ld from another stream (ordered behind their last use), %ld from the library\n", cacheHits, cacheForeign, cacheMisses);
+		printf("batches: %ld calls of the batch runner for %ld gates\n", batchesRun, batchedTasks);
 		printf("scheduler: %ld tasks, %ld cross-stream waits on %ld event records, at most %ld tasks recorded ahead; %zu workers busy %.3f s (%.3f in the gates, %.3f ordering streams), idle %.3f s in total\n",
 		       totalTasks, totalWaits, totalRecords, maxQueued, workers.size(), busySeconds, gateSeconds, orderSeconds, idleSeconds);
 	}
@@ -308,9 +355,17 @@ void releaseNode(Node *n) {
 	for (CuPolynomial *p : dead) delete p;
 }
 
-Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep) {
+void setBatchRunner(BatchRunner r, int mb) {
+	std::lock_guard<std::mutex> lk(mu);
+	const char *e = getenv("CUHE_SCHED_BATCH");
+	batchRunner = (e && atoi(e) == 0) ? nullptr : r;
+	maxBatch = e && atoi(e) > 1 ? atoi(e) : mb;
+	if (maxBatch > mb) maxBatch = mb;
+}
+Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep, int kind, long key, Node *subject,
+             Node *op1, Node *op2) {
 	Task *t = new Task;
-	t->fn = std::move(fn); t->dev = dev;
+	t->fn = std::move(fn); t->dev = dev; t->kind = kind; t->key = key; t->subject = subject; t->op1 = op1; t->op2 = op2;
 	std::lock_guard<std::mutex> lk(mu);
 	auto after = [&](Task *d) {
 		if (!d) return;
@@ -339,7 +394,7 @@ Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *
 	if (keep) ++t->refs;
 	++outstanding; ++totalTasks;
 	if (outstanding > maxQueued) maxQueued = outstanding;
-	if (t->pending == 0) { ready.push_back(t); cvReady.notify_one(); }
+	if (t->pending == 0) makeReady(t, -1, nullptr);
 	return t;
 }
 

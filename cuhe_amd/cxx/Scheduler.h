@@ -39,8 +39,15 @@ int threads();
 
 Node *newNode(CuPolynomial *obj);
 void releaseNode(Node *n);                 // the client object lets go (tasks may still hold the node)
-// record a gate: fn(stream) runs on a worker once every dependency has been issued
-Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep = false);
+// record a gate: fn(stream) runs on a worker once every dependency has been issued.
+// kind != 0: a BATCHABLE gate on ONE polynomial (`subject`, among the writes): ready tasks of one (kind, key, device) wait in a
+// staging area until the workers have nothing else to issue, then up to maxBatch of them run as ONE call of the batch runner
+// (gather the subjects' blocks, one array entry point of the C ABI over all their rows, scatter) instead of their closures.
+// op1 / op2: the operands of a batchable binary gate (subject = op1 (x) op2)
+Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep = false,
+             int kind = 0, long key = 0, Node *subject = nullptr, Node *op1 = nullptr, Node *op2 = nullptr);
+typedef void (*BatchRunner)(int kind, Node *const *subjects, Node *const *op1, Node *const *op2, int count, void *stream);
+void setBatchRunner(BatchRunner r, int maxBatch);      // (r == nullptr or CUHE_SCHED_BATCH=0: every task runs its own closure)
 void wait(Task *t);                        // until t has run on its worker and its device work has finished; drops the reference `keep` took
 void waitNode(Node *n);                    // until everything recorded on the node so far has finished on the device
 void drain();                              // until everything recorded so far has finished on the device

@@ -244,6 +244,17 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a_raw, const uint32_t 
 int cuhe_hip_intt_mod_batch(uint32_t *dst_crt, const uint64_t *src_ntt, int lvl, int batch, int dev, void *stream);
 /* modSwitch: src at level lvl (np rows each) -> dst at level lvl+1, packed u32[batch][np-1][crtLen] */
 int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, int batch, int dev, void *stream);
+/* `count` equally sized blocks (bytes: a multiple of 16, blocks 16-byte aligned) between their own addresses and one contiguous
+   array; the pointer list is HOST memory and travels as a kernel argument.  What lets the C++ layer's gate scheduler run the
+   ready gates of one kind on separately owned ciphertexts as one call of the array entry points above and below. */
+int cuhe_hip_gather_blocks(void *dst, const void *const *srcs, int count, size_t bytes, int dev, void *stream);
+int cuhe_hip_scatter_blocks(void *const *dsts, const void *src, int count, size_t bytes, int dev, void *stream);
+/* elementwise gates over LISTS of separately owned ciphertexts of one level, one launch per 32: ct rows z = x * y (mul != 0) or
+   x + y modulo P (cAnd / cXor in the NTT domain), CRT rows z = (a + b) mod p (cXor in the CRT domain); lists in host memory */
+int cuhe_hip_ct_binop_list(int mul, void *const *z, const void *const *x, const void *const *y, int count, int logq, int dev, void *stream);
+int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *const *b, int count, int logq, int dev, void *stream);
+/* n2c of `batch` NON-product ciphertexts of one level in one array (intt_mod_batch is the form for products) */
+int cuhe_hip_intt_batch(uint32_t *dst_crt, const uint64_t *src_ntt, int lvl, int batch, int dev, void *stream);
 /* cAnd over index pairs: dst[t] = src[idx_a[t]] * src[idx_b[t]], ciphertexts of np_rows rows */
 int cuhe_hip_ntt_mul_pairs(uint64_t *dst, const uint64_t *src, const int32_t *idx_a, const int32_t *idx_b, int npairs, int np_rows, int dev, void *stream);
 /* cXor / cNot over index lists: dst[o] = sum of the listed ciphertexts (+ add_const[o] on the constant coefficient);

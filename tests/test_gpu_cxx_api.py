@@ -51,9 +51,10 @@ def test_dhs_scheme_flow(params, sched):
 
 @pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"],
                                    ["--threads", "6", "--async", "--devices", "3", "--virtual"],
-                                   ["--threads", "1", "--sched"], ["--threads", "1", "--sched", "3", "--devices", "3", "--virtual"]],
+                                   ["--threads", "1", "--sched"], ["--threads", "1", "--sched", "3", "--devices", "3", "--virtual"],
+                                   ["--threads", "1", "--sched", "5", "--no-batching"]],
                          ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices",
-                              "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices"])
+                              "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices", "scheduled-1-thread-no-batching"])
 def test_prince_known_answer(flags):
     """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
     reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
@@ -61,7 +62,10 @@ def test_prince_known_answer(flags):
     Run with the reference's synchronous gate semantics on 8 host threads / streams, and with asynchronous gates
     (setAsynchronous: stream-ordered buffers, one synchronisation per S-box) on 4 threads and on the default stream;
     and in the reference's multi-GPU arrangement (Prince.cu:194-200: the S-boxes of a layer spread over the devices'
-    threads, moveTo to and from the device that holds the state) on three virtual devices of the one GPU."""
+    threads, moveTo to and from the device that holds the state) on three virtual devices of the one GPU.
+    scheduled-*: ONE client thread, default stream, a gate per call (the reference client's pattern) with the library's gate
+    scheduler on (setScheduled): ready gates of one kind run as one call of the array entry points; CUHE_SCHED_CHECK=1
+    verifies the client-side metadata mirrors whenever an object is taken back."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
@@ -70,7 +74,11 @@ def test_prince_known_answer(flags):
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_flow")
-    r = subprocess.run([exe] + flags, capture_output=True, text=True, timeout=1200, env=dict(os.environ, CUHE_SCHED_CHECK="1"))
+    env = dict(os.environ, CUHE_SCHED_CHECK="1")
+    if "--no-batching" in flags:                    # every recorded gate runs its own closure (CUHE_SCHED_BATCH=0): the path the batches replace
+        env["CUHE_SCHED_BATCH"] = "0"
+        flags = [f for f in flags if f != "--no-batching"]
+    r = subprocess.run([exe] + flags, capture_output=True, text=True, timeout=1200, env=env)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
