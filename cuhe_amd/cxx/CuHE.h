@@ -154,8 +154,9 @@ bool isAsynchronous();
 // (addition) scheduled gates: the SAME client code -- one host thread, default stream, a gate per call -- with the
 // independent gates running concurrently.  Every public gate and conversion records a task (what it reads, what it
 // writes); worker threads of the library issue the tasks on their own streams as their inputs become available, ordered
-// on the GPU by events.  The client blocks only in x2z(), in the raw-pointer getters, and in synchronize().  Results are
-// those of the synchronous gates, bit for bit.  Also switched on by CUHE_SCHED=1 (CUHE_SCHED_THREADS=n workers) in the
+// on the GPU by events; ready gates of one kind on ciphertexts of one level run as one call of the array entry points.
+// The client blocks only in x2z(), in the raw-pointer getters, and in synchronize().  Results are those of the
+// synchronous gates, bit for bit.  Also switched on by CUHE_SCHED=1 (CUHE_SCHED_THREADS=n workers) in the
 // environment at initCuHE, so that an unchanged client gets it.  Default: off (the reference's semantics).
 void setScheduled(bool on, int threads = 0);
 bool isScheduled();
