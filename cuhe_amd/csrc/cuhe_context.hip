@@ -86,8 +86,9 @@ int workspace(int dev, hipStream_t st, Workspace **out) {
 // Barrett / inttResult scratch for `rows` polynomial rows (at least one level-0 ciphertext)
 int ws_barrett(Workspace &w, int rows) {
     const Params &q = G_.prm;
-    const size_t need = (size_t)std::max(rows, q.numCrtPrime);
+    size_t need = (size_t)std::max(rows, q.numCrtPrime);
     if (w.n_barrett >= need && w.hold) return CUHE_OK;
+    if (w.hold) need = std::max(need, 2 * w.n_barrett);          // geometric growth: the re-allocation waits for the device
     size_t a = 0, b = 0, c = 0, d = 0;
     CHK(ws_grow(&w.b_mq, &a, need * q.nttLen)); CHK(ws_grow(&w.b_crt, &b, need * q.nttLen));
     CHK(ws_grow(&w.b_ntt, &c, need * q.nttLen)); CHK(ws_grow(&w.hold, &d, need * q.nttLen));
@@ -107,7 +108,9 @@ int ws_relin(Workspace &w, int cts) {
 }
 int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        // grow-only
     if (w.slab_bytes[li][which] < bytes) {
-        if (w.slab[li][which]) HIPCHK(hipFree(w.slab[li][which]));            // (synchronises: rare, sizes settle at once)
+        // hipFree waits for the whole device: grow geometrically, so that a caller whose row counts creep up (the gate scheduler's
+        // batches) pays for a handful of re-allocations, not one per new maximum
+        if (w.slab[li][which]) { HIPCHK(hipFree(w.slab[li][which])); bytes = std::max(bytes, 2 * w.slab_bytes[li][which]); }
         w.slab[li][which] = nullptr; w.slab_bytes[li][which] = 0;
         HIPCHK(hipMalloc((void **)&w.slab[li][which], bytes));
         w.slab_bytes[li][which] = bytes;
@@ -442,7 +445,7 @@ int cuhe_hip_alloc_counters(long long *out4) {
 void *cuhe_hip_malloc(int dev, size_t bytes) {
     if (set_dev(dev) != CUHE_OK) return nullptr;
     DevCtx &D = G_.dev[dev];
-    std::lock_guard<std::mutex> lk(G_.mu);
+    std::unique_lock<std::mutex> lk(G_.mu);
     auto it = D.freeBlocks.find(bytes);
     if (it == D.freeBlocks.end()) {
         // a miss: blocks of this size parked in the order of a stream that has gone idle since are free (several streams
@@ -463,7 +466,10 @@ void *cuhe_hip_malloc(int dev, size_t bytes) {
     }
     void *p = nullptr;
     ++g_alloc_counters[0];
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    lk.unlock();                                          // hipMalloc takes tens of microseconds to milliseconds: not under the library's lock
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    lk.lock();
+    if (e != hipSuccess) {
         (void)hipGetLastError();
         drop_cached(D);                                   // give the parked blocks back and try once more
         if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(CUHE_EHIP, "hipMalloc(%zu) failed", bytes); return nullptr; }

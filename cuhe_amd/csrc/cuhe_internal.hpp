@@ -215,7 +215,7 @@ int ws_buffer(T **ptr, size_t count) {           // lazily allocated, fixed-size
 template <typename T>
 int ws_grow(T **ptr, size_t *have, size_t count) {           // grow-only (re-allocation synchronises: sizes settle at once)
     if (*have >= count && *ptr) return CUHE_OK;
-    if (*ptr) HIPCHK(hipFree(*ptr));
+    if (*ptr) { HIPCHK(hipFree(*ptr)); count = std::max(count, 2 * *have); }      // (hipFree waits for the device: geometric growth)
     *ptr = nullptr; *have = 0;
     HIPCHK(hipMalloc((void **)ptr, std::max<size_t>(count, 1) * sizeof(T)));
     *have = count;

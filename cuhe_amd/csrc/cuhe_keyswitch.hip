@@ -407,13 +407,14 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     Workspace &Ws = *Wp;
     if (Ws.n_bt < (size_t)batch) {
         size_t x = 0, y = 0;
+        const size_t cap = std::max<size_t>(batch, 2 * Ws.n_bt);      // geometric: every re-allocation waits for the device (hipFree)
         if (Ws.bt_ntt) { HIPCHK(hipFree(Ws.bt_ntt)); Ws.bt_ntt = nullptr; }
         if (Ws.bt_crt) { HIPCHK(hipFree(Ws.bt_crt)); Ws.bt_crt = nullptr; }
-        CHK(ws_grow(&Ws.bt_ntt, &x, (size_t)batch * q.numCrtPrime * L));
-        CHK(ws_grow(&Ws.bt_crt, &y, (size_t)batch * q.numCrtPrime * cl));
-        Ws.n_bt = batch;
+        CHK(ws_grow(&Ws.bt_ntt, &x, cap * q.numCrtPrime * L));
+        CHK(ws_grow(&Ws.bt_crt, &y, cap * q.numCrtPrime * cl));
+        Ws.n_bt = cap;
     }
-    CHK(ws_relin(Ws, batch));
+    CHK(ws_relin(Ws, (int)std::max<size_t>(batch, Ws.n_relin < (size_t)batch ? 2 * Ws.n_relin : 0)));
     // reduction of `rows` ct-domain product rows to CRT rows (n2c with isProd, CuHE.cu:398-408)
     auto reduce_rows = [&](u32 *out, const u64 *in) -> int { return ct_inverse(out, in, rows, 0, np, true, dev, st); };
     const u32 *crt_rows = crt_in;
@@ -626,6 +627,20 @@ int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *cons
         PtrList Z, A, B;
         CHK(fill_list(Z, (const void *const *)z, c0, n)); CHK(fill_list(A, a, c0, n)); CHK(fill_list(B, b, c0, n));
         hipLaunchKernelGGL(k_crt_add_list, dim3((q.modLen + 255) / 256, np, n), dim3(256), 0, S(st), Z, A, B, prime_tab(D), q.modLen, q.crtLen);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+// dst[i] = src[i] for `count` separately owned blocks of `bytes` bytes (copy() of CuCtxt, CuHE.cu:81: one launch for the list)
+int cuhe_hip_copy_list(void *const *dst, const void *const *src, int count, size_t bytes, int dev, void *st) {
+    CHK(need_init(dev));
+    if (count < 1 || (bytes & 15)) return fail(CUHE_EINVAL, "copy of %d blocks of %zu bytes", count, bytes);
+    for (int c0 = 0; c0 < count; c0 += kPtrListMax) {
+        const int n = std::min(kPtrListMax, count - c0);
+        PtrList Dl, Sl;
+        CHK(fill_list(Dl, (const void *const *)dst, c0, n)); CHK(fill_list(Sl, src, c0, n));
+        const int gx = (int)std::min<size_t>((bytes / 16 + 255) / 256, 256);
+        hipLaunchKernelGGL(k_copy_list, dim3(gx, n), dim3(256), 0, S(st), Dl, Sl, (long)bytes);
     }
     HIPCHK(hipGetLastError());
     return CUHE_OK;

@@ -988,6 +988,13 @@ void k_crt_add_list(PtrList zl, PtrList al, PtrList bl, PrimeTab pt, int mlen, i
     const u32 *a = (const u32 *)al.p[blockIdx.z], *b = (const u32 *)bl.p[blockIdx.z];
     z[o] = mod_small((u64)a[o] + b[o], pt.p[crt], pt.pinv[crt]);
 }
+static __global__ __launch_bounds__(256)
+void k_copy_list(PtrList dl, PtrList sl, long bytes) {
+    char *d = (char *)dl.p[blockIdx.y];
+    const char *sr = (const char *)sl.p[blockIdx.y];
+    for (long o = ((long)blockIdx.x * 256 + threadIdx.x) * 16; o < bytes; o += (long)gridDim.x * 256 * 16)
+        *(v4i *)(d + o) = __builtin_nontemporal_load((const v4i *)(sr + o));
+}
 template <bool GATHER>
 __global__ __launch_bounds__(256)
 void k_move_blocks(char *__restrict__ contig, PtrList list, long bytes) {

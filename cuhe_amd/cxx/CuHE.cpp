@@ -106,7 +106,7 @@ static inline bool streamOrdered() { return asyncGates || gateDepth > 0 || sched
 // ---- scheduled gates (addition; Scheduler.h).  The client object mirrors the metadata, the recorded tasks run the very
 // same gates below on the scheduler-side objects (from a worker thread, where scheduled() is false).
 static void runBatchedGates(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int count, void *stream);
-enum { kMaxGateBatch = 64 };                // ready gates of one kind that run as one call of the array entry points
+enum { kMaxGateBatch = 128 };                // ready gates of one kind that run as one call of the array entry points
 void setScheduled(bool on, int threads) {
 	if (on) { sched::setBatchRunner(runBatchedGates, kMaxGateBatch); sched::start(threads); } else sched::stop();
 }
@@ -521,7 +521,7 @@ void CuPolynomial::n2c(cudaStream_t st) {
 	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }); } while (0)
 // ... as a BATCHABLE gate (Scheduler.h): ready gates of one kind on ciphertexts of one level / domain / device run as one call of
 // the array entry points (batchRunner below).  Ciphertexts only; the key says what the closure would find in the object.
-enum { kBatchX2C = 1, kBatchX2N = 2, kBatchRelin = 3, kBatchModSwitch = 4, kBatchAnd = 5, kBatchXor = 6 };
+enum { kBatchX2C = 1, kBatchX2N = 2, kBatchRelin = 3, kBatchModSwitch = 4, kBatchAnd = 5, kBatchXor = 6, kBatchCopy = 7 };
 static long batchKey(int level, int domain, bool prod) { return (long)level | (long)domain << 8 | (long)(prod ? 1 : 0) << 12; }
 #define RECORD_SELF_BATCH(call, kind, key) do { sched::Node *n_ = schedAttach(); \
 	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }, false, kind, key, n_); } while (0)
@@ -686,7 +686,8 @@ void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	if (&dst == &src) return;
 	if (recordGate(dst, src) && src.domain() > 0) {
 		sched::Node *ns = src.schedAttach(), *nd = dst.schedAttach();
-		sched::submit(src.device(), Nodes(1, ns), Nodes(1, nd), [ns, nd](void *s) { SchedAccess::stream(*nd->obj) = s; copy(OBJ(nd), OBJ(ns), s); });
+		sched::submit(src.device(), Nodes(1, ns), Nodes(1, nd), [ns, nd](void *s) { SchedAccess::stream(*nd->obj) = s; copy(OBJ(nd), OBJ(ns), s); },
+		              false, src.domain() >= 2 ? kBatchCopy : 0, batchKey(src.level(), src.domain(), false), nd, ns, NULL);
 		const bool prod = src.isProd(); const int terms = src.prodTerms();
 		SchedAccess::shapeLike(dst, src, src.domain());
 		SchedAccess::setProd(dst, prod, terms);
@@ -885,13 +886,48 @@ void cAndRelinSharded(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 // instead of np), the results are scattered into the ciphertexts' blocks, and every object is left exactly as its own gate
 // would have left it (the client-side mirrors were updated when the gates were recorded).  Bit-identical to the single gates:
 // the array entry points are (tests/cxx/test_cuhe_api.cpp, the array classes' PRINCE).
-static void *batchScratch(int dev, size_t bytes) { void *p = sched::taskAlloc(dev, bytes); if (!p) CSC(CUHE_EHIP); return p; }
-static void batchRelease(int dev, void *p, void *st) { if (!sched::taskFree(dev, p)) CSC(cuhe_hip_free_stream(dev, p, st)); }
+// Scratch arrays of a batch: three grow-only buffers per worker thread and device (a worker runs one batch at a time, on
+// its own stream: the next batch's use is ordered behind this one's), grown geometrically -- a PRINCE block sees batches of
+// 2 ... 128 ciphertexts at 25 levels, and every fresh hipMalloc of hundreds of megabytes costs milliseconds.
+struct BatchScratch {
+	struct Buf { void *p = NULL; size_t cap = 0; };
+	std::vector<std::vector<Buf>> perDev;
+	void *get(int dev, int slot, size_t bytes, void *st) {
+		if ((int)perDev.size() <= dev) perDev.resize(dev + 1, std::vector<Buf>(3));
+		Buf &b = perDev[dev][slot];
+		if (b.cap < bytes) {
+			if (b.p) CSC(cuhe_hip_free_stream(dev, b.p, st));        // (work of this stream may still read it: released in its order)
+			const size_t cap = bytes > 2 * b.cap ? bytes : 2 * b.cap;
+			b.p = cuhe_hip_malloc(dev, cap);
+			if (!b.p) CSC(CUHE_EHIP);
+			b.cap = cap;
+		}
+		return b.p;
+	}
+	~BatchScratch() { for (size_t d = 0; d < perDev.size(); ++d) for (Buf &b : perDev[d]) if (b.p && cuhe_hip_is_initialised()) cuhe_hip_free((int)d, b.p); }
+};
+static thread_local BatchScratch tlsBatchScratch;
 void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int n, void *st) {
 	CuCtxt *c[kMaxGateBatch] = {NULL};
 	if (n < 2 || n > kMaxGateBatch) misuse("Error: batch of scheduled gates out of range!");
 	for (int i = 0; i < n; ++i) { c[i] = &ct(subjects[i]); c[i]->stream_ = st; }
 	void *ptr[kMaxGateBatch];
+	if (kind == kBatchCopy) {                                    // out[i] = a copy of a[i] (CRT or NTT domain): one launch for the list
+		const void *ps[kMaxGateBatch];
+		CuCtxt &first = ct(op1[0]);
+		const int dom = first.domain_, dev = first.device_;
+		const size_t bytes = dom == 3 ? first.nRepSize() : first.cRepSize();
+		for (int i = 0; i < n; ++i) {
+			CuCtxt &src = ct(op1[i]);
+			c[i]->reset(); c[i]->stream_ = st;
+			c[i]->setLevelForOutput(src.level_, dom, dev, st);
+			c[i]->isProd_ = src.isProd_; c[i]->prodTerms_ = src.prodTerms_;
+			ptr[i] = dom == 3 ? (void *)c[i]->nRep_ : (void *)c[i]->cRep_;
+			ps[i] = dom == 3 ? (void *)src.nRep_ : (void *)src.cRep_;
+		}
+		CSC(cuhe_hip_copy_list(ptr, ps, n, bytes, dev, st));
+		return;
+	}
 	if (kind == kBatchAnd || kind == kBatchXor) {                // out[i] = a[i] (x) b[i]: one launch for the list
 		CuCtxt *a[kMaxGateBatch], *b[kMaxGateBatch];
 		const void *pa[kMaxGateBatch], *pb[kMaxGateBatch];
@@ -917,28 +953,26 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 	const size_t cBytes = cRows * sizeof(uint32), nBytes = nRows * sizeof(uint64);
 	const size_t cScratch = (size_t)cls * param.numCrtPrime * param.crtLen * sizeof(uint32), nScratch = (size_t)cls * param.numCrtPrime * cuhe_hip_ct_len() * sizeof(uint64);
 	if (kind == kBatchX2N) {                                     // c2n of every ciphertext: one transform call over n * np rows
-		uint32 *cin = (uint32 *)batchScratch(dev, cScratch);
-		uint64 *nout = (uint64 *)batchScratch(dev, nScratch);
+		uint32 *cin = (uint32 *)tlsBatchScratch.get(dev, 0, cScratch, st);
+		uint64 *nout = (uint64 *)tlsBatchScratch.get(dev, 1, nScratch, st);
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
 		CSC(cuhe_hip_gather_blocks(cin, ptr, n, cBytes, dev, st));
 		CSC(cuhe_hip_ntt_rows(U64P(nout), cin, n * np, dev, st));
 		for (int i = 0; i < n; ++i) { c[i]->nRepAlloc(st); ptr[i] = c[i]->nRep_; }
 		CSC(cuhe_hip_scatter_blocks(ptr, nout, n, nBytes, dev, st));
 		for (int i = 0; i < n; ++i) { c[i]->cRepFree(); c[i]->domain_ = 3; }
-		batchRelease(dev, cin, st); batchRelease(dev, nout, st);
 		return;
 	}
 	// the other three start from reduced CRT rows of every ciphertext in one array
-	uint32 *rows = (uint32 *)batchScratch(dev, cScratch);
+	uint32 *rows = (uint32 *)tlsBatchScratch.get(dev, 0, cScratch, st);
 	// (kernels that produce CRT rows write the modLen coefficients of the ring: on a ring shorter than the row the rest has to read as zero)
 	if (shortRing() && fromNtt) CSC(cuhe_hip_memset_async(dev, rows, 0, n * cBytes, st));
 	if (fromNtt) {                                               // n2c: inverse transform (+ reduction modulo the polynomial modulus for products)
-		uint64 *nin = (uint64 *)batchScratch(dev, nScratch);
+		uint64 *nin = (uint64 *)tlsBatchScratch.get(dev, 1, nScratch, st);
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->nRep_;
 		CSC(cuhe_hip_gather_blocks(nin, ptr, n, nBytes, dev, st));
 		if (prod) CSC(cuhe_hip_intt_mod_batch(rows, U64P(nin), lvl, n, dev, st));
 		else CSC(cuhe_hip_intt_batch(rows, U64P(nin), lvl, n, dev, st));
-		batchRelease(dev, nin, st);
 		for (int i = 0; i < n; ++i) { c[i]->cRepAlloc(st); c[i]->nRepFree(); c[i]->domain_ = 2; c[i]->isProd_ = false; c[i]->prodTerms_ = 0; }
 	} else {
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
@@ -950,7 +984,7 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		CSC(cuhe_hip_relin_batch(rows, rows, lvl, n, dev, st));
 		for (int i = 0; i < n; ++i) { c[i]->isProd_ = false; c[i]->prodTerms_ = 0; }
 	} else if (kind == kBatchModSwitch) {
-		next = (uint32 *)batchScratch(dev, cScratch);
+		next = (uint32 *)tlsBatchScratch.get(dev, 2, cScratch, st);
 		if (shortRing()) CSC(cuhe_hip_memset_async(dev, next, 0, n * cBytes, st));
 		CSC(cuhe_hip_crt_mod_switch_batch(next, rows, lvl, n, dev, st));
 		result = next; outBytes = (size_t)(np - 1) * param.crtLen * sizeof(uint32);
@@ -960,8 +994,6 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
 		CSC(cuhe_hip_scatter_blocks(ptr, result, n, outBytes, dev, st));
 	}
-	batchRelease(dev, rows, st);
-	if (next) batchRelease(dev, next, st);
 }
 static void runBatchedGates(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int count, void *stream) {
 	SchedAccess::runBatch(kind, subjects, op1, op2, count, stream);

@@ -253,6 +253,8 @@ int cuhe_hip_scatter_blocks(void *const *dsts, const void *src, int count, size_
    x + y modulo P (cAnd / cXor in the NTT domain), CRT rows z = (a + b) mod p (cXor in the CRT domain); lists in host memory */
 int cuhe_hip_ct_binop_list(int mul, void *const *z, const void *const *x, const void *const *y, int count, int logq, int dev, void *stream);
 int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *const *b, int count, int logq, int dev, void *stream);
+/* dst[i] = src[i] for `count` separately owned blocks of `bytes` bytes (a multiple of 16): copy() over a list, one launch per 32 */
+int cuhe_hip_copy_list(void *const *dst, const void *const *src, int count, size_t bytes, int dev, void *stream);
 /* n2c of `batch` NON-product ciphertexts of one level in one array (intt_mod_batch is the form for products) */
 int cuhe_hip_intt_batch(uint32_t *dst_crt, const uint64_t *src_ntt, int lvl, int batch, int dev, void *stream);
 /* cAnd over index pairs: dst[t] = src[idx_a[t]] * src[idx_b[t]], ciphertexts of np_rows rows */
