@@ -59,6 +59,7 @@ SIGNATURES = {
     "cuhe_hip_free": (i32, [i32, vp]),
     "cuhe_hip_set_alloc_cache": (i32, [sz]),
     "cuhe_hip_alloc_counters": (i32, [vp]),
+    "cuhe_hip_generation": (u64, []),
     "cuhe_hip_malloc_stream": (vp, [i32, sz, vp]),
     "cuhe_hip_free_stream": (i32, [i32, vp, vp]),
     "cuhe_hip_host_alloc": (vp, [sz]),

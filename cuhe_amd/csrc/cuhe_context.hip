@@ -362,6 +362,8 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
 }
 
 int cuhe_hip_is_initialised(void) { return G_.inited ? 1 : 0; }
+// bumped by every cuhe_hip_shutdown: device blocks handed out before it are gone (callers that keep blocks across calls compare it)
+unsigned long long cuhe_hip_generation(void) { return (unsigned long long)G_.generation; }
 int cuhe_hip_shutdown(void) {
     std::lock_guard<std::mutex> lk(G_.mu);
     for (int d = 0; d < (int)G_.dev.size(); ++d) {

@@ -892,7 +892,9 @@ void cAndRelinSharded(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 struct BatchScratch {
 	struct Buf { void *p = NULL; size_t cap = 0; };
 	std::vector<std::vector<Buf>> perDev;
+	unsigned long long generation = 0;
 	void *get(int dev, int slot, size_t bytes, void *st) {
+		if (generation != cuhe_hip_generation()) { perDev.clear(); generation = cuhe_hip_generation(); }     // the library was shut down since: its blocks went with it
 		if ((int)perDev.size() <= dev) perDev.resize(dev + 1, std::vector<Buf>(3));
 		Buf &b = perDev[dev][slot];
 		if (b.cap < bytes) {
@@ -904,7 +906,10 @@ struct BatchScratch {
 		}
 		return b.p;
 	}
-	~BatchScratch() { for (size_t d = 0; d < perDev.size(); ++d) for (Buf &b : perDev[d]) if (b.p && cuhe_hip_is_initialised()) cuhe_hip_free((int)d, b.p); }
+	~BatchScratch() {
+		if (generation != cuhe_hip_generation() || !cuhe_hip_is_initialised()) return;
+		for (size_t d = 0; d < perDev.size(); ++d) for (Buf &b : perDev[d]) if (b.p) cuhe_hip_free((int)d, b.p);
+	}
 };
 static thread_local BatchScratch tlsBatchScratch;
 void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int n, void *st) {

@@ -122,8 +122,14 @@ std::mutex cacheMu;
 std::vector<std::unordered_map<size_t, std::deque<Block>>> cache;       // per device, by size
 std::unordered_map<void *, size_t> cacheSize;                           // blocks handed out by taskAlloc
 long cacheHits = 0, cacheForeign = 0, cacheMisses = 0;
+unsigned long long cacheGeneration = 0;    // cuhe_hip_generation() the cached blocks belong to
+void cacheCheckGeneration() {              // cacheMu held: a cuhe_hip_shutdown since took every block with it
+	const unsigned long long g = cuhe_hip_generation();
+	if (g != cacheGeneration) { cache.clear(); cacheSize.clear(); cacheGeneration = g; }
+}
 void flushCache() {                        // the device has been synchronised: everything goes back to the library's pool
 	std::lock_guard<std::mutex> lk(cacheMu);
+	cacheCheckGeneration();
 	for (size_t d = 0; d < cache.size(); ++d)
 		for (auto &bySize : cache[d])
 			for (Block &b : bySize.second) { cacheSize.erase(b.ptr); CSC(cuhe_hip_free((int)d, b.ptr)); }
@@ -163,19 +169,36 @@ void makeReady(Task *t, int me, Task **next) {
 	if (me >= 0 && stealing) local[me].push_back(t); else ready.push_back(t);
 	cvReady.notify_one();
 }
+// streams of workers that have gone (setScheduled(false) ; setScheduled(true) cycles): a stream costs ~10 ms to create, and issued
+// tasks keep pointing at their StreamState, so the states are never destroyed -- the next workers take them over
+std::mutex idleMu;
+std::vector<std::vector<StreamState *>> idleStreams;     // per device
 StreamState *streamOf(int dev) {
 	if ((int)tlsStreams.size() <= dev) tlsStreams.resize(dev + 1, nullptr);
 	if (!tlsStreams[dev]) {
-		StreamState *ns = new StreamState;
-		ns->dev = dev;
-		CSC(cuhe_hip_stream_create(dev, &ns->stream));
-		CSC(cuhe_hip_event_create(dev, &ns->event));
+		StreamState *ns = nullptr;
+		{
+			std::lock_guard<std::mutex> lk(idleMu);
+			if ((int)idleStreams.size() > dev && !idleStreams[dev].empty()) { ns = idleStreams[dev].back(); idleStreams[dev].pop_back(); }
+		}
+		if (!ns) {
+			ns = new StreamState;
+			ns->dev = dev;
+			CSC(cuhe_hip_stream_create(dev, &ns->stream));
+			CSC(cuhe_hip_event_create(dev, &ns->event));
+		}
 		tlsStreams[dev] = ns;
 	}
 	return tlsStreams[dev];
 }
+struct ReturnStreams { ~ReturnStreams() {                 // at worker exit
+	std::lock_guard<std::mutex> lk(idleMu);
+	for (size_t d = 0; d < tlsStreams.size(); ++d) if (tlsStreams[d]) { if (idleStreams.size() <= d) idleStreams.resize(d + 1); idleStreams[d].push_back(tlsStreams[d]); }
+	tlsStreams.clear();
+} };
 void workerMain(int me) {
 	tlsWorker = true;
+	ReturnStreams giveBack;
 	// a stream costs ~10 ms to create: before the first task, not inside it
 	if (cuhe_hip_is_initialised()) for (int d = 0; d < cuhe_hip_num_gpus(); ++d) streamOf(d);
 	std::unique_lock<std::mutex> lk(mu);
@@ -297,6 +320,7 @@ void *taskAlloc(int dev, size_t bytes) {
 	Block b{nullptr, nullptr, 0};
 	{
 		std::lock_guard<std::mutex> lk(cacheMu);
+		cacheCheckGeneration();
 		if ((int)cache.size() <= dev) cache.resize(dev + 1);
 		auto it = cache[dev].find(bytes);
 		if (it != cache[dev].end() && !it->second.empty()) {
@@ -324,6 +348,7 @@ void forgetBlock(void *p) {                // released outside a task (the clien
 bool taskFree(int dev, void *p) {
 	StreamState *me = (int)tlsStreams.size() > dev ? tlsStreams[dev] : nullptr;
 	std::lock_guard<std::mutex> lk(cacheMu);
+	cacheCheckGeneration();
 	auto it = cacheSize.find(p);
 	if (it == cacheSize.end() || !me) return false;                 // not one of ours (allocated before the object was attached)
 	if ((int)cache.size() <= dev) cache.resize(dev + 1);

@@ -100,6 +100,8 @@ int cuhe_hip_set_alloc_cache(size_t bytes);
 /* diagnostics: out4 = { hipMalloc calls, allocations served from the settled pool, from the caller stream's parked blocks,
    blocks handed over from another stream's parked set behind an event } since the library was loaded */
 int cuhe_hip_alloc_counters(long long *out4);
+/* counts the cuhe_hip_shutdown calls so far: every device block the library handed out before a shutdown is gone with it */
+unsigned long long cuhe_hip_generation(void);
 /* stream-ordered variants: a block freed with free_stream is reused only by malloc_stream calls for the same stream
    until cuhe_hip_stream_sync(stream) has returned; callers can then enqueue chains of operations without a host
    synchronisation between them */
