@@ -1208,3 +1208,99 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
         ck(lib.cuhe_hip_set_onewg(1, 2))
         if o is not None:
             o.close()
+
+
+@pytest.mark.parametrize("name", ["toy1155", "pow2_32768"])
+def test_list_block_and_event_entry_points(gu, name):
+    """The round-4 additions to the C ABI that the C++ layer's gate scheduler is built on, each against the entry point it
+    generalises: gather / scatter / copy of separately owned blocks through pointer lists, cAnd / cXor over lists
+    (cuhe_hip_ct_binop_list, cuhe_hip_crt_add_list) against cuhe_hip_ct_mul / ct_add / crt_add per ciphertext, the array form of
+    n2c for non-products (cuhe_hip_intt_batch) against cuhe_hip_ct_intt, the event calls, and the diagnostics
+    (allocator counters, generation, transform scratch, dispatch info).  A cyclic and a negacyclic ring; 37 ciphertexts (two launches of the list kernels)."""
+    import ctypes as C
+    lib, ck = gu.lib, gu.ck
+    g = gu.GpuCtx(*PSETS[name])
+    try:
+        q = g.prm
+        lvl, n = 1, 37
+        npr, logq, ctlen = g.np_(lvl), g.logq(lvl), g.ctlen
+        rng = np.random.default_rng(77)
+        crt = [np.zeros((npr, q.crtLen), dtype=np.uint32) for _ in range(2 * n)]
+        for a in crt:
+            for t in range(npr):
+                a[t, :q.modLen] = rng.integers(0, g.primes[t], q.modLen, dtype=np.uint32)
+        dcrt = [gu.to_dev(a) for a in crt]
+        dntt = [gu.empty_u64(npr, ctlen) for _ in range(2 * n)]
+        for x, X in zip(dcrt, dntt):
+            ck(lib.cuhe_hip_ct_ntt(X.data_ptr(), x.data_ptr(), logq, 0, None))
+        plist = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        # ---- gather / scatter / copy of blocks
+        cbytes = npr * q.crtLen * 4
+        arr = gu.empty_u32(n, npr, q.crtLen)
+        ck(lib.cuhe_hip_gather_blocks(arr.data_ptr(), plist(dcrt[:n]), n, cbytes, 0, None))
+        assert np.array_equal(gu.host_u32(arr), np.stack(crt[:n]))
+        outs = [gu.empty_u32(npr, q.crtLen) for _ in range(n)]
+        ck(lib.cuhe_hip_scatter_blocks(plist(outs), arr.data_ptr(), n, cbytes, 0, None))
+        assert all(np.array_equal(gu.host_u32(o), c) for o, c in zip(outs, crt[:n]))
+        outs2 = [gu.empty_u32(npr, q.crtLen) for _ in range(n)]
+        ck(lib.cuhe_hip_copy_list(plist(outs2), plist(dcrt[n:]), n, cbytes, 0, None))
+        assert all(np.array_equal(gu.host_u32(o), c) for o, c in zip(outs2, crt[n:]))
+        assert lib.cuhe_hip_gather_blocks(arr.data_ptr(), plist(dcrt[:n]), n, cbytes + 4, 0, None) != 0      # not a multiple of 16
+        # ---- cAnd / cXor over lists against the single-ciphertext entry points
+        for mul, single in ((1, lib.cuhe_hip_ct_mul), (0, lib.cuhe_hip_ct_add)):
+            z = [gu.empty_u64(npr, ctlen) for _ in range(n)]
+            ck(lib.cuhe_hip_ct_binop_list(mul, plist(z), plist(dntt[:n]), plist(dntt[n:]), n, logq, 0, None))
+            want = gu.empty_u64(npr, ctlen)
+            for i in (0, 17, 31, 32, 36):
+                ck(single(want.data_ptr(), dntt[i].data_ptr(), dntt[n + i].data_ptr(), logq, 0, None))
+                assert np.array_equal(gu.host_u64(z[i]), gu.host_u64(want)), (mul, i)
+        zc = [gu.empty_u32(npr, q.crtLen) for _ in range(n)]
+        ck(lib.cuhe_hip_crt_add_list(plist(zc), plist(dcrt[:n]), plist(dcrt[n:]), n, logq, 0, None))
+        wantc = gu.empty_u32(npr, q.crtLen)
+        for i in (0, 31, 32, 36):
+            ck(lib.cuhe_hip_crt_add(wantc.data_ptr(), dcrt[i].data_ptr(), dcrt[n + i].data_ptr(), logq, 0, None))
+            assert np.array_equal(gu.host_u32(zc[i]), gu.host_u32(wantc)), i
+        # in place (out = first operand), as cXor(out, out, term) records it
+        ck(lib.cuhe_hip_crt_add_list(plist(zc), plist(zc), plist(dcrt[n:]), n, logq, 0, None))
+        ck(lib.cuhe_hip_crt_add(wantc.data_ptr(), wantc.data_ptr(), dcrt[n + 36].data_ptr(), logq, 0, None))
+        assert np.array_equal(gu.host_u32(zc[36]), gu.host_u32(wantc))
+        # ---- n2c of non-products over an array
+        nbytes = npr * ctlen * 8
+        narr = gu.empty_u64(n, npr, ctlen)
+        ck(lib.cuhe_hip_gather_blocks(narr.data_ptr(), plist(dntt[:n]), n, nbytes, 0, None))
+        back = gu.empty_u32(n, npr, q.crtLen)
+        ck(lib.cuhe_hip_intt_batch(back.data_ptr(), narr.data_ptr(), lvl, n, 0, None))
+        got = gu.host_u32(back)
+        for i in range(n):
+            assert np.array_equal(got[i][:, :q.modLen], crt[i][:, :q.modLen]), i          # the transform round trip, every ciphertext
+        # ---- events: a second stream waits for the first
+        s1, s2, ev = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ck(lib.cuhe_hip_stream_create(0, C.byref(s1))); ck(lib.cuhe_hip_stream_create(0, C.byref(s2))); ck(lib.cuhe_hip_event_create(0, C.byref(ev)))
+        a1, a2 = gu.empty_u64(npr, ctlen), gu.empty_u64(npr, ctlen)
+        ck(lib.cuhe_hip_ct_mul(a1.data_ptr(), dntt[0].data_ptr(), dntt[1].data_ptr(), logq, 0, s1))
+        ck(lib.cuhe_hip_event_record(0, ev, s1))
+        ck(lib.cuhe_hip_stream_wait_event(0, s2, ev))
+        ck(lib.cuhe_hip_ct_add(a2.data_ptr(), a1.data_ptr(), dntt[2].data_ptr(), logq, 0, s2))
+        ck(lib.cuhe_hip_stream_sync(0, s2))
+        ck(lib.cuhe_hip_event_sync(0, ev))
+        assert lib.cuhe_hip_event_query(0, ev) == 0
+        w = gu.empty_u64(npr, ctlen)
+        ck(lib.cuhe_hip_ct_mul(w.data_ptr(), dntt[0].data_ptr(), dntt[1].data_ptr(), logq, 0, None))
+        ck(lib.cuhe_hip_ct_add(w.data_ptr(), w.data_ptr(), dntt[2].data_ptr(), logq, 0, None))
+        assert np.array_equal(gu.host_u64(a2), gu.host_u64(w))
+        ck(lib.cuhe_hip_event_destroy(0, ev)); ck(lib.cuhe_hip_stream_destroy(0, s1)); ck(lib.cuhe_hip_stream_destroy(0, s2))
+        # ---- diagnostics
+        cnt = (C.c_longlong * 4)()
+        ck(lib.cuhe_hip_alloc_counters(cnt))
+        assert cnt[0] >= 0 and cnt[1] >= 0
+        gen0 = lib.cuhe_hip_generation()
+        info = C.create_string_buffer(256)
+        ck(lib.cuhe_hip_last_dispatch_info(0, info, 256))
+        assert b"rows of" in info.value
+        assert lib.cuhe_hip_ntt_swap(0)
+        cinfo = C.create_string_buffer(512)
+        ck(lib.cuhe_hip_comm_info(cinfo, 512))
+        assert b"rccl" in cinfo.value.lower()
+    finally:
+        g.close()
+    assert lib.cuhe_hip_generation() == gen0 + 1                  # close() shut the library down
