@@ -708,13 +708,16 @@ static void prepareOut(CuCtxt &out, CuCtxt &like, int domain, cudaStream_t st) {
 	if (&out != &like) { out.reset(); out.setLevelForOutput(like.level(), domain, like.device(), st); }
 }
 void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
+	// the result may be either operand: the reference resets `out` whenever it is not the FIRST one (cuhe/CuHE.cu:108-111), which
+	// loses an `out` that is the second; products and sums commute, so that call is taken with its operands exchanged
+	if (&out == &in1 && &out != &in0) { cAnd(out, in1, in0, st); return; }
 	if (in0.device() != in1.device()) misuse("Error: Multiplication of different devices!");
 	if (in0.domain() != 3 || in1.domain() != 3) misuse("Error: Multiplication of non-NTT domain!");
 	if (in0.logq() != in1.logq()) misuse("Error: Multiplication of different levels!");
 	if (recordGate(out, in0, in1)) {
 		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
 		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cAnd(OBJ(no), OBJ(n0), OBJ(n1), s); },
-		              false, &out != &in1 ? kBatchAnd : 0, batchKey(in0.level(), 3, false), no, n0, n1);
+		              false, kBatchAnd, batchKey(in0.level(), 3, false), no, n0, n1);
 		if (&out != &in0) SchedAccess::shapeLike(out, in0, 3);
 		SchedAccess::setProd(out, true, 1);
 		return;
@@ -742,6 +745,7 @@ void cAnd(CuCtxt &out, CuCtxt &inc, CuPtxt &inp, cudaStream_t st) {
 	GATE_SYNC(out.device(), st);
 }
 void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
+	if (&out == &in1 && &out != &in0) { cXor(out, in1, in0, st); return; }        // (see cAnd)
 	if (in0.device() != in1.device()) misuse("Error: Addition of different devices!");
 	if (recordGate(out, in0, in1)) {
 		if (in0.logq() != in1.logq()) misuse("Error: Addition of different levels!");
@@ -750,9 +754,9 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 		sched::Node *n0 = in0.schedAttach(), *n1 = in1.schedAttach(), *no = out.schedAttach();
 		const int terms = in0.prodTerms() + in1.prodTerms();
 		const bool prod = in0.isProd() || in1.isProd(), reduced = dom == 3 && in0.isProd() && in1.isProd() && terms > cuhe_hip_ct_prod_headroom();
-		// (a sum that has to reduce its operands first is a chain of gates: not batched; nor is an `out` that is the second operand)
+		// (a sum that has to reduce its operands first is a chain of gates: not batched)
 		sched::submit(in0.device(), Nodes{n0, n1}, Nodes(1, no), [n0, n1, no](void *s) { SchedAccess::stream(*no->obj) = s; cXor(OBJ(no), OBJ(n0), OBJ(n1), s); },
-		              false, (!reduced && &out != &in1) ? kBatchXor : 0, batchKey(in0.level(), dom, false), no, n0, n1);
+		              false, !reduced ? kBatchXor : 0, batchKey(in0.level(), dom, false), no, n0, n1);
 		// the mirror of what the gate below leaves in `out`
 		if (&out != &in0) SchedAccess::shapeLike(out, in0, dom);
 		if (dom == 3) SchedAccess::setProd(out, !reduced && prod, !reduced && prod ? (terms > 0 ? terms : 1) : 0);

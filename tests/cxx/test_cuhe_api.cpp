@@ -322,6 +322,23 @@ int main() {
 			w.x2z();
 			CHECK(w.zRep() == reduceCoeffs(aa + aa + aa + one, q2[0], n2), "array round trip, then a third product: exact");
 		}
+		{
+			// the result may be the SECOND operand (the reference resets it before reading it: cuhe/CuHE.cu:108-111,141-145)
+			ZZX ra2 = randomPoly(n2, q2[0]), rb2 = randomPoly(n2, q2[0]);
+			CuCtxt x, y;
+			x.setLevel(0, 0, ra2); y.setLevel(0, 0, rb2); x.x2n(); y.x2n();
+			cXor(y, x, y);
+			CuCtxt t; copy(t, y); t.x2z();
+			CHECK(t.zRep() == reduceCoeffs(ra2 + rb2, q2[0], n2), "cXor(out = second operand) in the NTT domain");
+			y.x2c(); x.x2c();
+			cXor(y, x, y);
+			copy(t, y); t.x2z();
+			CHECK(t.zRep() == reduceCoeffs(ra2 + ra2 + rb2, q2[0], n2), "cXor(out = second operand) in the CRT domain");
+			x.x2n(); y.x2n();
+			cAnd(y, x, y);
+			y.x2z();
+			CHECK(y.zRep() == hostMul(ra2, reduceCoeffs(ra2 + ra2 + rb2, q2[0], n2), xn1, q2[0], n2), "cAnd(out = second operand)");
+		}
 		ZZX ra = randomPoly(n2, q2[0]), rb = randomPoly(n2, q2[0]);
 		CuCtxt cra, crb, s2;
 		cra.setLevel(0, 0, ra); crb.setLevel(0, 0, rb); cra.x2n(); crb.x2n();
