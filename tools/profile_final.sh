@@ -4,7 +4,7 @@
 # HBM counters of the batched multiply + relinearise call.  Text summaries land in gpurun_out/final/;
 # tools/make_traffic_json.py turns the PMC passes into profiles/traffic_rNN.json (bytes and VALU lane-instructions per
 # transform, tagged with the hash of the kernel sources bench.py checks).  Every step runs under its own timeout.
-# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r02]
+# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r04]
 export TMPDIR=/tmp
 tag=${2:-r04}
 out=$PWD/gpurun_out/final; mkdir -p $out
@@ -36,6 +36,7 @@ done
 cd $R
 python tools/make_traffic_json.py $out $tag > $out/traffic_$tag.json && cat $out/traffic_$tag.json
 # the one-workgroup transforms against the two-pass kernels (equality + timing), and the table of doc/Perf_NTT.txt
+[ -x $R/cuhe_amd/lib/ow_ab ] || hipcc -O2 $R/tools/ow_ab.cpp -I$R/include -L$R/cuhe_amd/lib -lcuhe_hip -Wl,-rpath,$R/cuhe_amd/lib -o $R/cuhe_amd/lib/ow_ab
 timeout 300 $R/cuhe_amd/lib/ow_ab 4096 10 > $out/onewg_ab.txt 2>&1; grep -v mismatch $out/onewg_ab.txt; grep -c identical $out/onewg_ab.txt
 timeout 300 python bench.py --perf-table $out/perf_ntt_table.txt > /dev/null 2>&1; tail -11 $out/perf_ntt_table.txt
 head -14 $out/kernel_trace_stats.txt | cut -c1-72,110-200
