@@ -21,14 +21,15 @@ LIB = os.path.join(LIBDIR, "libcuhe_hip.so")
 UNITS = [("cuhe_context", "cuhe_context.hip", []),
          ("cuhe_transforms", "cuhe_transforms.hip", []),
          ("cuhe_keyswitch", "cuhe_keyswitch.hip", []),
+         ("icrt_mfma", "icrt_mfma.hip", []),
          ("ntt_onewg_12", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=12"]),
          ("ntt_onewg_13", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=13"]),
          ("ntt_onewg_14", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=14"]),
          ("ntt_onewg_15", "ntt_onewg_inst.hip", ["-DCUHE_OW_LGH=15"])]
 COMMON = ["ntt_kernels.cuh", "modp.cuh", os.path.join("..", "..", "include", "cuhe_hip.h")]
-ABI = ["cuhe_internal.hpp", "ops_kernels.cuh", "host_math.hpp", "comm.hpp", "ntt_onewg.hpp"] + COMMON
+ABI = ["cuhe_internal.hpp", "ops_kernels.cuh", "icrt_mfma.cuh", "host_math.hpp", "comm.hpp", "ntt_onewg.hpp"] + COMMON
 DEPS = {"cuhe_context.hip": ["cuhe_context.hip"] + ABI, "cuhe_transforms.hip": ["cuhe_transforms.hip"] + ABI,
-        "cuhe_keyswitch.hip": ["cuhe_keyswitch.hip"] + ABI,
+        "cuhe_keyswitch.hip": ["cuhe_keyswitch.hip"] + ABI, "icrt_mfma.hip": ["icrt_mfma.hip"] + ABI,
         "ntt_onewg_inst.hip": ["ntt_onewg_inst.hip", "ntt_onewg.cuh", "ntt_onewg.hpp"] + COMMON}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-command-line-argument"]

@@ -190,6 +190,49 @@ int init_device(int dev) {
             hrp[i] = 1.0 / (double)hp[i];
         }
         CHK(upload(&I.M, hM)); CHK(upload(&I.mi, hmi)); CHK(upload(&I.bi, hbi)); CHK(upload(&I.rp, hrp));
+        // the same constants for the matrix-core form (icrt_mfma.cuh): signed base-256 digits of 128^a (M / p_i), laid out as
+        // the first operand of v_mfma_i32_32x32x32_i8 reads them; per-prime constants by K step; NM = 2^(32 NW) - M
+        uint32_t pmax = 0;
+        for (int i = 0; i < I.np; ++i) pmax = std::max(pmax, hp[i]);
+        I.tiles = (I.W + 1 + 7) / 8; I.ksteps = (I.np + 7) / 8;
+        if (pmax < (1u << 28) && I.np <= 128) {
+            const int NW = 8 * I.tiles, WH = 4 * I.tiles, ND = 4 * NW, ks = I.ksteps;
+            std::vector<signed char> dg((size_t)ks * 8 * 4 * ND, 0);                 // [prime][a][digit]
+            std::vector<u32> cw(NW + 1);
+            for (int i = 0; i < I.np; ++i)
+                for (int a = 0; a < 4; ++a) {
+                    std::fill(cw.begin(), cw.end(), 0u);
+                    for (int k = 0; k < I.W; ++k) {
+                        const u64 v = (u64)hmi[(size_t)i * W4 + k] << (7 * a);
+                        cw[k] |= (u32)v; cw[k + 1] |= (u32)(v >> 32);
+                    }
+                    int carry = 0;
+                    signed char *o = &dg[((size_t)i * 4 + a) * ND];
+                    for (int d = 0; d < ND; ++d) {
+                        const int v = (int)((cw[d >> 2] >> (8 * (d & 3))) & 0xff) + carry;
+                        carry = v >= 128;
+                        o[d] = (signed char)(carry ? v - 256 : v);
+                    }
+                    if (carry) return fail(CUHE_EINVAL, "ICRT digit table: value does not fit %d words", NW);
+                }
+            std::vector<unsigned char> tab((size_t)I.tiles * ks * 1024, 0);
+            for (int m = 0; m < I.tiles; ++m)
+                for (int s = 0; s < ks; ++s)
+                    for (int l = 0; l < 64; ++l) {
+                        const int rho = l & 31, hk = l >> 5, d = 4 * (((rho >> 2) & 1) * WH + 4 * m + (rho >> 3)) + (rho & 3);
+                        for (int e = 0; e < 4; ++e)
+                            for (int a = 0; a < 4; ++a)
+                                tab[(((size_t)m * ks + s) * 64 + l) * 16 + e * 4 + a] = (unsigned char)dg[((size_t)(8 * s + 4 * hk + e) * 4 + a) * ND + d];
+                    }
+            std::vector<IcrtPrimeConst> hpc((size_t)ks * 8);
+            for (int i = 0; i < ks * 8; ++i)
+                hpc[i] = i < I.np ? IcrtPrimeConst{hp[i], hbi[i], (u32)(((u64)hbi[i] << 32) / hp[i]), 0u, hrp[i], 0}
+                                  : IcrtPrimeConst{hp[0], 0u, 0u, 0u, 0.0, 0};
+            std::vector<u32> hnm(NW);
+            u64 c = 1;
+            for (int k = 0; k < NW; ++k) { c += (u64)(u32)~(k < I.W ? hM[k] : 0u); hnm[k] = (u32)c; c >>= 32; }
+            CHK(upload(&I.dig, tab)); CHK(upload(&I.pc, hpc)); CHK(upload(&I.nm, hnm));
+        }
     }
     // ---- transforms + scratch (initNtt: cuhe/Operations.cu:173-184)
     CHK(ensure_ntt(dev, L, pnum));
@@ -377,7 +420,7 @@ int cuhe_hip_shutdown(void) {
         for (auto &t : D.ow) { hipFree(t.TW1f); hipFree(t.TW1i); hipFree(t.TW1h); hipFree(t.TW2); hipFree(t.TW1g); hipFree(t.TW1hi); }
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);
-        for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); }
+        for (auto &I : D.icrt) { hipFree(I.M); hipFree(I.mi); hipFree(I.bi); hipFree(I.rp); hipFree(I.dig); hipFree(I.pc); hipFree(I.nm); }
         for (auto &kv : D.freeBlocks) hipFree(kv.second);
         for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) hipFree(kv.second);     // parked in stream order
         for (auto &kv : D.allocated) hipFree(kv.first);

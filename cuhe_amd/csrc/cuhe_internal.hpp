@@ -24,6 +24,7 @@
 #include "ntt_kernels.cuh"
 #include "ntt_onewg.hpp"
 #include "ops_kernels.cuh"
+#include "icrt_mfma.cuh"
 
 namespace cuhe_impl {
 using namespace cuhe;
@@ -79,7 +80,11 @@ struct Workspace {
     // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
     hipStream_t lane_stream = nullptr; hipEvent_t ev_lane = nullptr, ev_in = nullptr;
 };
-struct IcrtLevel { u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0; };
+struct IcrtLevel {
+    u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0;
+    // the constants in the layout of the matrix-core form (icrt_mfma.cuh); dig == nullptr: that form does not apply (primes of 2^28 and more)
+    unsigned char *dig = nullptr; IcrtPrimeConst *pc = nullptr; u32 *nm = nullptr; int tiles = 0, ksteps = 0;
+};
 
 // tables of the one-workgroup transforms (ntt_onewg.cuh) of Lh = 2^(13 + index) points
 struct OwTab {
@@ -228,6 +233,10 @@ int upload(T **dptr, const std::vector<T> &h) {
     return CUHE_OK;
 }
 
+// ---- matrix-core inverse CRT (icrt_mfma.hip)
+bool icrt_mfma_supported(const IcrtLevel &I);
+int launch_icrt_mfma(u32 *dst, const u32 *src, const DevCtx &D, const IcrtLevel &I, int np, int W, int batch, long src_ct_stride, long dst_ct_stride,
+                     hipStream_t st, const IcrtWindows &wo);
 // ---- transforms (cuhe_transforms.hip)
 int ensure_ntt(int dev, int len, int batch_hint);
 int ensure_twist(int dev, int len);

@@ -8,6 +8,8 @@
 namespace cuhe_impl {
 
 int g_icrt_acc64 = getenv("CUHE_ICRT_ACC64") ? atoi(getenv("CUHE_ICRT_ACC64")) : 1;      // (environment override: A/B runs)
+// the column sums of the ICRT on the matrix cores (icrt_mfma.cuh) wherever that form applies; 0: the VALU kernel k_icrt
+int g_icrt_mfma = getenv("CUHE_ICRT_MFMA") ? atoi(getenv("CUHE_ICRT_MFMA")) : 1;
 int icrt_lds_attr(size_t lds) {                 // k_icrt needs the large-LDS attribute for many primes
     static AttrOnce once;
     if (lds <= 64 * 1024) return CUHE_OK;
@@ -23,6 +25,8 @@ int launch_icrt(u32 *dst, const u32 *src, const DevCtx &D, int lvl, int np, int 
     const IcrtLevel &I = D.icrt[lvl];
     IcrtTab it{I.M, I.mi, I.bi, I.rp};
     const dim3 grid((q.modLen + kIcrtCoef - 1) / kIcrtCoef, batch), block(kIcrtCoef * kIcrtGroups);
+    if (g_icrt_mfma && icrt_mfma_supported(I) && np == I.np && W == I.W)
+        return launch_icrt_mfma(dst, src, D, I, np, W, batch, src_ct_stride, dst_ct_stride, st, wo);
     const size_t lds = icrt_lds_bytes(np, W);
     CHK(icrt_lds_attr(lds));
     // 64-bit column sums where they cannot overflow (see icrt_mac4_64): sum_i t_i m_i[k] + q M[k] < np pmax 2^32 + np 2^32 with
@@ -377,6 +381,11 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 // measured crossover at config 4: 2 and 4 ciphertexts are a little faster on the VALU kernel (0.190 / 0.127 vs 0.197 / 0.134 ms per
 // ciphertext), 6 already on the matrix cores (0.110 vs 0.141: one half-filled tile instead of two VALU groups)
 static int g_mac_mfma_min = getenv("CUHE_MAC_MFMA_MIN") ? atoi(getenv("CUHE_MAC_MFMA_MIN")) : 5;     // smallest batch that takes the MFMA kernel; 0 = never
+int cuhe_hip_set_icrt_mfma(int on) {
+    if (on != 0 && on != 1) return fail(CUHE_EINVAL, "on %d", on);
+    g_icrt_mfma = on;
+    return CUHE_OK;
+}
 int cuhe_hip_set_relin_mfma(int min_batch) {
     if (min_batch < 0) return fail(CUHE_EINVAL, "min_batch %d", min_batch);
     g_mac_mfma_min = min_batch;

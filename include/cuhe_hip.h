@@ -235,6 +235,11 @@ int cuhe_hip_set_relin_lanes(int n);
    large as the keys) are laid out on the first such call; a device without room for them keeps the VALU kernel.
    Default 5 (the measured crossover); 0 = never (the VALU kernel). */
 int cuhe_hip_set_relin_mfma(int min_batch);
+/* The inverse CRT (cuhe_hip_icrt and every chain that contains it; cuhe/Base.cu:884-960) forms its column sums
+   sum_i t_i (M / p_i) on the matrix cores (base-128 digits of t_i against signed base-256 digits of the constants,
+   v_mfma_i32_32x32x32_i8, exact) for parameter sets with primes below 2^28 and at most 47 words per coefficient; others
+   keep the VALU kernel.  on = 1 (default) / 0 = the VALU kernel everywhere.  Results do not depend on the setting. */
+int cuhe_hip_set_icrt_mfma(int on);
 /* `batch` independent full multiplications raw -> raw of one level in one call (mulZZX without the host staging,
    CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the
    single sequence crt, crt, ntt, ntt, ntt_mul, intt_mod, icrt */

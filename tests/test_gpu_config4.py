@@ -97,8 +97,14 @@ def test_batched_key_switch_21_distinct_ciphertexts_vs_integers(gu, ring):
             ck(lib.cuhe_hip_relin_batch(d_dst2.data_ptr(), d_src.data_ptr(), lvl, B, 0, None))
             assert np.array_equal(gu.host_u32(d_dst2).reshape(B, npr, q.crtLen), got), (ring, lvl)
             ck(lib.cuhe_hip_set_relin_mfma(5))
+            # and with the inverse CRT on the VALU kernel instead of the matrix cores (cuhe_hip_set_icrt_mfma): bit-identical
+            ck(lib.cuhe_hip_set_icrt_mfma(0))
+            ck(lib.cuhe_hip_relin_batch(d_dst2.data_ptr(), d_src.data_ptr(), lvl, B, 0, None))
+            assert np.array_equal(gu.host_u32(d_dst2).reshape(B, npr, q.crtLen), got), (ring, lvl)
+            ck(lib.cuhe_hip_set_icrt_mfma(1))
     finally:
         lib.cuhe_hip_set_relin_mfma(5)
+        lib.cuhe_hip_set_icrt_mfma(1)
         g.close()
 
 

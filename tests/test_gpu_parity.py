@@ -167,6 +167,39 @@ def test_crt_icrt(ctxpair):
         assert np.array_equal(g.icrt(g.crt(raw, lvl), lvl), raw)
 
 
+def test_icrt_matrix_core_form_equals_valu_form_and_oracle(ctxpair, gu):
+    """cuhe_hip_set_icrt_mfma: the column sums on the matrix cores (icrt_mfma.cuh) against the VALU kernel and the oracle, at
+    EVERY level: reduced rows of edge values (0, small, M - small, multiples of M / np: quotient estimates next to an integer)
+    and unreduced rows (x_i up to 2^32 - 1)."""
+    import oracle_lib as O
+    name, g, o = ctxpair
+    q = o.prm
+    try:
+        for lvl in range(q.depth):
+            W, M, npl = o.words(lvl), o.coeff_modulus(lvl), o.np_(lvl)
+            raw, vals = O.random_raw(q.rawLen, q.modLen, W, M, 177 + lvl)
+            edge = [0, 1, 2, M - 1, M - 2, M // 2, M // 2 + 1] + [k * M // npl + e for k in range(1, min(npl, 6)) for e in (-1, 0, 1)]
+            for i, v in enumerate(edge[:q.modLen]):
+                vals[i] = v % M
+            raw = O.ints_to_raw(vals, q.rawLen, W)
+            rows = o.crt(raw, lvl)
+            rng = np.random.default_rng(500 + lvl)
+            wild = rows.copy()
+            wild[:, :q.modLen] = rng.integers(0, 1 << 32, (npl, q.modLen), dtype=np.uint64).astype(np.uint32)
+            wild[:, :4] = 0xFFFFFFFF
+            out = {}
+            for on in (1, 0):
+                gu.ck(gu.lib.cuhe_hip_set_icrt_mfma(on))
+                out[on] = (g.icrt(rows, lvl), g.icrt(wild, lvl))
+            assert np.array_equal(out[1][0], raw), (name, lvl)
+            assert np.array_equal(out[0][0], raw), (name, lvl)
+            assert np.array_equal(out[1][1], out[0][1]), (name, lvl)
+            assert np.array_equal(out[1][1], o.icrt(wild, lvl)), (name, lvl)
+        assert gu.lib.cuhe_hip_set_icrt_mfma(2) != 0
+    finally:
+        gu.lib.cuhe_hip_set_icrt_mfma(1)
+
+
 def test_ntt_intt_roundtrip_and_oracle(ctxpair):
     name, g, o = ctxpair
     q = o.prm
