@@ -753,7 +753,7 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
                    "key_bytes_per_ciphertext": key_bytes // min(B, 16),
                    "algorithmic_bytes_per_ciphertext": int(alg), "frac_hbm": round(alg / bdt / 1e9 / HBM_PEAK_GBS, 4),
                    "checked": "%d distinct ciphertext pairs, every result equal to the single chain" % B,
-                   "note": "B independent chains per call on one stream; products formed on load by the inverse transforms; key-switch inner product on the matrix cores (int8 MFMA over signed base-256 digits) in tiles of 16 ciphertexts"}
+                   "note": "B independent chains per call on one stream; products formed on load by the inverse transforms; inverse CRT column sums on the matrix cores (int8 MFMA, base-128 digits of the residue products); key-switch inner product on the matrix cores (int8 MFMA over signed base-256 digits) in tiles of 16 ciphertexts"}
         # twice the batch (the keys are amortised over more ciphertexts): the same operands twice, the two halves of the result equal
         try:
             B2 = 2 * B
