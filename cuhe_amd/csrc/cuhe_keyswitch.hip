@@ -18,6 +18,37 @@ int icrt_lds_attr(size_t lds) {                 // k_icrt needs the large-LDS at
     return once64.set(k_icrt<true>, 160 * 1024);
 }
 
+// CRT of `batch` polynomials (raw words -> residues of the primes prime0 ...): the sums on the FP64 pipe (k_crt_f64) where
+// the f64 tables exist, else the 64-bit integer kernel; CUHE_CRT_F64=0 keeps the integer kernel (A/B runs)
+int g_crt_f64 = getenv("CUHE_CRT_F64") ? atoi(getenv("CUHE_CRT_F64")) : 1;
+template <int PB>
+static void launch_crt_f64(u32 *dst, const u32 *src, const DevCtx &D, int prime0, int np, int W, const dim3 &grid, long ss, long ds, hipStream_t st) {
+    const Params &q = G_.prm;
+    CrtF64Tab T{D.powd + (size_t)prime0 * D.maxW, D.pd + prime0, D.rpd + prime0, D.maxW};
+    hipLaunchKernelGGL(k_crt_f64<PB>, grid, dim3(kCrtCoef * kCrtGroups), (size_t)((W + 3) & ~3) * (kCrtCoef + 1) * 4, st, dst, src, T, np, W, q.modLen, q.crtLen, ss, ds);
+}
+int launch_crt(u32 *dst, const u32 *src, const DevCtx &D, int prime0, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st) {
+    const Params &q = G_.prm;
+    if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
+    const dim3 grid((q.modLen + kCrtCoef - 1) / kCrtCoef, batch);
+    if (g_crt_f64 && D.powd) {
+        // primes per wave and pass: the fewest idle slots over the four waves, then the fewest conversions (largest PB)
+        int best = 4, slots = 1 << 30;
+        for (int pb : {4, 6, 8}) {
+            const int groups = (np + pb - 1) / pb, s = ((groups + kCrtGroups - 1) / kCrtGroups) * kCrtGroups * pb;
+            if (s <= slots) { slots = s; best = pb; }
+        }
+        if (best == 4) launch_crt_f64<4>(dst, src, D, prime0, np, W, grid, src_ct_stride, dst_ct_stride, st);
+        else if (best == 6) launch_crt_f64<6>(dst, src, D, prime0, np, W, grid, src_ct_stride, dst_ct_stride, st);
+        else launch_crt_f64<8>(dst, src, D, prime0, np, W, grid, src_ct_stride, dst_ct_stride, st);
+    } else {
+        hipLaunchKernelGGL(k_crt, grid, dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, st, dst, src, prime_tab_at(D, prime0),
+                           np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+
 // ICRT of `batch` ciphertexts of level lvl (np primes, W words)
 int launch_icrt(u32 *dst, const u32 *src, const DevCtx &D, int lvl, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st,
                 IcrtWindows wo = IcrtWindows{nullptr, 0, 0, 0, 0}) {
@@ -118,12 +149,7 @@ int cuhe_hip_crt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st
     CHK(need_init(dev));
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     DevCtx &D = G_.dev[dev];
-    if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
-    const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab(D),
-                       np, W, q.modLen, q.crtLen, 0L, 0L);
-    HIPCHK(hipGetLastError());
-    return CUHE_OK;
+    return launch_crt(dst, src, D, 0, np, W, 1, 0L, 0L, S(st));
 }
 int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st) {
     CHK(need_init(dev));
@@ -381,6 +407,11 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 // measured crossover at config 4: 2 and 4 ciphertexts are a little faster on the VALU kernel (0.190 / 0.127 vs 0.197 / 0.134 ms per
 // ciphertext), 6 already on the matrix cores (0.110 vs 0.141: one half-filled tile instead of two VALU groups)
 static int g_mac_mfma_min = getenv("CUHE_MAC_MFMA_MIN") ? atoi(getenv("CUHE_MAC_MFMA_MIN")) : 5;     // smallest batch that takes the MFMA kernel; 0 = never
+int cuhe_hip_set_crt_f64(int on) {
+    if (on != 0 && on != 1) return fail(CUHE_EINVAL, "on %d", on);
+    g_crt_f64 = on;
+    return CUHE_OK;
+}
 int cuhe_hip_set_icrt_mfma(int on) {
     if (on != 0 && on != 1) return fail(CUHE_EINVAL, "on %d", on);
     g_icrt_mfma = on;
@@ -726,11 +757,8 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     u32 *ca = Ws.mr_crt, *cb = Ws.mr_crt + (size_t)rows * cl;
     u64 *na = Ws.mr_ntt;
     if (q.modLen < cl) HIPCHK(hipMemsetAsync(Ws.mr_crt, 0, (size_t)2 * rows * cl * sizeof(u32), st));
-    const size_t lds_crt = (size_t)((W + 7) & ~7) * kCrtCoef * 4;
-    const dim3 gcrt((q.modLen + kCrtCoef - 1) / kCrtCoef, batch);
-    hipLaunchKernelGGL(k_crt, gcrt, dim3(kCrtCoef * kCrtGroups), lds_crt, st, ca, a, prime_tab(D), np, W, q.modLen, cl, (long)q.rawLen * W, (long)np * cl);
-    hipLaunchKernelGGL(k_crt, gcrt, dim3(kCrtCoef * kCrtGroups), lds_crt, st, cb, b, prime_tab(D), np, W, q.modLen, cl, (long)q.rawLen * W, (long)np * cl);
-    HIPCHK(hipGetLastError());
+    CHK(launch_crt(ca, a, D, 0, np, W, batch, (long)q.rawLen * W, (long)np * cl, st));
+    CHK(launch_crt(cb, b, D, 0, np, W, batch, (long)q.rawLen * W, (long)np * cl, st));
     // transforms of the a operands, then those of the b operands with the pointwise product riding on their output
     // (kOutU64Mul with the a transforms as the table: row r of b times row r of a) -- no separate product pass
     u64 *nb = na + (size_t)rows * L;
@@ -769,11 +797,7 @@ int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0,
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     if (prime0 < 0 || count < 1 || prime0 + count > np) return fail(CUHE_EINVAL, "prime range [%d,%d)", prime0, prime0 + count);
     DevCtx &D = G_.dev[dev];
-    const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt, dim3((q.modLen + kCrtCoef - 1) / kCrtCoef), dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, S(st), dst, src, prime_tab_at(D, prime0),
-                       count, W, q.modLen, q.crtLen, 0L, 0L);
-    HIPCHK(hipGetLastError());
-    return CUHE_OK;
+    return launch_crt(dst, src, D, prime0, count, W, 1, 0L, 0L, S(st));
 }
 
 

@@ -167,7 +167,7 @@ def test_crt_icrt(ctxpair):
         assert np.array_equal(g.icrt(g.crt(raw, lvl), lvl), raw)
 
 
-def test_icrt_matrix_core_form_equals_valu_form_and_oracle(ctxpair, gu):
+def test_crt_icrt_kernel_forms_equal_each_other_and_oracle(ctxpair, gu):
     """cuhe_hip_set_icrt_mfma: the column sums on the matrix cores (icrt_mfma.cuh) against the VALU kernel and the oracle, at
     EVERY level: reduced rows of edge values (0, small, M - small, multiples of M / np: quotient estimates next to an integer)
     and unreduced rows (x_i up to 2^32 - 1)."""
@@ -187,6 +187,11 @@ def test_icrt_matrix_core_form_equals_valu_form_and_oracle(ctxpair, gu):
             wild = rows.copy()
             wild[:, :q.modLen] = rng.integers(0, 1 << 32, (npl, q.modLen), dtype=np.uint64).astype(np.uint32)
             wild[:, :4] = 0xFFFFFFFF
+            for on in (1, 0):                                    # the CRT on the FP64 pipe and with integer multiply-adds (cuhe_hip_set_crt_f64)
+                gu.ck(gu.lib.cuhe_hip_set_crt_f64(on))
+                assert np.array_equal(g.crt(raw, lvl), rows), (name, lvl, on)
+                full = np.full_like(raw, 0xFFFFFFFF)              # every word 2^32 - 1: the largest sums
+                assert np.array_equal(g.crt(full, lvl), o.crt(full, lvl)), (name, lvl, on)
             out = {}
             for on in (1, 0):
                 gu.ck(gu.lib.cuhe_hip_set_icrt_mfma(on))
@@ -196,8 +201,10 @@ def test_icrt_matrix_core_form_equals_valu_form_and_oracle(ctxpair, gu):
             assert np.array_equal(out[1][1], out[0][1]), (name, lvl)
             assert np.array_equal(out[1][1], o.icrt(wild, lvl)), (name, lvl)
         assert gu.lib.cuhe_hip_set_icrt_mfma(2) != 0
+        assert gu.lib.cuhe_hip_set_crt_f64(2) != 0
     finally:
         gu.lib.cuhe_hip_set_icrt_mfma(1)
+        gu.lib.cuhe_hip_set_crt_f64(1)
 
 
 def test_ntt_intt_roundtrip_and_oracle(ctxpair):
