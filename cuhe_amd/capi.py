@@ -130,7 +130,7 @@ SIGNATURES = {
     "cuhe_hip_set_relin_lanes": (i32, [i32]),
     "cuhe_hip_set_relin_mfma": (i32, [i32]),
     "cuhe_hip_set_icrt_mfma": (i32, [i32]),
-    "cuhe_hip_set_crt_f64": (i32, [i32]),
+    "cuhe_hip_set_crt_acc64": (i32, [i32]),
     "cuhe_hip_mul_relin_batch": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_relin_cache_size": (sz, []),
     "cuhe_hip_relin_export": (i32, [vp, sz, i32]),

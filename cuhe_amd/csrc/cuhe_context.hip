@@ -173,18 +173,6 @@ int init_device(int dev) {
         for (int j = 0; j < i; ++j) hinv[(size_t)i * (i - 1) / 2 + j] = host::invmod32(hp[i] % hp[j], hp[j]);
     CHK(upload(&D.p, hp)); CHK(upload(&D.pinv, hpi)); CHK(upload(&D.e64, he));
     CHK(upload(&D.pow32, hpow)); CHK(upload(&D.invp, hinv));
-    {   // f64 copies for k_crt_f64: exact while W 2^16 pmax < 2^53
-        uint32_t pmax = 0;
-        for (int i = 0; i < pnum; ++i) pmax = std::max(pmax, hp[i]);
-        if ((u64)(q.wordsCoeff(0) + 1) * 65536ull * pmax < (1ull << 53)) {
-            std::vector<double> hpd((size_t)(pnum + 8) * D.maxW, 0.0), hp_d(pnum + 8, 1.0), hrp_d(pnum + 8, 0.0);
-            for (int i = 0; i < pnum; ++i) {
-                for (int k = 0; k < D.maxW; ++k) hpd[(size_t)i * D.maxW + k] = (double)hpow[(size_t)i * D.maxW + k];
-                hp_d[i] = (double)hp[i]; hrp_d[i] = 1.0 / (double)hp[i];
-            }
-            CHK(upload(&D.powd, hpd)); CHK(upload(&D.pd, hp_d)); CHK(upload(&D.rpd, hrp_d));
-        }
-    }
     // ---- ICRT constants for every level, all resident (cuhe/Operations.cu:107-156)
     D.icrt.resize(q.depth);
     for (int lvl = 0; lvl < q.depth; ++lvl) {
@@ -428,7 +416,7 @@ int cuhe_hip_shutdown(void) {
         for (auto &t : D.ntt) { hipFree(t.T1w); hipFree(t.T2); hipFree(t.T2inv); hipFree(t.tw); hipFree(t.twinv); hipFree(t.Wn1); t = NttTab(); }
         if (D.s1) { hipStreamDestroy(D.s1); hipStreamDestroy(D.s2); hipEventDestroy(D.ev_start); for (int i = 0; i < 2; ++i) { hipEventDestroy(D.ev_p1[i]); hipEventDestroy(D.ev_p2[i]); } }
         if (D.sh_stream) { hipStreamDestroy(D.sh_stream); hipEventDestroy(D.sh_e1); hipEventDestroy(D.sh_e2); }
-        void *ptrs[] = {D.p, D.e64, D.pow32, D.powd, D.pd, D.rpd, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek, D.ekd};
+        void *ptrs[] = {D.p, D.e64, D.pow32, D.invp, D.pinv, D.u_ntt, D.m_ntt, D.uh_ntt, D.mh_ntt, D.m_crt, D.ek, D.ekd};
         for (auto &t : D.ow) { hipFree(t.TW1f); hipFree(t.TW1i); hipFree(t.TW1h); hipFree(t.TW2); hipFree(t.TW1g); hipFree(t.TW1hi); }
         for (Workspace *w : D.spaces) free_workspace(w);
         for (void *p : ptrs) if (p) hipFree(p);

@@ -103,7 +103,6 @@ struct DevCtx {
     int cus = 0;                         // compute units (policy of the one-workgroup transforms)
     // prime tables
     u32 *p = nullptr, *e64 = nullptr, *pow32 = nullptr, *invp = nullptr;
-    double *powd = nullptr, *pd = nullptr, *rpd = nullptr;      // f64 tables of k_crt_f64 (powers 2^(32k) mod p, p, 1 / p); null: the form does not apply
     u64 *pinv = nullptr;
     int maxW = 0;
     std::vector<IcrtLevel> icrt;
@@ -213,7 +212,7 @@ int need_init(int dev);
 int level_of(int logq, int *lvl, int *np, int *W);
 inline PrimeTab prime_tab(const DevCtx &D) { return PrimeTab{D.p, D.pinv, D.e64, D.pow32, D.maxW}; }
 PrimeTab prime_tab_at(const DevCtx &D, int prime0);
-// CRT of `batch` polynomials onto the primes prime0 .. prime0 + np - 1 (k_crt_f64 where it applies, else k_crt)
+// CRT of `batch` polynomials onto the primes prime0 .. prime0 + np - 1
 int launch_crt(u32 *dst, const u32 *src, const DevCtx &D, int prime0, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st);
 template <typename T>
 int ws_buffer(T **ptr, size_t count) {           // lazily allocated, fixed-size workspace member

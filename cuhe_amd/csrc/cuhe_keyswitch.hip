@@ -18,33 +18,20 @@ int icrt_lds_attr(size_t lds) {                 // k_icrt needs the large-LDS at
     return once64.set(k_icrt<true>, 160 * 1024);
 }
 
-// CRT of `batch` polynomials (raw words -> residues of the primes prime0 ...): the sums on the FP64 pipe (k_crt_f64) where
-// the f64 tables exist, else the 64-bit integer kernel; CUHE_CRT_F64=0 keeps the integer kernel (A/B runs)
-int g_crt_f64 = getenv("CUHE_CRT_F64") ? atoi(getenv("CUHE_CRT_F64")) : 1;
-template <int PB>
-static void launch_crt_f64(u32 *dst, const u32 *src, const DevCtx &D, int prime0, int np, int W, const dim3 &grid, long ss, long ds, hipStream_t st) {
-    const Params &q = G_.prm;
-    CrtF64Tab T{D.powd + (size_t)prime0 * D.maxW, D.pd + prime0, D.rpd + prime0, D.maxW};
-    hipLaunchKernelGGL(k_crt_f64<PB>, grid, dim3(kCrtCoef * kCrtGroups), (size_t)((W + 3) & ~3) * (kCrtCoef + 1) * 4, st, dst, src, T, np, W, q.modLen, q.crtLen, ss, ds);
-}
+// CRT of `batch` polynomials (raw words -> residues of the primes prime0 ...).  Where the sums  sum_k word_k (2^(32k) mod p)
+// fit 64 bits (W 2^32 pmax <= 2^64: every parameter set of the reference's examples) the kernel keeps no carry word and
+// reduces once; CUHE_CRT_ACC64=0 keeps the 96-bit form (A/B runs)
+int g_crt_acc64 = getenv("CUHE_CRT_ACC64") ? atoi(getenv("CUHE_CRT_ACC64")) : 1;
 int launch_crt(u32 *dst, const u32 *src, const DevCtx &D, int prime0, int np, int W, int batch, long src_ct_stride, long dst_ct_stride, hipStream_t st) {
     const Params &q = G_.prm;
     if (W > D.maxW) return fail(CUHE_EINVAL, "coefficient words %d exceed table %d", W, D.maxW);
-    const dim3 grid((q.modLen + kCrtCoef - 1) / kCrtCoef, batch);
-    if (g_crt_f64 && D.powd) {
-        // primes per wave and pass: the fewest idle slots over the four waves, then the fewest conversions (largest PB)
-        int best = 4, slots = 1 << 30;
-        for (int pb : {4, 6, 8}) {
-            const int groups = (np + pb - 1) / pb, s = ((groups + kCrtGroups - 1) / kCrtGroups) * kCrtGroups * pb;
-            if (s <= slots) { slots = s; best = pb; }
-        }
-        if (best == 4) launch_crt_f64<4>(dst, src, D, prime0, np, W, grid, src_ct_stride, dst_ct_stride, st);
-        else if (best == 6) launch_crt_f64<6>(dst, src, D, prime0, np, W, grid, src_ct_stride, dst_ct_stride, st);
-        else launch_crt_f64<8>(dst, src, D, prime0, np, W, grid, src_ct_stride, dst_ct_stride, st);
-    } else {
-        hipLaunchKernelGGL(k_crt, grid, dim3(kCrtCoef * kCrtGroups), (size_t)((W + 7) & ~7) * kCrtCoef * 4, st, dst, src, prime_tab_at(D, prime0),
-                           np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride);
-    }
+    const dim3 grid((q.modLen + kCrtCoef - 1) / kCrtCoef, batch), block(kCrtCoef * kCrtGroups);
+    const size_t lds = (size_t)((W + 7) & ~7) * kCrtRow * 4;
+    unsigned long long pmax = 0;
+    for (int i = prime0; i < prime0 + np && i < (int)G_.primes.size(); ++i) pmax = std::max<unsigned long long>(pmax, G_.primes[i]);
+    const bool acc64 = g_crt_acc64 && pmax > 0 && (unsigned long long)W * pmax <= (1ull << 32);
+    if (acc64) hipLaunchKernelGGL(k_crt<true>, grid, block, lds, st, dst, src, prime_tab_at(D, prime0), np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride);
+    else hipLaunchKernelGGL(k_crt<false>, grid, block, lds, st, dst, src, prime_tab_at(D, prime0), np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -407,9 +394,9 @@ int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int de
 // measured crossover at config 4: 2 and 4 ciphertexts are a little faster on the VALU kernel (0.190 / 0.127 vs 0.197 / 0.134 ms per
 // ciphertext), 6 already on the matrix cores (0.110 vs 0.141: one half-filled tile instead of two VALU groups)
 static int g_mac_mfma_min = getenv("CUHE_MAC_MFMA_MIN") ? atoi(getenv("CUHE_MAC_MFMA_MIN")) : 5;     // smallest batch that takes the MFMA kernel; 0 = never
-int cuhe_hip_set_crt_f64(int on) {
+int cuhe_hip_set_crt_acc64(int on) {
     if (on != 0 && on != 1) return fail(CUHE_EINVAL, "on %d", on);
-    g_crt_f64 = on;
+    g_crt_acc64 = on;
     return CUHE_OK;
 }
 int cuhe_hip_set_icrt_mfma(int on) {

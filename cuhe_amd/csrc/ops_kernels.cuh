@@ -698,24 +698,31 @@ void k_extract_windows(u32 *__restrict__ win, const u32 *__restrict__ raw, int W
 // 64*W-word slab load, transposed to [W][64]).  Wave g takes the primes i = 4g + 16t + j, j < 4, four at a time: the
 // prime index is WAVE-UNIFORM, so the powers 2^(32k) mod p_i come in through scalar loads and every multiply-add is
 // one v_mad_u64_u32 with an SGPR operand plus one carry add; a word is read from LDS once per four primes.
-static constexpr int kCrtCoef = 64, kCrtGroups = 4, kCrtPB = 4;
-static __global__ __launch_bounds__(kCrtCoef * kCrtGroups)
+static constexpr int kCrtCoef = 64, kCrtGroups = 4, kCrtPB = 4, kCrtRow = kCrtCoef + 1;
+// ACC64: the sums fit 64 bits (W 2^32 pmax <= 2^64): no carry word, one reduction
+template <bool ACC64>
+__global__ __launch_bounds__(kCrtCoef * kCrtGroups)
 void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int np, int W, int mlen, int clen,
            long src_ct_stride, long dst_ct_stride) {
     src += (long)blockIdx.y * src_ct_stride;         // blockIdx.y: polynomial of a batched call (strides in words)
     dst += (long)blockIdx.y * dst_ct_stride;
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W8][64], W8 = W rounded up to 8, tail rows zero
-    constexpr int CB = kCrtCoef, NG = kCrtGroups, PB = kCrtPB;
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W8][65], W8 = W rounded up to 8, tail rows zero; rows padded: the transposing stores spread over the banks
+    constexpr int CB = kCrtCoef, NG = kCrtGroups, PB = kCrtPB, RS = kCrtRow;
     const int ci = threadIdx.x % CB;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x / CB);
     const int W8 = (W + 7) & ~7;
     const long base = (long)blockIdx.x * CB;
     const int nvalid = (int)min((long)CB, (long)mlen - base);
     const long slab = (long)nvalid * W;
-    for (int e = threadIdx.x; e < (W8 - W) * CB; e += CB * NG) sh[W * CB + e] = 0;
-    for (long e = threadIdx.x; e < slab; e += CB * NG) {
-        const int c2 = (int)(e / W), k = (int)(e % W);
-        sh[k * CB + c2] = src[base * W + e];
+    for (int e = threadIdx.x; e < (W8 - W) * RS; e += CB * NG) sh[W * RS + e] = 0;
+    {   // (coefficient, word) of element e advance without a division per element
+        const int dc = (CB * NG) / W, dk = (CB * NG) % W;
+        int c2 = (int)threadIdx.x / W, k = (int)threadIdx.x % W;
+        for (long e = threadIdx.x; e < slab; e += CB * NG) {
+            sh[k * RS + c2] = src[base * W + e];
+            c2 += dc; k += dk;
+            if (k >= W) { k -= W; ++c2; }
+        }
     }
     __syncthreads();
     if (ci >= nvalid) return;
@@ -733,11 +740,11 @@ void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int 
                 for (int kk = 0; kk < 8; ++kk) c[j][kk] = pw[(long)j * pt.maxW + k0 + kk];   // uniform: s_load_dwordx8
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                const u32 x = sh[(k0 + kk) * CB + ci];
+                const u32 x = sh[(k0 + kk) * RS + ci];
 #pragma unroll
                 for (int j = 0; j < PB; ++j) {
                     const u64 nl = (u64)x * c[j][kk] + lo[j];
-                    hi[j] += (nl < lo[j]);
+                    if (!ACC64) hi[j] += (nl < lo[j]);
                     lo[j] = nl;
                 }
             }
@@ -749,86 +756,11 @@ void k_crt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, int 
                 const u32 p = pt.p[i];
                 const u64 m = pt.pinv[i];
                 const u32 r1 = mod_small(lo[j], p, m);
-                const u64 r2 = (u64)hi[j] * pt.e64[i] + r1;
-                dst[(long)i * clen + base + ci] = mod_small(r2, p, m);
-            }
-        }
-    }
-}
-
-// The same sums on the FP64 pipe (round 4).  v_mad_u64_u32 issues at a quarter of the rate of v_fma_f64, and an f64
-// multiply-add of integers is EXACT while the result stays below 2^53: with the words split into 16-bit halves,
-//     A = sum_k lo16(word_k) c_k,   B = sum_k hi16(word_k) c_k,   c_k = 2^(32k) mod p      (A, B < W 2^16 p < 2^53)
-// and the residue is (A + 2^16 B) mod p.  Two f64 multiply-adds (8 cycles) replace a 64-bit multiply-add, its compare
-// and carry add (24 cycles); the halves are converted once per PB primes.  The reduction stays in f64 as well:
-// floor(t / p) through the reciprocal is off by at most one either way, t - q p is exact (fused), two conditional
-// corrections bring it into [0, p).  Same decomposition as k_crt (64 coefficients per block, wave-uniform primes, powers
-// through scalar loads); applies while W 2^16 pmax < 2^53, i.e. for every prime size the library generates.
-struct CrtF64Tab {
-    const double *pow;   // [np + 8][maxW]  2^(32k) mod p_i as f64, eight zero rows behind the last prime
-    const double *p;     // [np + 8]
-    const double *rp;    // [np + 8]  1 / p_i
-    int maxW;            // multiple of 8
-};
-template <int PB>
-__global__ __launch_bounds__(kCrtCoef * kCrtGroups)
-void k_crt_f64(u32 *__restrict__ dst, const u32 *__restrict__ src, CrtF64Tab T, int np, int W, int mlen, int clen,
-               long src_ct_stride, long dst_ct_stride) {
-    src += (long)blockIdx.y * src_ct_stride;
-    dst += (long)blockIdx.y * dst_ct_stride;
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];   // [W4][65], W4 = W rounded up to 4, tail rows zero; rows padded: the transposing stores hit 32 banks
-    constexpr int CB = kCrtCoef, NG = kCrtGroups, RS = kCrtCoef + 1;
-    const int ci = threadIdx.x % CB;
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x / CB);
-    const int W4 = (W + 3) & ~3;
-    const long base = (long)blockIdx.x * CB;
-    const int nvalid = (int)min((long)CB, (long)mlen - base);
-    const long slab = (long)nvalid * W;
-    for (int e = threadIdx.x; e < (W4 - W) * RS; e += CB * NG) sh[W * RS + e] = 0;
-    {   // (coefficient, word) of element e advance without a division per element
-        const int dc = (CB * NG) / W, dk = (CB * NG) % W;
-        int c2 = (int)threadIdx.x / W, k = (int)threadIdx.x % W;
-        for (long e = threadIdx.x; e < slab; e += CB * NG) {
-            sh[k * RS + c2] = src[base * W + e];
-            c2 += dc; k += dk;
-            if (k >= W) { k -= W; ++c2; }
-        }
-    }
-    __syncthreads();
-    if (ci >= nvalid) return;
-    for (int i0 = g * PB; i0 < np; i0 += NG * PB) {
-        double A[PB], B[PB];
-#pragma unroll
-        for (int j = 0; j < PB; ++j) { A[j] = 0.0; B[j] = 0.0; }
-        const double *pw = T.pow + (long)i0 * T.maxW;
-        for (int k0 = 0; k0 < W4; k0 += 4) {
-            double c[PB][4];
-#pragma unroll
-            for (int j = 0; j < PB; ++j)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) c[j][kk] = pw[(long)j * T.maxW + k0 + kk];      // uniform: s_load_dwordx8
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const u32 x = sh[(k0 + kk) * RS + ci];
-                const double xl = (double)(x & 0xffffu), xh = (double)(x >> 16);
-#pragma unroll
-                for (int j = 0; j < PB; ++j) {
-                    A[j] = __builtin_fma(xl, c[j][kk], A[j]);
-                    B[j] = __builtin_fma(xh, c[j][kk], B[j]);
+                if (ACC64) dst[(long)i * clen + base + ci] = r1;
+                else {
+                    const u64 r2 = (u64)hi[j] * pt.e64[i] + r1;
+                    dst[(long)i * clen + base + ci] = mod_small(r2, p, m);
                 }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            const int i = i0 + j;
-            if (i < np) {
-                const double p = T.p[i], rp = T.rp[i];
-                const double rb = __builtin_fma(-__builtin_trunc(B[j] * rp), p, B[j]);      // B mod p, in [-p, 2p)
-                const double t = __builtin_fma(65536.0, rb, A[j]);                          // |t| < 2^53: exact
-                double r = __builtin_fma(-__builtin_floor(t * rp), p, t);                   // in [-p, 2p)
-                r = r < 0.0 ? r + p : r;
-                r = r >= p ? r - p : r;
-                dst[(long)i * clen + base + ci] = (u32)r;
             }
         }
     }

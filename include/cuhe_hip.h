@@ -240,11 +240,10 @@ int cuhe_hip_set_relin_mfma(int min_batch);
    v_mfma_i32_32x32x32_i8, exact) for parameter sets with primes below 2^28 and at most 47 words per coefficient; others
    keep the VALU kernel.  on = 1 (default) / 0 = the VALU kernel everywhere.  Results do not depend on the setting. */
 int cuhe_hip_set_icrt_mfma(int on);
-/* The CRT (cuhe_hip_crt and every chain that contains it; cuhe/Base.cu:857-879) forms its sums  sum_k word_k (2^(32k) mod p)
-   on the FP64 pipe: 16-bit halves of the words times the powers as exact f64 multiply-adds (everything stays below 2^53),
-   the reduction modulo p in f64 as well.  on = 1 (default) / 0 = the kernel with 64-bit integer multiply-adds.  Results do
-   not depend on the setting. */
-int cuhe_hip_set_crt_f64(int on);
+/* The CRT (cuhe_hip_crt and every chain that contains it; cuhe/Base.cu:857-879) keeps its sums  sum_k word_k (2^(32k) mod p)
+   in 64 bits without a carry word wherever they fit (W 2^32 pmax <= 2^64: one multiply-add per term, one reduction).
+   on = 1 (default) / 0 = the 96-bit form everywhere.  Results do not depend on the setting. */
+int cuhe_hip_set_crt_acc64(int on);
 /* `batch` independent full multiplications raw -> raw of one level in one call (mulZZX without the host staging,
    CuHE.cu:259-268): a, b, dst = u32[batch][rawLen][W], W = words of the level's coefficients; bit-identical to the
    single sequence crt, crt, ntt, ntt, ntt_mul, intt_mod, icrt */

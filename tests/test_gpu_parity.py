@@ -187,8 +187,8 @@ def test_crt_icrt_kernel_forms_equal_each_other_and_oracle(ctxpair, gu):
             wild = rows.copy()
             wild[:, :q.modLen] = rng.integers(0, 1 << 32, (npl, q.modLen), dtype=np.uint64).astype(np.uint32)
             wild[:, :4] = 0xFFFFFFFF
-            for on in (1, 0):                                    # the CRT on the FP64 pipe and with integer multiply-adds (cuhe_hip_set_crt_f64)
-                gu.ck(gu.lib.cuhe_hip_set_crt_f64(on))
+            for on in (1, 0):                                    # the CRT with 64-bit sums and with the carry word (cuhe_hip_set_crt_acc64)
+                gu.ck(gu.lib.cuhe_hip_set_crt_acc64(on))
                 assert np.array_equal(g.crt(raw, lvl), rows), (name, lvl, on)
                 full = np.full_like(raw, 0xFFFFFFFF)              # every word 2^32 - 1: the largest sums
                 assert np.array_equal(g.crt(full, lvl), o.crt(full, lvl)), (name, lvl, on)
@@ -201,10 +201,10 @@ def test_crt_icrt_kernel_forms_equal_each_other_and_oracle(ctxpair, gu):
             assert np.array_equal(out[1][1], out[0][1]), (name, lvl)
             assert np.array_equal(out[1][1], o.icrt(wild, lvl)), (name, lvl)
         assert gu.lib.cuhe_hip_set_icrt_mfma(2) != 0
-        assert gu.lib.cuhe_hip_set_crt_f64(2) != 0
+        assert gu.lib.cuhe_hip_set_crt_acc64(2) != 0
     finally:
         gu.lib.cuhe_hip_set_icrt_mfma(1)
-        gu.lib.cuhe_hip_set_crt_f64(1)
+        gu.lib.cuhe_hip_set_crt_acc64(1)
 
 
 def test_ntt_intt_roundtrip_and_oracle(ctxpair):
