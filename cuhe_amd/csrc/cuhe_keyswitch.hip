@@ -180,16 +180,29 @@ int cuhe_hip_crt_mul_int(uint32_t *prod, const uint32_t *x, int a, int logq, int
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
+// modulus switch of `batch` ciphertexts; 16-byte accesses when the rows allow them (CUHE_ELEMENTWISE_VEC=0: never, A/B runs)
+static int g_elem_vec = getenv("CUHE_ELEMENTWISE_VEC") ? atoi(getenv("CUHE_ELEMENTWISE_VEC")) : 1;
+static bool rows_vec4(const void *a, const void *b, long s1, long s2) {
+    const Params &q = G_.prm;
+    return g_elem_vec && q.modLen % 4 == 0 && q.crtLen % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && s1 % 4 == 0 && s2 % 4 == 0;
+}
+static int launch_modswitch(u32 *dst, const u32 *src, const DevCtx &D, int np, int batch, long ss, long ds, hipStream_t st) {
+    const Params &q = G_.prm;
+    const int groups = (np - 1 + kModswPrimes - 1) / kModswPrimes;
+    if (rows_vec4(dst, src, ss, ds))
+        hipLaunchKernelGGL(k_modswitch<4>, dim3((q.modLen / 4 + 255) / 256, groups, batch), dim3(256), 0, st, dst, src, prime_tab(D), D.invp, np, q.modLen, q.crtLen, q.modMsg, ss, ds);
+    else
+        hipLaunchKernelGGL(k_modswitch<1>, dim3((q.modLen + 255) / 256, groups, batch), dim3(256), 0, st, dst, src, prime_tab(D), D.invp, np, q.modLen, q.crtLen, q.modMsg, ss, ds);
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
 int cuhe_hip_crt_mod_switch(uint32_t *dst, const uint32_t *src, int logq, int dev, void *st) {
     CHK(need_init(dev));
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     if (np < 2) return fail(CUHE_EINVAL, "modSwitch needs >= 2 primes");
     const Params &q = G_.prm;
     DevCtx &D = G_.dev[dev];
-    hipLaunchKernelGGL(k_modswitch, dim3((q.modLen + 255) / 256, np - 1), dim3(256), 0, S(st), dst, src, prime_tab(D),
-                       D.invp, np, q.modLen, q.crtLen, q.modMsg, 0L, 0L);
-    HIPCHK(hipGetLastError());
-    return CUHE_OK;
+    return launch_modswitch(dst, src, D, np, 1, 0L, 0L, S(st));
 }
 
 // ---------------------------------------------------------------- relinearisation
@@ -594,10 +607,7 @@ int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, i
     const int np = q.numCrtPrimeAt(lvl);
     if (np < 2) return fail(CUHE_EINVAL, "modSwitch needs >= 2 primes");
     DevCtx &D = G_.dev[dev];
-    hipLaunchKernelGGL(k_modswitch, dim3((q.modLen + 255) / 256, np - 1, batch), dim3(256), 0, S(st), dst, src, prime_tab(D),
-                       D.invp, np, q.modLen, q.crtLen, q.modMsg, (long)np * q.crtLen, (long)(np - 1) * q.crtLen);
-    HIPCHK(hipGetLastError());
-    return CUHE_OK;
+    return launch_modswitch(dst, src, D, np, batch, (long)np * q.crtLen, (long)(np - 1) * q.crtLen, S(st));
 }
 // `count` blocks of `bytes` bytes each (a multiple of 16, 16-byte aligned) between their own addresses and one contiguous
 // array: gather (blocks -> array) / scatter (array -> blocks); the pointer list is HOST memory (it travels as a kernel argument)
@@ -708,8 +718,12 @@ int cuhe_hip_crt_combine(uint32_t *dst, const uint32_t *src_a, int nA, const uin
     if (nout < 1) return fail(CUHE_EINVAL, "nout %d", nout);
     const int np = q.numCrtPrimeAt(lvl);
     DevCtx &D = G_.dev[dev];
-    hipLaunchKernelGGL(k_crt_combine, dim3((q.modLen + 255) / 256, np, nout), dim3(256), 0, S(st), dst, src_a, nA, src_b, off, list, add_const,
-                       prime_tab(D), np, q.modLen, q.crtLen);
+    if (rows_vec4(dst, src_a, 0, 0) && (!src_b || ((uintptr_t)src_b % 16) == 0))
+        hipLaunchKernelGGL(k_crt_combine<4>, dim3((q.modLen / 4 + 255) / 256, np, nout), dim3(256), 0, S(st), dst, src_a, nA, src_b, off, list, add_const,
+                           prime_tab(D), np, q.modLen, q.crtLen);
+    else
+        hipLaunchKernelGGL(k_crt_combine<1>, dim3((q.modLen + 255) / 256, np, nout), dim3(256), 0, S(st), dst, src_a, nA, src_b, off, list, add_const,
+                           prime_tab(D), np, q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }

@@ -45,7 +45,7 @@ struct IcrtMfmaTab {
 static constexpr int kIcrtMfmaThreads = 256, kIcrtMfmaTile = 32;
 static inline size_t icrt_mfma_lds_bytes(int tiles, int ksteps) {
     return (size_t)tiles * ksteps * 1024 + (size_t)ksteps * 8 * sizeof(IcrtPrimeConst) + (size_t)8 * tiles * 4 +
-           (size_t)(kIcrtMfmaThreads / 64) * 8 * tiles * kIcrtMfmaTile * 4;
+           (size_t)(kIcrtMfmaThreads / 64) * 8 * tiles * (kIcrtMfmaTile + 1) * 4;
 }
 // base-128 digits of t < 2^28, one per byte
 __device__ __forceinline__ int digits128(u32 t) {
@@ -59,14 +59,14 @@ template <int TILES>
 __global__ __launch_bounds__(kIcrtMfmaThreads, CUHE_ICRT_WAVES)
 void k_icrt_mfma(u32 *__restrict__ dst, const u32 *__restrict__ src, IcrtMfmaTab T, int np, int W, int mlen, int clen,
                  long src_ct_stride, long dst_ct_stride, int ncts, IcrtWindows wo) {
-    constexpr int WH = 4 * TILES, NW = 8 * TILES, CB = kIcrtMfmaTile;
+    constexpr int WH = 4 * TILES, NW = 8 * TILES, CB = kIcrtMfmaTile, RS = kIcrtMfmaTile + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char shraw[];
     const int ks = T.ksteps;
     v4i *tab = reinterpret_cast<v4i *>(shraw);                                        // [TILES * ks][64]
     IcrtPrimeConst *pc = reinterpret_cast<IcrtPrimeConst *>(tab + TILES * ks * 64);   // [8 ks]
     u32 *nm = reinterpret_cast<u32 *>(pc + ks * 8);                                   // [NW]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    u32 *wl = nm + NW + wave * NW * CB;                                               // [NW][32]: result words of this wave's tile
+    u32 *wl = nm + NW + wave * NW * RS;                                               // [NW][33]: result words of this wave's tile (rows padded: the slab stores read down a column)
     for (int e = threadIdx.x; e < TILES * ks * 64; e += kIcrtMfmaThreads) tab[e] = reinterpret_cast<const v4i *>(T.dig)[e];
     for (int e = threadIdx.x; e < ks * 8 * 4; e += kIcrtMfmaThreads) reinterpret_cast<u64 *>(pc)[e] = reinterpret_cast<const u64 *>(T.pc)[e];
     for (int e = threadIdx.x; e < NW; e += kIcrtMfmaThreads) nm[e] = T.nm[e];
@@ -198,7 +198,7 @@ void k_icrt_mfma(u32 *__restrict__ dst, const u32 *__restrict__ src, IcrtMfmaTab
         }
         if (!dst && (win_regs || !wo.win)) continue;
 #pragma unroll
-        for (int jj = 0; jj < WH; ++jj) wl[(h * WH + jj) * CB + c] = wd[jj];
+        for (int jj = 0; jj < WH; ++jj) wl[(h * WH + jj) * RS + c] = wd[jj];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -207,7 +207,7 @@ void k_icrt_mfma(u32 *__restrict__ dst, const u32 *__restrict__ src, IcrtMfmaTab
             const u32 mask = (u32)((1u << wo.w) - 1u);
             for (int j = h; j < wo.k; j += 2) {
                 const int bit = wo.w * j, wi = bit >> 5;             // wi + 1 <= W < NW: the word above is always there (zero above the value)
-                const u64 sv = (u64)wl[wi * CB + c] | (u64)wl[(wi + 1) * CB + c] << 32;
+                const u64 sv = (u64)wl[wi * RS + c] | (u64)wl[(wi + 1) * RS + c] << 32;
                 wrow[(long)j * wo.clen] = (u32)(sv >> (bit & 31)) & mask;
             }
         }
@@ -216,7 +216,7 @@ void k_icrt_mfma(u32 *__restrict__ dst, const u32 *__restrict__ src, IcrtMfmaTab
             const int slab = nvalid * W, dc = 64 / W, dk = 64 % W;
             int c2 = lane / W, k = lane % W;
             for (int e = lane; e < slab; e += 64) {
-                o[e] = wl[k * CB + c2];
+                o[e] = wl[k * RS + c2];
                 c2 += dc; k += dk;
                 if (k >= W) { k -= W; ++c2; }
             }

@@ -67,21 +67,30 @@ void k_ntt_mul_pairs(u64 *__restrict__ dst, const u64 *__restrict__ src, const i
 // dst[o] = sum of the CRT-domain ciphertexts srcs[list[t]] for t in [off[o], off[o+1])  (+ addc[o] on the constant
 // coefficient), residues mod p_i.  A list entry e < nA addresses srcA[e], otherwise srcB[e - nA].  blockIdx.y = prime
 // row, blockIdx.z = output.  This is a whole layer of cXor / cNot gates (CuHE.cu:122-215) in one launch.
-static __global__ __launch_bounds__(256)
+template <int VEC>          // coefficients per thread: 4 (16-byte accesses; mlen, clen multiples of 4) or 1
+__global__ __launch_bounds__(256)
 void k_crt_combine(u32 *__restrict__ dst, const u32 *__restrict__ srcA, int nA, const u32 *__restrict__ srcB,
                    const int *__restrict__ off, const int *__restrict__ list, const int *__restrict__ addc,
                    PrimeTab pt, int np, int mlen, int clen) {
-    const int o = blockIdx.z, i = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.z, i = blockIdx.y, idx = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (idx >= mlen) return;
     const u32 p = pt.p[i];
-    u64 acc = 0;
+    u64 acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
     for (int t = off[o]; t < off[o + 1]; ++t) {
         const int e = list[t];
         const u32 *s = e < nA ? srcA + ((long)e * np + i) * clen : srcB + ((long)(e - nA) * np + i) * clen;
-        acc += s[idx];                                   // residues < 2^32, a few dozen terms at most
+        if (VEC == 4) { const uint4 x = *reinterpret_cast<const uint4 *>(s + idx); acc[0] += x.x; acc[1 % VEC] += x.y; acc[2 % VEC] += x.z; acc[3 % VEC] += x.w; }
+        else acc[0] += s[idx];                           // residues < 2^32, a few dozen terms at most
     }
-    if (idx == 0) acc += (u32)addc[o];
-    dst[((long)o * np + i) * clen + idx] = mod_small(acc, p, pt.pinv[i]);
+    if (idx == 0) acc[0] += (u32)addc[o];
+    u32 r[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) r[v] = mod_small(acc[v], p, pt.pinv[i]);
+    u32 *d = dst + ((long)o * np + i) * clen + idx;
+    if (VEC == 4) *reinterpret_cast<uint4 *>(d) = make_uint4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    else d[0] = r[0];
 }
 
 // ---------------------------------------------------------------- CRT-domain ops
@@ -123,31 +132,49 @@ static __global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict_
 }
 
 // ---------------------------------------------------------------- modulus switching (Base.cu:1112-1138)
-// grid.y = target prime i < np-1.  dst may alias src (row i only depends on rows i and np-1,
-// and row np-1 is never written).
-static __global__ __launch_bounds__(256)
+// dst may alias src (row i only depends on rows i and np-1, and row np-1 is never written).
+// A thread owns VEC consecutive coefficients (VEC = 4: 16-byte accesses, mlen and clen multiples of 4) and kModswPrimes
+// target primes (blockIdx.y = group of primes): the dropped prime's residue and its parity fix are formed once per
+// coefficient, not once per (coefficient, prime); no branch on the sign of the difference (a multiple of p is added first).
+// Round 4: the one-element-per-thread form ran at 1 TB/s on arrays of 64 ciphertexts (profiles/r04_elementwise_ab.txt).
+static constexpr int kModswPrimes = 4;
+template <int VEC>
+__global__ __launch_bounds__(256)
 void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt,
                  const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg, long src_ct_stride, long dst_ct_stride) {
     src += (long)blockIdx.z * src_ct_stride;         // blockIdx.z: ciphertext of a batched call (the result has np-1 rows,
     dst += (long)blockIdx.z * dst_ct_stride;         // so a packed result array has a smaller stride than its source)
-    const int i = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (idx >= mlen) return;
     const u32 ptl = pt.p[np - 1];
-    int dirty = (int)src[(long)(np - 1) * clen + idx];
-    const int ep = dirty % modmsg;
-    if (ep != 0) {
-        if ((u32)dirty > ((ptl - 1) / 2)) dirty -= ep * (int)ptl;
-        else dirty += ep * (int)ptl;
+    u32 raw[VEC];
+    if (VEC == 4) { const uint4 v = *reinterpret_cast<const uint4 *>(src + (long)(np - 1) * clen + idx); raw[0] = v.x; raw[1 % VEC] = v.y; raw[2 % VEC] = v.z; raw[3 % VEC] = v.w; }
+    else raw[0] = src[(long)(np - 1) * clen + idx];
+    long long dirty[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const int d = (int)raw[v];
+        const int ep = modmsg == 2 ? (d & 1) : d % modmsg;          // (the residue is below 2^31: non-negative as an int)
+        dirty[v] = d;
+        if (ep != 0) dirty[v] += (raw[v] > ((ptl - 1) / 2)) ? -(long long)ep * (long long)ptl : (long long)ep * (long long)ptl;
     }
-    const u32 p = pt.p[i];
-    const u64 m = pt.pinv[i];
-    // (src - dirty) mod p, then times p_t^-1 mod p
-    long long diff = (long long)src[(long)i * clen + idx] - (long long)dirty;   // |diff| < 2^34
-    u32 r;
-    if (diff >= 0) r = mod_small((u64)diff, p, m);
-    else { u32 t = mod_small((u64)(-diff), p, m); r = t ? p - t : 0; }
-    const u32 inv = invp[(np - 1) * (np - 2) / 2 + i];
-    dst[(long)i * clen + idx] = mod_small((u64)r * inv, p, m);
+    const int i1 = min((int)(blockIdx.y + 1) * kModswPrimes, np - 1);
+    for (int i = blockIdx.y * kModswPrimes; i < i1; ++i) {
+        const u32 p = pt.p[i];
+        const u64 m = pt.pinv[i];
+        const u32 inv = invp[(np - 1) * (np - 2) / 2 + i];
+        const u64 lift = (u64)p * ((((u64)1 << 42) / p) + 1);        // a multiple of p above every |src - dirty| (< 2^32 + modmsg 2^31)
+        u32 x[VEC], r[VEC];
+        if (VEC == 4) { const uint4 v = *reinterpret_cast<const uint4 *>(src + (long)i * clen + idx); x[0] = v.x; x[1 % VEC] = v.y; x[2 % VEC] = v.z; x[3 % VEC] = v.w; }
+        else x[0] = src[(long)i * clen + idx];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const u32 t = mod_small((u64)((long long)x[v] - dirty[v] + (long long)lift), p, m);       // (src - dirty) mod p
+            r[v] = mod_small((u64)t * inv, p, m);                                                     // times p_t^-1 mod p
+        }
+        if (VEC == 4) *reinterpret_cast<uint4 *>(dst + (long)i * clen + idx) = make_uint4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+        else dst[(long)i * clen + idx] = r[0];
+    }
 }
 
 // ---------------------------------------------------------------- polynomial Barrett pieces
