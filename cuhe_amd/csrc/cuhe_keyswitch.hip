@@ -146,12 +146,20 @@ int cuhe_hip_icrt(uint32_t *dst, const uint32_t *src, int logq, int dev, void *s
     const Params &q = G_.prm;
     return launch_icrt(dst, src, D, lvl, np, W, 1, 0L, 0L, S(st));
 }
+// elementwise CRT-domain kernels: 16-byte accesses when the rows allow them (CUHE_ELEMENTWISE_VEC=0: never, A/B runs)
+static int g_elem_vec = getenv("CUHE_ELEMENTWISE_VEC") ? atoi(getenv("CUHE_ELEMENTWISE_VEC")) : 1;
+static bool rows_vec4(const void *a, const void *b, long s1, long s2) {
+    const Params &q = G_.prm;
+    return g_elem_vec && q.modLen % 4 == 0 && q.crtLen % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && s1 % 4 == 0 && s2 % 4 == 0;
+}
 int cuhe_hip_crt_add(uint32_t *sum, const uint32_t *x, const uint32_t *y, int logq, int dev, void *st) {
     CHK(need_init(dev));
     int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
     const Params &q = G_.prm;
-    hipLaunchKernelGGL(k_crt_add, dim3((q.modLen + 255) / 256, np), dim3(256), 0, S(st), sum, x, y, prime_tab(G_.dev[dev]),
-                       q.modLen, q.crtLen);
+    if (rows_vec4(sum, x, 0, 0) && ((uintptr_t)y % 16) == 0)
+        hipLaunchKernelGGL(k_crt_add<4>, dim3((q.modLen / 4 + 255) / 256, np), dim3(256), 0, S(st), sum, x, y, prime_tab(G_.dev[dev]), q.modLen, q.crtLen);
+    else
+        hipLaunchKernelGGL(k_crt_add<1>, dim3((q.modLen + 255) / 256, np), dim3(256), 0, S(st), sum, x, y, prime_tab(G_.dev[dev]), q.modLen, q.crtLen);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -180,12 +188,7 @@ int cuhe_hip_crt_mul_int(uint32_t *prod, const uint32_t *x, int a, int logq, int
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
-// modulus switch of `batch` ciphertexts; 16-byte accesses when the rows allow them (CUHE_ELEMENTWISE_VEC=0: never, A/B runs)
-static int g_elem_vec = getenv("CUHE_ELEMENTWISE_VEC") ? atoi(getenv("CUHE_ELEMENTWISE_VEC")) : 1;
-static bool rows_vec4(const void *a, const void *b, long s1, long s2) {
-    const Params &q = G_.prm;
-    return g_elem_vec && q.modLen % 4 == 0 && q.crtLen % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && s1 % 4 == 0 && s2 % 4 == 0;
-}
+// modulus switch of `batch` ciphertexts
 static int launch_modswitch(u32 *dst, const u32 *src, const DevCtx &D, int np, int batch, long ss, long ds, hipStream_t st) {
     const Params &q = G_.prm;
     const int groups = (np - 1 + kModswPrimes - 1) / kModswPrimes;
@@ -663,7 +666,10 @@ int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *cons
         const int n = std::min(kPtrListMax, count - c0);
         PtrList Z, A, B;
         CHK(fill_list(Z, (const void *const *)z, c0, n)); CHK(fill_list(A, a, c0, n)); CHK(fill_list(B, b, c0, n));
-        hipLaunchKernelGGL(k_crt_add_list, dim3((q.modLen + 255) / 256, np, n), dim3(256), 0, S(st), Z, A, B, prime_tab(D), q.modLen, q.crtLen);
+        bool vec = rows_vec4(nullptr, nullptr, 0, 0);
+        for (int t = 0; t < n && vec; ++t) vec = (((uintptr_t)Z.p[t] | (uintptr_t)A.p[t] | (uintptr_t)B.p[t]) % 16) == 0;
+        if (vec) hipLaunchKernelGGL(k_crt_add_list<4>, dim3((q.modLen / 4 + 255) / 256, np, n), dim3(256), 0, S(st), Z, A, B, prime_tab(D), q.modLen, q.crtLen);
+        else hipLaunchKernelGGL(k_crt_add_list<1>, dim3((q.modLen + 255) / 256, np, n), dim3(256), 0, S(st), Z, A, B, prime_tab(D), q.modLen, q.crtLen);
     }
     HIPCHK(hipGetLastError());
     return CUHE_OK;

@@ -97,13 +97,19 @@ void k_crt_combine(u32 *__restrict__ dst, const u32 *__restrict__ srcA, int nA, 
 // inputs are residues < p_i, so (a+b)%p is one conditional subtract when a,b < p;
 // the reference uses % (Base.cu:1088-1109) which also accepts unreduced inputs --
 // we keep exact % semantics through mod_small.
-static __global__ __launch_bounds__(256)
-void k_crt_add(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__restrict__ b,
-               PrimeTab pt, int mlen, int clen) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+template <int VEC>          // coefficients per thread: 4 (16-byte accesses) or 1
+__global__ __launch_bounds__(256)
+void k_crt_add(u32 *z, const u32 *a, const u32 *b, PrimeTab pt, int mlen, int clen) {       // (z may be a or b)
+    const int crt = blockIdx.y, idx = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (idx >= mlen) return;
     const long o = (long)crt * clen + idx;
-    z[o] = mod_small((u64)a[o] + b[o], pt.p[crt], pt.pinv[crt]);
+    const u32 p = pt.p[crt];
+    const u64 m = pt.pinv[crt];
+    if (VEC == 4) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(a + o), y = *reinterpret_cast<const uint4 *>(b + o);
+        *reinterpret_cast<uint4 *>(z + o) = make_uint4(mod_small((u64)x.x + y.x, p, m), mod_small((u64)x.y + y.y, p, m),
+                                                       mod_small((u64)x.z + y.z, p, m), mod_small((u64)x.w + y.w, p, m));
+    } else z[o] = mod_small((u64)a[o] + b[o], p, m);
 }
 static __global__ __launch_bounds__(256)
 void k_crt_add_nx1(u32 *__restrict__ z, const u32 *__restrict__ a, const u32 *__restrict__ s,
@@ -1016,14 +1022,21 @@ void k_ntt_binop_list(PtrList zl, PtrList xl, PtrList yl, long n2) {
         z[i] = r;
     }
 }
-static __global__ __launch_bounds__(256)
+template <int VEC>          // coefficients per thread: 4 (16-byte accesses; mlen, clen multiples of 4, blocks 16-byte aligned) or 1
+__global__ __launch_bounds__(256)
 void k_crt_add_list(PtrList zl, PtrList al, PtrList bl, PrimeTab pt, int mlen, int clen) {
-    const int crt = blockIdx.y, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int crt = blockIdx.y, idx = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (idx >= mlen) return;
     const long o = (long)crt * clen + idx;
     u32 *z = (u32 *)zl.p[blockIdx.z];
     const u32 *a = (const u32 *)al.p[blockIdx.z], *b = (const u32 *)bl.p[blockIdx.z];
-    z[o] = mod_small((u64)a[o] + b[o], pt.p[crt], pt.pinv[crt]);
+    const u32 p = pt.p[crt];
+    const u64 m = pt.pinv[crt];
+    if (VEC == 4) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(a + o), y = *reinterpret_cast<const uint4 *>(b + o);
+        *reinterpret_cast<uint4 *>(z + o) = make_uint4(mod_small((u64)x.x + y.x, p, m), mod_small((u64)x.y + y.y, p, m),
+                                                       mod_small((u64)x.z + y.z, p, m), mod_small((u64)x.w + y.w, p, m));
+    } else z[o] = mod_small((u64)a[o] + b[o], p, m);
 }
 static __global__ __launch_bounds__(256)
 void k_copy_list(PtrList dl, PtrList sl, long bytes) {
