@@ -2,9 +2,9 @@
 //
 // cuhe/Base.cu:884-960 of the reference rebuilds a coefficient from its residues with one thread per coefficient and a
 // 104-word register array; k_icrt (ops_kernels.cuh) turns that into  S = sum_i t_i (M / p_i),  t_i = x_i b_i mod p_i,
-// minus q M, with np W multiply-adds (v_mad_u64_u32) per coefficient -- 1728 at 48 primes of 24 bits, ~3700 vector
-// instructions per coefficient with the residue products and the LDS reads: issue bound (0.22 ms per 32 ciphertexts of
-// x^32768 + 1, 1 TB/s of traffic).
+// minus q M, with np W multiply-adds (v_mad_u64_u32) per coefficient -- 1728 at 48 primes of 24 bits, 4681 vector lane
+// instructions per coefficient with the residue products, the LDS reads and the fix-up (SQ_INSTS_VALU): issue bound
+// (0.22 ms per 32 ciphertexts of x^32768 + 1, 1 TB/s of traffic).
 //
 // The sum is a matrix product: coefficients are columns, the contraction runs over (prime, digit of t_i) and the rows are
 // the BYTES of the result.  With t_i in four base-128 digits (non-negative int8; primes below 2^28) and the constants
@@ -12,8 +12,9 @@
 // the digit sums                 out[d] = sum_(i,a) digit_a(t_i) * c_(i,a)[d]                     (|out[d]| < 2^23)
 // are exact in the int32 accumulators of v_mfma_i32_32x32x32_i8 (32 result bytes x 32 coefficients x 8 primes per
 // instruction), and  S = sum_d out[d] 256^d.  What is left for the vector ALU is the residue products (leaner: see
-// IcrtPrimeConst), four shift-adds per result word, the carry ripple and one conditional subtraction of M: ~2000 vector
-// instructions per coefficient, and the kernel runs 1.83x faster -- at the speed of its bytes.
+// IcrtPrimeConst), four shift-adds per result word, the carry ripple and one conditional subtraction of M: 2555 vector
+// lane instructions per coefficient (SQ_INSTS_VALU; 1.83x fewer), and the kernel runs 1.83x faster -- at the speed of
+// its bytes.
 //
 // Lane map (one wave = one tile of 32 coefficients): lane = 32 h + c.  Second operand: lane (c, h) holds the digits of
 // the primes 8 s + 4 h + e (e < 4) of coefficient c in K step s -- it formed those residue products itself, so the
