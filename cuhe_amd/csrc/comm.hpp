@@ -4,9 +4,11 @@
 // Two transports:
 //  * one process per GPU (bench.py / torchrun, any MPI-style launcher): RCCL.  librccl is opened at run time (dlopen),
 //    re-using the copy a host process already loaded (PyTorch ships one), so that libcuhe_hip.so has no link-time
-//    dependency on it and single-GPU clients never touch it.  The ranks' row blocks differ in size when the number of
-//    primes is not a multiple of the number of ranks, so the gather is a group of ncclBroadcast calls (root r sends its
-//    block in place) rather than one ncclAllGather.
+//    dependency on it and single-GPU clients never touch it.  The exchange IS the collective SURVEY 8(e) names: ONE
+//    ncclAllGather, in place, when the ranks' blocks are equal (config 4 at level 0: 48 primes over 2 / 4 / 8 ranks); when
+//    the number of primes is not a multiple of the number of ranks, one ncclAllGather of blocks padded to the largest
+//    (through a staging buffer, unpacked by two strided copies); exchange_path() below is the whole policy.  The group
+//    of ncclBroadcast calls of rounds 2-4 (root r sends its block in place) is kept as a selectable fallback.
 //  * one process driving several devices (the reference's multiGPUs(n) model, cuhe/CuHE.cu:217-256): peer copies over
 //    xGMI ordered by events (cuhe_keyswitch.hip, cuhe_hip_mul_relin_sharded_inproc) -- every block goes straight over the
 //    link between its two devices, which is what a direct all-gather of 0.2-1.5 MiB blocks amounts to on a fully
@@ -58,10 +60,31 @@ inline const char *const *required_symbols() {
                                         "ncclAllGather", "ncclGetErrorString", nullptr};
     return names;
 }
+// how the CRT rows of a level travel (cuhe_hip_exchange_path reports it without a GPU)
+enum Path { kPathNone = 0, kPathAllGather = 1, kPathAllGatherPadded = 2, kPathBroadcastGroup = 3 };
+inline const char *path_name(int p) {
+    switch (p) {
+    case kPathNone: return "one rank: nothing to exchange";
+    case kPathAllGather: return "RCCL: one ncclAllGather, in place (equal blocks)";
+    case kPathAllGatherPadded: return "RCCL: one ncclAllGather of padded blocks through a staging buffer (unequal blocks)";
+    case kPathBroadcastGroup: return "RCCL: group of ncclBroadcast, one per rank's block, in place";
+    }
+    return "?";
+}
+// force: 0 / 1 = the policy, 2 = padded all-gather, 3 = broadcast group (tests and A/B runs; CUHE_EXCHANGE=allgather|padded|bcast)
+inline int exchange_path(int np, int nranks, int force) {
+    if (nranks <= 1 && force <= 0) return kPathNone;
+    if (force == 2) return kPathAllGatherPadded;
+    if (force == 3) return kPathBroadcastGroup;
+    if (np < nranks) return kPathBroadcastGroup;                    // a rank without a block: nothing to pad from
+    return np % nranks == 0 ? kPathAllGather : kPathAllGatherPadded;
+}
 struct State {
     ncclComm_t comm = nullptr; int nranks = 1, rank = 0;
-    bool force_exchange = false;          // tests: issue the grouped broadcast on a communicator of ONE rank too
+    int force_exchange = 0;               // tests: > 0 exchanges on a communicator of ONE rank too; 2 / 3 also pick the path (exchange_path)
     const char *last_path = "none yet"; long exchanges = 0;
+    long path_count[4] = {0, 0, 0, 0};    // exchanges per path (cuhe_hip_comm_info)
+    unsigned *stage = nullptr; size_t stage_words = 0; int stage_dev = -1;      // staging buffer of the padded all-gather
 };
 inline State &state() { static State s; return s; }
 

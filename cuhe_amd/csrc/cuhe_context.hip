@@ -385,6 +385,14 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
             return fail(CUHE_EINVAL, "ring degree %d needs the negacyclic representation: modulus x^n + 1, primes with 2 n p^2 < P%s", n,
                         G_.nc_mode == 0 ? " (and cuhe_hip_set_negacyclic(0) is in effect)" : "");
     }
+    // k_modswitch lifts (src - dirty) by a multiple of p in [2^42, 2^43) instead of branching on its sign: |src - dirty| < 2^32 +
+    // modMsg * p_t has to stay below 2^42 (the reference's int arithmetic wraps much earlier, Base.cu:1117-1123)
+    {
+        uint64_t pmax = 0;
+        for (uint32_t p : G_.primes) pmax = std::max<uint64_t>(pmax, p);
+        if ((uint64_t)q.modMsg * pmax + (1ull << 32) >= (1ull << 42))
+            return fail(CUHE_EINVAL, "modMsg=%d is too large for the modulus switch with %d-bit CRT primes (modMsg * p must stay below 2^42)", q.modMsg, q.logCrtPrime);
+    }
     G_.coeffModulus.assign(q.depth, BigU(1));                      // cuhe/Operations.cu:81-90
     for (int i = 0; i < q.depth; ++i)
         for (int j = 0; j < q.numCrtPrime - i; ++j) G_.coeffModulus[i].mul_small(G_.primes[j]);
@@ -424,7 +432,9 @@ int cuhe_hip_shutdown(void) {
         for (auto &kv : D.freeBlocks) hipFree(kv.second);
         for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) hipFree(kv.second);     // parked in stream order
         for (auto &kv : D.allocated) hipFree(kv.first);
+        std::set<hipStream_t> keep; keep.swap(D.ownStreams);       // streams outlive an initialisation (the gate scheduler keeps its workers' streams)
         D = DevCtx();
+        D.ownStreams.swap(keep);
     }
     G_.inited = false; G_.relin_ready = false; G_.allocator_on = false;
     ++G_.generation;
@@ -487,6 +497,8 @@ int cuhe_hip_alloc_counters(long long *out4) {
     for (int i = 0; i < 4; ++i) out4[i] = g_alloc_counters[i];
     return CUHE_OK;
 }
+// may the allocator touch this stream handle on its own?  (only handles known to be alive)
+static inline bool probeable(const DevCtx &D, hipStream_t st) { return st == nullptr || D.ownStreams.count(st) != 0; }
 void *cuhe_hip_malloc(int dev, size_t bytes) {
     if (set_dev(dev) != CUHE_OK) return nullptr;
     DevCtx &D = G_.dev[dev];
@@ -496,7 +508,7 @@ void *cuhe_hip_malloc(int dev, size_t bytes) {
         // a miss: blocks of this size parked in the order of a stream that has gone idle since are free (several streams
         // of one host thread under the gate scheduler, none of which is ever synchronised by the client)
         for (auto sb = D.streamBlocks.begin(); sb != D.streamBlocks.end();) {
-            if (sb->second.find(bytes) != sb->second.end() && hipStreamQuery(sb->first) == hipSuccess) {
+            if (sb->second.find(bytes) != sb->second.end() && probeable(D, sb->first) && hipStreamQuery(sb->first) == hipSuccess) {
                 for (auto &kv : sb->second) D.freeBlocks.insert(kv);
                 sb = D.streamBlocks.erase(sb);
             } else { (void)hipGetLastError(); ++sb; }
@@ -561,7 +573,7 @@ void *cuhe_hip_malloc_stream(int dev, size_t bytes, void *st) {
         // every such hand-over ends in hipMalloc (hundreds of microseconds, under the library's lock).
         if (D.freeBlocks.find(bytes) == D.freeBlocks.end()) {
             for (auto &other : D.streamBlocks) {
-                if (other.first == S(st)) continue;
+                if (other.first == S(st) || !probeable(D, other.first)) continue;
                 auto it = other.second.find(bytes);
                 if (it == other.second.end()) continue;
                 hipEvent_t ev = nullptr;
@@ -614,12 +626,17 @@ int cuhe_hip_stream_create(int dev, void **out) {
     CHK(set_dev(dev));
     hipStream_t s = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    { std::lock_guard<std::mutex> lk(G_.mu); G_.dev[dev].ownStreams.insert(s); }
     *out = (void *)s;
     return CUHE_OK;
 }
 int cuhe_hip_stream_destroy(int dev, void *st) {
     CHK(set_dev(dev));
-    if (st) { HIPCHK(hipStreamSynchronize(S(st))); settle_stream_blocks(G_.dev[dev], S(st)); HIPCHK(hipStreamDestroy(S(st))); }
+    if (st) {
+        HIPCHK(hipStreamSynchronize(S(st))); settle_stream_blocks(G_.dev[dev], S(st));
+        { std::lock_guard<std::mutex> lk(G_.mu); G_.dev[dev].ownStreams.erase(S(st)); }
+        HIPCHK(hipStreamDestroy(S(st)));
+    }
     return CUHE_OK;
 }
 int cuhe_hip_stream_sync(int dev, void *st) {

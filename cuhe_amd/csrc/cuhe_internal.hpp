@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -127,6 +128,8 @@ struct DevCtx {
     std::map<void *, size_t> allocated;
     size_t cachedBytes = 0;              // bytes parked in freeBlocks and streamBlocks
     std::map<hipStream_t, std::multimap<size_t, void *>> streamBlocks;   // freed in stream order, not yet synchronised
+    std::set<hipStream_t> ownStreams;    // streams made by cuhe_hip_stream_create (and not destroyed yet): the only ones, besides the null stream, the allocator
+                                         // queries or records on by itself -- a client's own handle may have been destroyed behind the library's back
     std::vector<hipEvent_t> fenceEvents;                                  // hand-over of a parked block to another stream (cuhe_hip_malloc_stream)
 };
 

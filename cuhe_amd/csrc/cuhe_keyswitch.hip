@@ -871,12 +871,14 @@ int cuhe_hip_comm_init(int nranks, int rank, const void *id128) {
 int cuhe_hip_comm_destroy(void) {
     comm::State &C = comm::state();
     if (C.comm) { comm::api().CommDestroy(C.comm); C.comm = nullptr; }
-    C.nranks = 1; C.rank = 0; C.force_exchange = false;
+    if (C.stage) { (void)hipFree(C.stage); C.stage = nullptr; C.stage_words = 0; C.stage_dev = -1; }
+    C.nranks = 1; C.rank = 0; C.force_exchange = 0; C.exchanges = 0; C.last_path = "none yet";
+    for (long &n : C.path_count) n = 0;
     return CUHE_OK;
 }
 int cuhe_hip_comm_size(void) { return comm::state().nranks; }
 int cuhe_hip_comm_rank(void) { return comm::state().rank; }
-int cuhe_hip_comm_force_exchange(int on) { comm::state().force_exchange = on != 0; return CUHE_OK; }
+int cuhe_hip_comm_force_exchange(int on) { comm::state().force_exchange = on < 0 ? 0 : on; return CUHE_OK; }
 // what RCCL itself reports about the communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion) and which path the
 // last exchange of CRT rows took: the first thing to read when a multi-GPU run misbehaves
 int cuhe_hip_comm_info(char *buf, size_t cap) {
@@ -888,36 +890,70 @@ int cuhe_hip_comm_info(char *buf, size_t cap) {
     if (A.GetVersion) A.GetVersion(&ver);
     if (C.comm && A.CommCount) A.CommCount(C.comm, &cnt);
     if (C.comm && A.CommUserRank) A.CommUserRank(C.comm, &urank);
-    snprintf(buf, cap, "rccl %d; communicator %s; ncclCommCount %d, ncclCommUserRank %d (library: %d ranks, rank %d); exchanges so far %ld, last: %s",
-             ver, C.comm ? "initialised" : "not initialised", cnt, urank, C.nranks, C.rank, C.exchanges, C.last_path);
+    snprintf(buf, cap, "rccl %d; communicator %s; ncclCommCount %d, ncclCommUserRank %d (library: %d ranks, rank %d); exchanges so far %ld "
+             "(ncclAllGather in place %ld, padded %ld, broadcast group %ld), last: %s",
+             ver, C.comm ? "initialised" : "not initialised", cnt, urank, C.nranks, C.rank, C.exchanges, C.path_count[1], C.path_count[2], C.path_count[3], C.last_path);
     return CUHE_OK;
 }
+// which form the exchange of a level takes for a communicator of `nranks` ranks (comm::exchange_path): 0 none, 1 one in-place
+// ncclAllGather, 2 one ncclAllGather of padded blocks, 3 the group of broadcasts.  Host logic only: no GPU, no RCCL needed.
+int cuhe_hip_exchange_path(int lvl, int nranks, int force) {
+    if (!G_.params_set || lvl < 0 || lvl >= G_.prm.depth || nranks < 1) return fail(CUHE_EINVAL, "exchange_path(lvl %d, nranks %d)", lvl, nranks), -1;
+    return comm::exchange_path(G_.prm.numCrtPrimeAt(lvl), nranks, force);
+}
 // rows: u32[np][crtLen] of level lvl on this rank's device, the rank's own block already in place; on return (in stream
-// order) every block is.  A group of broadcasts, root r sending its block in place, because the blocks differ in size
-// when np is not a multiple of the number of ranks.
+// order) every block is.  ONE ncclAllGather: in place when the blocks are equal; of blocks padded to the largest, through a
+// staging buffer and two strided copies, when they are not (np not a multiple of the number of ranks).
 int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *st) {
     CHK(need_init(dev));
     if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     comm::State &C = comm::state();
-    if (C.nranks == 1 && !(C.force_exchange && C.comm)) { C.last_path = "one rank: nothing to exchange"; return CUHE_OK; }
+    int force = C.comm ? C.force_exchange : 0;
+    if (const char *e = getenv("CUHE_EXCHANGE")) { if (!strcmp(e, "padded")) force = 2; else if (!strcmp(e, "bcast")) force = 3; }
+    const int np = G_.prm.numCrtPrimeAt(lvl), cl = G_.prm.crtLen;
+    const int path = comm::exchange_path(np, C.nranks, force);
+    if (path == comm::kPathNone) { C.last_path = comm::path_name(path); return CUHE_OK; }
     if (!C.comm) return fail(CUHE_ENOTINIT, "cuhe_hip_comm_init has not been called");
     comm::Api &A = comm::api();
-    const int np = G_.prm.numCrtPrimeAt(lvl), cl = G_.prm.crtLen;
     // every failing call is named with its rank, root and RCCL's own message: the first multi-GPU contact must explain itself
-    ncclResult_t r = A.GroupStart();
-    if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupStart: %s", C.rank, C.nranks, A.GetErrorString(r));
-    int bad_root = -1;
-    for (int rk = 0; rk < C.nranks && r == ncclSuccess; ++rk) {
-        int f, c; comm::shard_bounds(np, C.nranks, rk, &f, &c);
-        if (c == 0) continue;
-        u32 *blk = rows + (size_t)f * cl;
-        r = A.Broadcast(blk, blk, (size_t)c * cl, ncclUint32, rk, C.comm, S(st));
-        if (r != ncclSuccess) bad_root = rk;
+    if (path == comm::kPathAllGather) {
+        const size_t cnt = (size_t)(np / C.nranks) * cl;           // in place: this rank's block sits at rows + rank * cnt
+        const ncclResult_t r = A.AllGather(rows + (size_t)C.rank * cnt, rows, cnt, ncclUint32, C.comm, S(st));
+        if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclAllGather(%zu words per rank): %s", C.rank, C.nranks, cnt, A.GetErrorString(r));
+    } else if (path == comm::kPathAllGatherPadded) {
+        const int base = np / C.nranks, extra = np % C.nranks, maxc = base + (extra ? 1 : 0);
+        const size_t slot = (size_t)maxc * cl, need = slot * C.nranks;
+        if (C.stage_words < need || C.stage_dev != dev) {          // grow-only; a re-allocation waits for the device (hipFree), as every workspace does
+            if (C.stage) { HIPCHK(hipFree(C.stage)); C.stage = nullptr; C.stage_words = 0; }
+            HIPCHK(hipMalloc((void **)&C.stage, need * sizeof(u32)));
+            C.stage_words = need; C.stage_dev = dev;
+        }
+        int f, c; comm::shard_bounds(np, C.nranks, C.rank, &f, &c);
+        u32 *mine = C.stage + (size_t)C.rank * slot;
+        HIPCHK(hipMemcpyAsync(mine, rows + (size_t)f * cl, (size_t)c * cl * sizeof(u32), hipMemcpyDeviceToDevice, S(st)));
+        const ncclResult_t r = A.AllGather(mine, C.stage, slot, ncclUint32, C.comm, S(st));
+        if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclAllGather(padded, %zu words per rank): %s", C.rank, C.nranks, slot, A.GetErrorString(r));
+        // unpack: the first `extra` ranks hold base + 1 rows each, the others base rows: two strided copies (the own block is rewritten with itself)
+        const size_t pitch = slot * sizeof(u32);
+        if (extra) HIPCHK(hipMemcpy2DAsync(rows, (size_t)(base + 1) * cl * sizeof(u32), C.stage, pitch, (size_t)(base + 1) * cl * sizeof(u32), extra, hipMemcpyDeviceToDevice, S(st)));
+        if (base) HIPCHK(hipMemcpy2DAsync(rows + (size_t)extra * (base + 1) * cl, (size_t)base * cl * sizeof(u32), C.stage + (size_t)extra * slot, pitch,
+                                         (size_t)base * cl * sizeof(u32), C.nranks - extra, hipMemcpyDeviceToDevice, S(st)));
+    } else {
+        ncclResult_t r = A.GroupStart();
+        if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupStart: %s", C.rank, C.nranks, A.GetErrorString(r));
+        int bad_root = -1;
+        for (int rk = 0; rk < C.nranks && r == ncclSuccess; ++rk) {
+            int f, c; comm::shard_bounds(np, C.nranks, rk, &f, &c);
+            if (c == 0) continue;
+            u32 *blk = rows + (size_t)f * cl;
+            r = A.Broadcast(blk, blk, (size_t)c * cl, ncclUint32, rk, C.comm, S(st));
+            if (r != ncclSuccess) bad_root = rk;
+        }
+        const ncclResult_t e = A.GroupEnd();
+        if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclBroadcast(root %d): %s", C.rank, C.nranks, bad_root, A.GetErrorString(r));
+        if (e != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupEnd: %s", C.rank, C.nranks, A.GetErrorString(e));
     }
-    const ncclResult_t e = A.GroupEnd();
-    if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclBroadcast(root %d): %s", C.rank, C.nranks, bad_root, A.GetErrorString(r));
-    if (e != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupEnd: %s", C.rank, C.nranks, A.GetErrorString(e));
-    C.last_path = "RCCL: group of ncclBroadcast, one per rank's block, in place"; ++C.exchanges;
+    C.last_path = comm::path_name(path); ++C.exchanges; ++C.path_count[path];
     return CUHE_OK;
 }
 // cAnd + relin with the level's primes sharded over the ranks of the communicator: a_own, b_own = ct rows of the rank's

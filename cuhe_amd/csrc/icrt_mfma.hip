@@ -13,13 +13,17 @@ static int launch_tiles(u32 *dst, const u32 *src, const DevCtx &D, const IcrtLev
     if (lds > 64 * 1024) CHK(once.set(k_icrt_mfma<TILES>, 160 * 1024));
     // resident workgroups loop over the tiles (32 coefficients each, a wave per tile): the 30 KB of constants are staged once
     const long tiles = (long)((q.modLen + kIcrtMfmaTile - 1) / kIcrtMfmaTile) * batch, wgs = (tiles + 3) / 4;
-    static std::atomic<int> occ{0};                 // resident workgroups per CU (registers and LDS): asked once per instantiation
-    int per_cu = occ.load(std::memory_order_relaxed);
+    // resident workgroups per CU (registers and LDS).  The LDS size follows the level (ksteps), so the answer is kept per
+    // K-step count of this instantiation (one cached value served launches with another LDS size); devices of one
+    // process are the same part.  Performance only: the kernel walks its tiles with a grid stride.
+    static std::atomic<int> occ[64];
+    const int slot = I.ksteps >= 0 && I.ksteps < 64 ? I.ksteps : 0;
+    int per_cu = occ[slot].load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_icrt_mfma<TILES>, kIcrtMfmaThreads, lds));
         per_cu = std::max(nb, 1);
-        occ.store(per_cu, std::memory_order_relaxed);
+        occ[slot].store(per_cu, std::memory_order_relaxed);
     }
     const long resident = (long)std::max(D.cus, 1) * per_cu;
     const dim3 grid((unsigned)std::min(wgs, resident)), block(kIcrtMfmaThreads);

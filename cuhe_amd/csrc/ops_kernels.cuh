@@ -169,7 +169,7 @@ void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt
         const u32 p = pt.p[i];
         const u64 m = pt.pinv[i];
         const u32 inv = invp[(np - 1) * (np - 2) / 2 + i];
-        const u64 lift = (u64)p << (11 + __clz(p));                  // a multiple of p in [2^42, 2^43): above every |src - dirty| (< 2^32 + modmsg 2^31)
+        const u64 lift = (u64)p << (11 + __clz(p));                  // a multiple of p in [2^42, 2^43): above every |src - dirty| (< 2^32 + modmsg p_t < 2^42: checked by cuhe_hip_init)
         u32 x[VEC], r[VEC];
         if (VEC == 4) { const uint4 v = *reinterpret_cast<const uint4 *>(src + (long)i * clen + idx); x[0] = v.x; x[1 % VEC] = v.y; x[2 % VEC] = v.z; x[3 % VEC] = v.w; }
         else x[0] = src[(long)i * clen + idx];

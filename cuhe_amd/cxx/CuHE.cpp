@@ -301,6 +301,7 @@ CuPolynomial::~CuPolynomial() { reset(); }
 // ---- attached / detached (scheduled mode)
 bool CuPolynomial::scheduled() {
 	if (sched::inWorker()) return false;                        // a recorded gate running on the scheduler-side objects
+	if (!schedulable()) return false;                           // a client's own subclass: no scheduler-side twin can be made of it
 	if (sched::on()) return true;
 	if (node_) schedDetach();                                   // the mode was switched off: back to a plain object
 	return false;

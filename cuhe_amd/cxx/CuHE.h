@@ -84,7 +84,11 @@ public:
 	bool scheduled();                // true: record the operation instead of running it (detaches first when the mode is off)
 protected:
 	friend struct SchedAccess;
-	virtual CuPolynomial *newSameKind() const = 0;
+	// (scheduled mode) a fresh object of the same dynamic type for the scheduler's side.  Not pure: the reference's class has no such
+	// member (cuhe/CuHE.h:45-110), so a client's own subclass of CuPolynomial keeps compiling -- it simply is not schedulable and
+	// its conversions run at once on the calling thread, in scheduled mode too.
+	virtual CuPolynomial *newSameKind() const { return NULL; }
+	virtual bool schedulable() const { return false; }
 	virtual void moveStateFrom(CuPolynomial &other);
 	void schedRelease();             // let go of the node: its buffers are released by a recorded task
 	void z2r(cudaStream_t st = 0);   // ZZX -> RAW
@@ -123,6 +127,7 @@ public:
 protected:
 	friend struct SchedAccess;
 	CuPolynomial *newSameKind() const { return new CuCtxt; }
+	bool schedulable() const { return true; }
 	void moveStateFrom(CuPolynomial &other);
 	int level_;
 };
@@ -136,6 +141,7 @@ public:
 	size_t nRepSize();
 protected:
 	CuPolynomial *newSameKind() const { return new CuPtxt; }
+	bool schedulable() const { return true; }
 };
 
 // initialisation: setParameters first, then (optionally) multiGPUs, then initCuHE.

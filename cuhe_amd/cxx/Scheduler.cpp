@@ -85,21 +85,20 @@ void unrefNode(Node *n, std::vector<CuPolynomial *> &dead) {
 // readers of a node that is never written (a key bit read by every round) would pile up: of the readers that have been
 // issued, the last one per stream stands for the earlier ones of that stream
 void pruneReaders(Node *n) {               // mu held
-	size_t keep = 0;
 	const std::vector<Task *> all = n->readers;
+	std::vector<char> shadowed(all.size(), 0);
 	for (size_t i = 0; i < all.size(); ++i) {
 		Task *r = all[i];
-		bool shadowed = false;
-		if (r->issued)
-			for (size_t j = 0; j < all.size() && !shadowed; ++j) {
-				Task *o = all[j];
-				shadowed = j != i && o->issued && o->ss == r->ss && (o->seq > r->seq || (o->seq == r->seq && j > i));
-			}
-		if (!shadowed) n->readers[keep++] = r;
+		if (!r->issued) continue;
+		for (size_t j = 0; j < all.size() && !shadowed[i]; ++j) {
+			Task *o = all[j];
+			shadowed[i] = j != i && o->issued && o->ss == r->ss && (o->seq > r->seq || (o->seq == r->seq && j > i));
+		}
 	}
-	n->readers.resize(keep);
-	for (size_t i = 0; i < all.size(); ++i)
-		if (std::find(n->readers.begin(), n->readers.end(), all[i]) == n->readers.end()) unrefTask(all[i]);
+	// one reference per ENTRY (submit() enters a task once per node, but the count must not depend on that: ADVICE r04)
+	n->readers.clear();
+	for (size_t i = 0; i < all.size(); ++i) if (!shadowed[i]) n->readers.push_back(all[i]);
+	for (size_t i = 0; i < all.size(); ++i) if (shadowed[i]) unrefTask(all[i]);
 }
 // stream `s` (of device `dev`) waits until task #seq of `from` has finished; returns the number of events recorded (0 or 1)
 int orderAfter(int dev, void *s, StreamState *from, long seq) {
@@ -389,6 +388,7 @@ void setBatchRunner(BatchRunner r, int mb) {
 }
 Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep, int kind, long key, Node *subject,
              Node *op1, Node *op2) {
+	if (dev < 0) dev = 0;                       // (an object that was never placed: its task only releases host state)
 	Task *t = new Task;
 	t->fn = std::move(fn); t->dev = dev; t->kind = kind; t->key = key; t->subject = subject; t->op1 = op1; t->op2 = op2;
 	std::lock_guard<std::mutex> lk(mu);
@@ -404,6 +404,7 @@ Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *
 	for (Node *w : writes) { after(w->lastWrite); for (Task *r : w->readers) after(r); }
 	for (Node *r : reads) {
 		if (written(r)) continue;
+		if (!r->readers.empty() && r->readers.back() == t) continue;      // listed twice (cAnd(out, x, x)): one entry, one reference
 		if (r->readers.size() >= 24) pruneReaders(r);
 		r->readers.push_back(t); ++t->refs;
 	}

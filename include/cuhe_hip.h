@@ -304,11 +304,18 @@ int cuhe_hip_comm_destroy(void);
 int cuhe_hip_comm_size(void);
 int cuhe_hip_comm_rank(void);
 /* diagnostics for the first contact with N > 1 GPUs: what RCCL itself reports about the communicator (version, ncclCommCount,
-   ncclCommUserRank) beside the library's view, and which path the last exchange of CRT rows took.  comm_force_exchange(1): tests --
-   issue the grouped broadcast on a communicator of ONE rank too (by default one rank has nothing to exchange). */
+   ncclCommUserRank) beside the library's view, how many exchanges took which path and which the last one took.
+   comm_force_exchange(on): tests -- on > 0 runs the exchange on a communicator of ONE rank too (by default one rank has nothing
+   to exchange); 1 = the policy below, 2 = the padded all-gather, 3 = the group of broadcasts; 0 = off. */
 int cuhe_hip_comm_info(char *buf, size_t cap);
 int cuhe_hip_comm_force_exchange(int on);
-/* rows = u32[np][crtLen] of level lvl with this rank's block in place -> every block in place (stream ordered) */
+/* the form the exchange of level lvl takes on nranks ranks: 0 none (one rank), 1 ONE in-place ncclAllGather (blocks equal: the
+   level's primes are a multiple of nranks), 2 ONE ncclAllGather of blocks padded to the largest (staging buffer + two strided
+   copies), 3 a group of ncclBroadcast (only when a rank owns no prime, or forced).  Host logic, no GPU: the policy is testable
+   for every (level, nranks).  force as in comm_force_exchange.  -1 on bad arguments. */
+int cuhe_hip_exchange_path(int lvl, int nranks, int force);
+/* rows = u32[np][crtLen] of level lvl with this rank's block in place -> every block in place (stream ordered): the one
+   collective of the sharded multiply ("RCCL all-gather only at the ICRT recombine step") */
 int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *stream);
 /* a_own, b_own: ct rows of the rank's primes u64[count][ct_len]; dst_own: reduced CRT rows u32[count][crtLen] */
 int cuhe_hip_mul_relin_sharded(uint32_t *dst_own, const uint64_t *a_own, const uint64_t *b_own, int lvl, int dev, void *stream);

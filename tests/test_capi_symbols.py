@@ -139,3 +139,52 @@ def test_rccl_symbols_of_comm_hpp_resolve_in_the_image():
         assert hasattr(lib, n), "librccl lacks " + n
     ver = C.c_int(0)
     assert lib.ncclGetVersion(C.byref(ver)) == 0 and ver.value > 20000
+
+
+def test_reference_library_names_exist(capi):
+    """The reference's build files produce a static `cuHE` and a shared `cuHEShared` and its examples look for the latter
+    (cuhe/CMakeLists.txt:25,38; examples/DHS/CMakeLists.txt:14): both names exist beside libcuHE.so and carry the C++ API."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cuhe_amd", "cxx"), "-s"])
+    lib = os.path.join(ROOT, "cuhe_amd", "lib")
+    for name in ("libcuHE.so", "libcuHEShared.so"):
+        syms = subprocess.run(["nm", "-D", "-C", "--defined-only", os.path.join(lib, name)], capture_output=True, text=True, check=True).stdout
+        assert "cuHE::initCuHE" in syms and "cuHE::setParameters" in syms and "cuHE::multiGPUs" in syms, name
+    members = subprocess.run(["ar", "t", os.path.join(lib, "libcuHE.a")], capture_output=True, text=True, check=True).stdout.split()
+    assert sorted(members) == ["CuHE.o", "Scheduler.o", "Utils.o"]
+
+
+def test_exchange_path_policy_for_every_level_of_config4(capi, golden):
+    """SURVEY 8(e) / VERDICT r04 item 4: the one exchange of the sharded multiply is an RCCL all-gather.  Host logic of
+    cuhe_hip_allgather_rows, without a GPU: for every level of config 4 (both rings) and 1 ... 9 ranks the policy picks ONE in-place
+    ncclAllGather when the level's primes split evenly, ONE padded ncclAllGather otherwise, the broadcast group only when a rank
+    would own no prime; one rank exchanges nothing unless forced."""
+    lib = capi.lib
+    for args in ([25, 2, 16, 576, 24, 65536], [25, 2, 16, 552, 23, 131072]):
+        lib.cuhe_hip_reset_parameters()
+        capi.check(lib.cuhe_hip_set_parameters(*args))
+        depth = capi.get_params().depth
+        assert depth == 25
+        seen = set()
+        for lvl in range(depth):
+            np_ = lib.cuhe_hip_num_crt_prime(lvl)
+            assert lib.cuhe_hip_exchange_path(lvl, 1, 0) == 0
+            assert lib.cuhe_hip_exchange_path(lvl, 1, 1) == 1          # forced on one rank: equal blocks by definition
+            for nranks in range(2, 10):
+                want = 3 if np_ < nranks else (1 if np_ % nranks == 0 else 2)
+                assert lib.cuhe_hip_exchange_path(lvl, nranks, 0) == want, (lvl, np_, nranks)
+                assert lib.cuhe_hip_exchange_path(lvl, nranks, 2) == 2 and lib.cuhe_hip_exchange_path(lvl, nranks, 3) == 3
+                seen.add(want)
+                # the blocks the paths move: contiguous, balanced, covering
+                import ctypes as C2
+                at = 0
+                for r in range(nranks):
+                    f, c = C2.c_int(), C2.c_int()
+                    capi.check(lib.cuhe_hip_shard_bounds(lvl, nranks, r, C2.byref(f), C2.byref(c)))
+                    assert f.value == at and c.value in (np_ // nranks, np_ // nranks + 1)
+                    at += c.value
+                assert at == np_
+        assert lib.cuhe_hip_exchange_path(0, 2, 0) == 1 and lib.cuhe_hip_exchange_path(0, 4, 0) == 1 and lib.cuhe_hip_exchange_path(0, 8, 0) == 1
+        assert seen >= {1, 2}
+        assert lib.cuhe_hip_exchange_path(depth, 2, 0) == -1
+    lib.cuhe_hip_reset_parameters()

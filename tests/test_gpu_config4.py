@@ -171,10 +171,12 @@ def test_sharded_multiply_at_config4_size_on_2_4_5_8_virtual_devices(gu):
 
 def test_sharded_multiply_through_rccl_on_one_rank_at_config4_size(gu):
     """cuhe_hip_mul_relin_sharded (the one-process-per-GPU form) at the FULL config-4 size through a communicator of one rank
-    with the exchange FORCED (cuhe_hip_comm_force_exchange): librccl is opened, the communicator made, and the grouped
-    ncclBroadcast of the CRT rows really runs on the compute stream between the two stages -- everything the N > 1 path does
-    except a second GPU.  Result against exact integers (a * b * s with sparse b and s), two levels, twice per buffer set;
-    cuhe_hip_comm_info must report what RCCL says about the communicator and that the RCCL path was taken."""
+    with the exchange FORCED (cuhe_hip_comm_force_exchange): librccl is opened, the communicator made, and the collective on
+    the CRT rows really runs on the compute stream between the two stages -- everything the N > 1 path does except a second
+    GPU.  All three forms of the exchange run: the in-place ncclAllGather the policy picks for equal blocks, the padded
+    ncclAllGather (staging buffer + strided unpack) and the broadcast group.  Result against exact integers (a * b * s with
+    sparse b and s), two levels, twice per buffer set; cuhe_hip_comm_info must report what RCCL says about the communicator and
+    which paths were taken."""
     lib, ck = gu.lib, gu.ck
     g = gu.GpuCtx(*RINGS["x^32768+1"])
     try:
@@ -204,14 +206,18 @@ def test_sharded_multiply_through_rccl_on_one_rank_at_config4_size(gu):
             ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), gu.to_dev(a).data_ptr(), logq, 0, None))
             ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), gu.to_dev(b).data_ptr(), logq, 0, None))
             out = gu.empty_u32(npr, q.crtLen)
-            for rep in range(2):
-                out.zero_()
-                ck(lib.cuhe_hip_mul_relin_sharded(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, 0, None))
-                ck(lib.cuhe_hip_stream_sync(0, None))
-                assert np.array_equal(gu.host_u32(out)[:, :n].astype(np.uint64), want), (lvl, rep)
+            for force in (1, 2, 3):                        # the policy (one rank: equal blocks -> in place), padded, broadcast group
+                ck(lib.cuhe_hip_comm_force_exchange(force))
+                assert lib.cuhe_hip_exchange_path(lvl, 1, force) == force
+                for rep in range(2):
+                    out.zero_()
+                    ck(lib.cuhe_hip_mul_relin_sharded(out.data_ptr(), na.data_ptr(), nb.data_ptr(), lvl, 0, None))
+                    ck(lib.cuhe_hip_stream_sync(0, None))
+                    assert np.array_equal(gu.host_u32(out)[:, :n].astype(np.uint64), want), (lvl, force, rep)
         ck(lib.cuhe_hip_comm_info(info, 512))
         txt = info.value.decode()
-        assert "ncclCommCount 1" in txt and "ncclCommUserRank 0" in txt and "exchanges so far 4" in txt and "ncclBroadcast" in txt, txt
+        assert "ncclCommCount 1" in txt and "ncclCommUserRank 0" in txt and "exchanges so far 12" in txt, txt
+        assert "ncclAllGather in place 4, padded 4, broadcast group 4" in txt and "ncclBroadcast" in txt, txt
     finally:
         lib.cuhe_hip_comm_destroy()
         g.close()
