@@ -58,6 +58,121 @@ def kernel_sha16():
     return h.hexdigest()[:16]
 
 
+class SmiSampler:
+    """Shader clock and socket power of one GPU sampled from a background thread while a load runs (the
+    limiter of the transforms -- integer issue under the chip's power limit -- belongs in the driver-run record, not in a
+    builder-side microbenchmark).  Sources, in order: the amdsmi python binding of the ROCm image, then the amdgpu sysfs files;
+    neither present -> every figure is None and `source` says so.  Nothing here touches the GPU's queues."""
+
+    def __init__(self, index):
+        import threading
+        self.index, self.source, self.samples, self._stop, self._thr = index, None, [], threading.Event(), None
+        self._read = None
+        try:
+            sys.path.append("/opt/rocm/share/amd_smi")
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[index]
+
+            def read():
+                clk = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                pw = amdsmi.amdsmi_get_power_info(h)
+                w = pw.get("current_socket_power", pw.get("average_socket_power", pw.get("socket_power")))
+                return (float(clk.get("clk", clk.get("cur_clk"))), float(w) if isinstance(w, (int, float)) else None)
+            read()
+            self._read, self.source = read, "amdsmi"
+        except Exception as ex:
+            self._err = repr(ex)[:120]
+        if self._read is None:
+            try:
+                cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+                base = os.path.dirname(cards[index])
+                hw = (glob.glob(os.path.join(base, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(base, "hwmon", "hwmon*", "power1_input")) + [None])[0]
+
+                def read():
+                    mhz = None
+                    for line in open(os.path.join(base, "pp_dpm_sclk")):
+                        if "*" in line:
+                            mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                    return (mhz, float(open(hw).read()) / 1e6 if hw else None)
+                read()
+                self._read, self.source = read, "sysfs"
+            except Exception as ex:
+                self._err = getattr(self, "_err", "") + " | " + repr(ex)[:120]
+
+    def _loop(self, period):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                pass
+            self._stop.wait(period)
+
+    def start(self, period=0.01):
+        import threading
+        self.samples = []
+        self._stop.clear()
+        if self._read:
+            self._thr = threading.Thread(target=self._loop, args=(period,), daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thr:
+            self._thr.join()
+            self._thr = None
+        return self.summary(self.samples)
+
+    def idle(self):
+        try:
+            return self.summary([self._read()]) if self._read else None
+        except Exception:
+            return None
+
+    @staticmethod
+    def summary(samples):
+        def stat(vals):
+            vals = [v for v in vals if v is not None]
+            return {"mean": round(sum(vals) / len(vals), 1), "min": round(min(vals), 1), "max": round(max(vals), 1)} if vals else None
+        return {"samples": len(samples), "sclk_mhz": stat([c for c, _ in samples]), "socket_power_w": stat([w for _, w in samples])}
+
+
+def measure_limiter(lib, ck, torch, step, local_rank, seconds=1.0):
+    """what the chip does under (a) the timed step itself and (b) a dense stream of the 64-bit integer instructions the field
+    arithmetic lowers to, both for about `seconds`: shader clock and socket power from the SMI, the dense stream's sustained
+    rate and clock from the library's probe kernel (cuhe_hip_probe_valu, s_memtime of its own waves)."""
+    out = {"source": None}
+    smi = SmiSampler(local_rank)
+    out["source"] = smi.source or ("unavailable: " + getattr(smi, "_err", "no amdsmi, no sysfs"))
+    torch.cuda.synchronize()
+    time.sleep(0.25)
+    out["idle"] = smi.idle()
+    # (a) the benchmarked step, back to back
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); step(); torch.cuda.synchronize(); one = max(time.perf_counter() - t0, 1e-4)
+    n = max(3, int(seconds / one))
+    smi.start()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    rec = smi.stop()
+    rec.update({"steps": n, "seconds": round(wall, 3), "ms_per_step": round(wall / n * 1e3, 4)})
+    out["under_the_timed_step"] = rec
+    # (b) the dense instruction stream at the occupancies the transforms run at
+    dense = {}
+    for wps in (2, 4):
+        r, mhz, cyc = C.c_double(0), C.c_double(0), C.c_double(0)
+        smi.start()
+        ck(lib.cuhe_hip_probe_valu(0, wps, int(seconds * 500), C.byref(r), C.byref(mhz), C.byref(cyc)))
+        rec = smi.stop()
+        rec.update({"lane_instructions_T_per_s": round(r.value / 1e12, 2), "shader_mhz_from_s_memtime": round(mhz.value, 1), "cycles_per_wave_instruction_per_simd": round(cyc.value, 3)})
+        dense["%d_waves_per_simd" % wps] = rec
+    out["dense_64bit_integer_stream"] = dense
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +200,7 @@ def main():
                          "the other ring is reported beside it unless --one-ring")
     ap.add_argument("--one-ring", action="store_true")
     ap.add_argument("--no-prince", action="store_true")
+    ap.add_argument("--no-limiter", action="store_true", help="skip the ~3 s clock / power / dense-stream measurement (roofline.valu_ceiling.live)")
     ap.add_argument("--perf-table", default="", help="write the bundle-size table of doc/Perf_NTT.txt (tests/test_ntt.cu:140-151) to this file and exit")
     args = ap.parse_args()
     args.relin_params = RING_PARAMS[args.ring]
@@ -238,6 +354,12 @@ def main():
                     "algorithmic_bytes_per_transform": alg_bytes,
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),
                     "pass1_ms_per_batch": round(ms1.value / iters, 4), "pass2_ms_per_batch": round(ms2.value / iters, 4)}
+        limiter = None
+        if not args.no_limiter:
+            try:
+                limiter = measure_limiter(lib, ck, torch, step, local_rank)
+            except Exception as ex:
+                limiter = {"error": repr(ex)[:300]}
         if lane_instr:
             # the limiter that actually binds: integer VALU issue under the chip's power limit.  Dense
             # streams of these instructions saturate near 36.5 T lane-instructions/s (profiles/r02_valu_cost_model.txt)
@@ -246,6 +368,13 @@ def main():
             roofline["valu_ceiling"] = {"lane_instructions_per_transform": lane_instr, "achieved_T_per_s": round(got, 2),
                                         "dense_stream_ceiling_T_per_s": ceil_t, "frac_of_dense_stream_ceiling": round(got / ceil_t, 3) if ceil_t else None,
                                         "note": "ceiling = pure v_lshl_add_u64 / v_mad_u64_u32 / v_cmp_u64 streams at 4 waves per SIMD (profiles/r02_valu_cost_model.txt)"}
+        if limiter is not None:
+            # measured IN THIS RUN: clock and power under the timed step and under the dense stream, the dense stream's own rate
+            vc = roofline.setdefault("valu_ceiling", {})
+            vc["live"] = limiter
+            d4 = (limiter.get("dense_64bit_integer_stream") or {}).get("4_waves_per_simd") or {}
+            if lane_instr and d4.get("lane_instructions_T_per_s"):
+                vc["frac_of_live_dense_stream"] = round(n_tr * lane_instr / pair_s / 1e12 / d4["lane_instructions_T_per_s"], 3)
 
         # ---- the shorter zero-padded transforms of the reference contract (cuhe/Base.cu:309-437, 492-608): same bytes per step
         # as the 64K-point batch.  Their sub-transforms of 16K / 8K points run in the one-workgroup form (ntt_onewg.cuh)
@@ -283,10 +412,13 @@ def main():
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
-            xs = src[:4].cpu().numpy().view(np.uint32)
-            got = dst[:4].cpu().numpy().view(np.uint64)
-            for b in range(2):
-                assert np.array_equal(got[b], O.ntt_ext(xs[b], L)), "GPU NTT differs from the oracle"
+            # rows of the first round, of the middle of the persistent walk and the last one (both halves of a rendezvous pair)
+            checked_rows = sorted({0, 1, B // 2, B // 2 + 1, B - 2, B - 1} & set(range(B)))
+            for b in checked_rows:
+                xs = src[b].cpu().numpy().view(np.uint32)
+                got = dst[b].cpu().numpy().view(np.uint64)
+                assert np.array_equal(got, O.ntt_ext(xs, L)), "GPU NTT differs from the oracle (row %d of %d)" % (b, B)
+            roofline["checked_rows_vs_oracle"] = checked_rows
         if not args.no_cpu and world == 1:              # rank 0 at N = 1 only (torchrun pins OMP_NUM_THREADS=1 per rank)
             # ---- CPU baseline: the oracle's O(L log L) transform on the host cores, bounded sample
             cores = os.cpu_count() or 1

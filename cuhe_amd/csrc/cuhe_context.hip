@@ -665,6 +665,63 @@ int cuhe_hip_event_query(int dev, void *ev) {
     return fail(CUHE_EHIP, "hipEventQuery failed : %s", hipGetErrorString(e));
 }
 
+// ---- cuhe_hip_probe_valu: the dense 64-bit integer stream the transforms are measured against (include/cuhe_hip.h)
+}  // extern "C"
+namespace {
+constexpr int kProbeIters = 2048;          // x 24 wave-instructions
+__global__ __launch_bounds__(256) void k_probe_valu(unsigned *out, unsigned long long *ticks, unsigned seed) {
+    unsigned a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;
+    unsigned long long b0 = a0, b1 = a1, b2 = a2, b3 = a3, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < kProbeIters; ++i) {
+        asm volatile("v_mad_u64_u32 %8, vcc, %0, %1, %8\n v_mad_u64_u32 %9, vcc, %1, %2, %9\n v_mad_u64_u32 %10, vcc, %2, %3, %10\n v_mad_u64_u32 %11, vcc, %3, %4, %11\n"
+                     "v_mad_u64_u32 %12, vcc, %4, %5, %12\n v_mad_u64_u32 %13, vcc, %5, %6, %13\n v_mad_u64_u32 %14, vcc, %6, %7, %14\n v_mad_u64_u32 %15, vcc, %7, %0, %15\n"
+                     "v_lshl_add_u64 %8, %8, 0, %9\n v_lshl_add_u64 %9, %9, 0, %10\n v_lshl_add_u64 %10, %10, 0, %11\n v_lshl_add_u64 %11, %11, 0, %12\n"
+                     "v_lshl_add_u64 %12, %12, 0, %13\n v_lshl_add_u64 %13, %13, 0, %14\n v_lshl_add_u64 %14, %14, 0, %15\n v_lshl_add_u64 %15, %15, 0, %8\n"
+                     "v_cmp_lt_u64 vcc, %8, %9\n v_cmp_lt_u64 vcc, %9, %10\n v_cmp_lt_u64 vcc, %10, %11\n v_cmp_lt_u64 vcc, %11, %12\n"
+                     "v_cmp_lt_u64 vcc, %12, %13\n v_cmp_lt_u64 vcc, %13, %14\n v_cmp_lt_u64 vcc, %14, %15\n v_cmp_lt_u64 vcc, %15, %8"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+                       "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) : : "vcc");
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) ticks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (unsigned)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7);
+}
+}  // namespace
+extern "C" {
+int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_instr_per_s, double *shader_mhz, double *cycles_per_instr) {
+    if (waves_per_simd < 1 || waves_per_simd > 8 || millis < 1 || !lane_instr_per_s || !shader_mhz || !cycles_per_instr) return fail(CUHE_EINVAL, "probe_valu(%d waves, %d ms)", waves_per_simd, millis);
+    if (hipSetDevice(G_.dev_base + (G_.virtual_devices ? 0 : dev)) != hipSuccess) return fail(CUHE_EHIP, "hipSetDevice");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, G_.dev_base + (G_.virtual_devices ? 0 : dev)));
+    const int blocks = prop.multiProcessorCount * waves_per_simd;      // a 256-thread block = one wave per SIMD of a CU
+    unsigned *out = nullptr; unsigned long long *ticks = nullptr;
+    HIPCHK(hipMalloc((void **)&out, (size_t)blocks * 256 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void **)&ticks, (size_t)blocks * 4 * sizeof(unsigned long long)));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    auto run = [&](int reps, float *ms) -> int {
+        HIPCHK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_probe_valu, dim3(blocks), dim3(256), 0, 0, out, ticks, 1u);
+        HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(ms, e0, e1));
+        return CUHE_OK;
+    };
+    float ms = 0;
+    CHK(run(3, &ms));                                                   // warm-up and a duration estimate
+    const int reps = std::max(4, (int)(millis / std::max(ms / 3, 1e-3f)));
+    CHK(run(reps, &ms));
+    std::vector<unsigned long long> h((size_t)blocks * 4);
+    HIPCHK(hipMemcpy(h.data(), ticks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double avg = 0; for (unsigned long long t : h) avg += (double)t; avg /= (double)h.size();
+    const double instr = (double)kProbeIters * 24;
+    *lane_instr_per_s = (double)reps * blocks * 256.0 * instr / (ms * 1e-3);
+    *shader_mhz = avg / (ms * 1e3 / reps);                              // ticks of one wave per microsecond of one kernel
+    *cycles_per_instr = avg / instr / waves_per_simd;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(out); hipFree(ticks);
+    return CUHE_OK;
+}
+
 // waits for everything enqueued on the device; every block freed in stream order becomes an ordinary free block
 int cuhe_hip_device_sync(int dev) {
     CHK(set_dev(dev));

@@ -373,6 +373,14 @@ int cuhe_hip_set_onewg_split(int mode);
 int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch, int iters, int dev, void *stream,
                           float *ms_pass1, float *ms_pass2, float *ms_total);
 
+/* measurement of the limiter the transforms run against (bench.py roofline.valu_ceiling): a dense stream of the
+ * 64-bit integer instructions the field arithmetic lowers to (v_mad_u64_u32, v_lshl_add_u64, v_cmp_lt_u64, equal parts), every
+ * SIMD of the chip filled with `waves_per_simd` waves (1 ... 8), repeated for about `millis` ms.  Returns the sustained rate in
+ * lane-instructions per second (*lane_instr_per_s), the shader clock the chip settled at under that load (*shader_mhz: s_memtime
+ * ticks of a wave per microsecond of kernel time) and the issue cost (*cycles_per_instr: shader cycles per wave-instruction and
+ * SIMD).  No counterpart in the reference; a diagnostic, never on the product path. */
+int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_instr_per_s, double *shader_mhz, double *cycles_per_instr);
+
 /* ---- field arithmetic test hooks (tests/test_ModP.cu:50-135): elementwise over n u64 */
 int cuhe_hip_modp_add(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *stream);
 int cuhe_hip_modp_sub(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *stream);

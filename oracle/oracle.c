@@ -812,6 +812,54 @@ int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, i
     return 0;
 }
 
+/* cAnd then CuCtxt::relin (cuhe/CuHE.cu:101,570-581; Relinearization.cu:76-88) for B ciphertext pairs on a ring x^n + 1 at the
+ * sizes of BASELINE config 4, where orc_mul_relin_crt's key table (np x K x nttLen words) no longer fits: the same chain with
+ * every product modulo x^n + 1 taken per prime through the negacyclic restatement above (pinned against the cyclic chain by
+ * tests/test_oracle_negacyclic.py), the key transforms formed once per prime and shared by the B pairs.
+ *   a, b, dst: u32[B][np][crtLen] reduced CRT rows of level lvl; ekc: u32[K][np0][crtLen] = orc_crt of the K raw keys (level 0).
+ * Returns -1 when a centred lift would be ambiguous (2 n p^2 >= P or 2 k n 2^w p >= P). */
+int orc_nc_mul_relin_crt_batch(const orc_ctx *c, uint32_t *dst, const uint32_t *a, const uint32_t *b, int B, int lvl, const uint32_t *ekc) {
+    const orc_params *q = &c->prm;
+    const int n = q->modLen, cl = q->crtLen, np = orc_num_crt_prime(q, lvl), np0 = q->numCrtPrime, W = orc_words_coeff(q, lvl);
+    const int k = orc_num_eval_key(q, lvl), w = q->logRelin;
+    if (n != cl || (n & (n - 1))) return -1;
+    for (int i = 0; i < np; i++) {
+        const u128 p = c->primes[i];
+        if ((u128)2 * n * (p - 1) * (p - 1) >= ORC_P || (u128)2 * k * n * (((u128)1 << w) - 1) * (p - 1) >= ORC_P) return -1;
+    }
+    const size_t cn = (size_t)np * cl;
+    uint32_t *cr = (uint32_t *)malloc(sizeof(uint32_t) * cn);
+    uint32_t *raw = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)q->rawLen * W);
+    uint32_t *win = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint64_t *wn = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)B * k * n);          /* transforms of the windows of every pair */
+    for (int t = 0; t < B; t++) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+        for (int i = 0; i < np; i++)                                                   /* cAnd ; n2c (isProd) */
+            orc_negacyclic_mul_modp(cr + (size_t)i * cl, a + t * cn + (size_t)i * cl, b + t * cn + (size_t)i * cl, n, c->primes[i]);
+        orc_icrt(c, raw, cr, lvl);                                                     /* c2r */
+        for (int j = 0; j < k; j++) {                                                  /* Base.cu:345-385: windows, then their transforms */
+            for (int idx = 0; idx < n; idx++) win[idx] = window_of(raw + (size_t)idx * W, W, w, j);
+            orc_nc_ntt(wn + ((size_t)t * k + j) * n, win, n);
+        }
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+    for (int i = 0; i < np; i++) {                                                     /* Base.cu:1024-1033 per prime, then n2c (isProd) */
+        uint64_t *acc = (uint64_t *)calloc((size_t)B * n, sizeof(uint64_t)), *key = (uint64_t *)malloc(sizeof(uint64_t) * n);
+        for (int j = 0; j < k; j++) {
+            orc_nc_ntt(key, ekc + ((size_t)j * np0 + i) * cl, n);
+            for (int t = 0; t < B; t++) {
+                const uint64_t *x = wn + ((size_t)t * k + j) * n;
+                uint64_t *y = acc + (size_t)t * n;
+                for (int idx = 0; idx < n; idx++) y[idx] = orc_add_modP(y[idx], orc_mul_modP(x[idx], key[idx]));
+            }
+        }
+        for (int t = 0; t < B; t++) orc_nc_intt_modp(dst + t * cn + (size_t)i * cl, acc + (size_t)t * n, n, c->primes[i]);
+        free(acc); free(key);
+    }
+    free(cr); free(raw); free(win); free(wn);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* optional CPU baseline: the multiplication the reference delegates to NTL   */
 /* (examples/DHS/DHS.cu:219-221: t = a * b; t %= Phi; coefficients mod q) done */

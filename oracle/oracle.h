@@ -148,6 +148,8 @@ void orc_nc_ntt(uint64_t *dst, const uint32_t *src, int n);
 int orc_nc_intt_modp(uint32_t *dst, const uint64_t *src, int n, uint32_t p);
 /* sum_j win[j] * key[j] mod (x^n + 1) mod p over k window / key rows of n coefficients (cuhe/Relinearization.cu:76-88) */
 int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, int k, int n, uint32_t p);
+/* cAnd + relin of B pairs on x^n + 1 at config-4 sizes: per prime through the negacyclic restatement (CuHE.cu:101,570-581) */
+int orc_nc_mul_relin_crt_batch(const orc_ctx *c, uint32_t *dst, const uint32_t *a, const uint32_t *b, int B, int lvl, const uint32_t *ekc);
 
 /* ---- optional second CPU baseline (bench.py): the product the reference delegates to NTL (examples/DHS/DHS.cu:219-221) on
  * x^n + 1 by Kronecker substitution and ONE big-integer multiplication through GMP, opened at run time (NTL is not in

@@ -84,6 +84,7 @@ def lib():
         L.orc_negacyclic_mul_modp_naive.restype = None; L.orc_negacyclic_mul_modp_naive.argtypes = [vp, vp, vp, i32, u32]
         L.orc_negacyclic_mul_modp.restype = i32; L.orc_negacyclic_mul_modp.argtypes = [vp, vp, vp, i32, u32]
         L.orc_nc_relin_modp.restype = i32; L.orc_nc_relin_modp.argtypes = [vp, vp, vp, i32, i32, u32]
+        L.orc_nc_mul_relin_crt_batch.restype = i32; L.orc_nc_mul_relin_crt_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.orc_gmp_available.restype = i32; L.orc_gmp_available.argtypes = []
         L.orc_gmp_mul_xn1.restype = i32; L.orc_gmp_mul_xn1.argtypes = [vp, vp, vp, i32, i32, vp, i32]
         L.orc_set_threads.restype = i32; L.orc_set_threads.argtypes = [i32]
@@ -352,6 +353,22 @@ class Ctx:
         a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
         out = np.empty((self.np_(lvl), self.prm.crtLen), dtype=np.uint32)
         lib().orc_mul_relin_crt(self.h, _p(out), _p(a), _p(b), lvl, _p(ek))
+        return out
+
+
+    def key_residues(self, evalkey_raw):
+        """u32[K][np0][crtLen]: the CRT rows of the K raw evaluation keys (Relinearization.cu:43-57 before the transforms)"""
+        ek_raw = np.ascontiguousarray(evalkey_raw, dtype=np.uint32)
+        return np.stack([self.crt(ek_raw[j], 0) for j in range(ek_raw.shape[0])])
+
+    def nc_mul_relin_crt_batch(self, a, b, lvl, ekc):
+        """cAnd + relin of B pairs on a ring x^n + 1 (a, b: u32[B][np][crtLen]), per prime through the negacyclic
+        restatement: the form of mul_relin_crt that fits BASELINE config 4 (no np x K x nttLen key table)"""
+        a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
+        ekc = np.ascontiguousarray(ekc, dtype=np.uint32)
+        assert a.shape == b.shape == (a.shape[0], self.np_(lvl), self.prm.crtLen) and ekc.shape[1:] == (self.prm.numCrtPrime, self.prm.crtLen)
+        out = np.empty_like(a)
+        assert lib().orc_nc_mul_relin_crt_batch(self.h, _p(out), _p(a), _p(b), a.shape[0], lvl, _p(ekc)) == 0, "not a ring x^n + 1 within the lift bounds"
         return out
 
 

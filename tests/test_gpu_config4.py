@@ -243,3 +243,71 @@ def test_bench_two_ranks_on_one_gpu_runs_every_leg():
     sh = d["mul_relin_sharded"]
     assert sh["primes_per_rank"] == 24 and sh["key_primes_per_rank"] <= 30 and 0 < sh["serial_fraction"] < 1
     assert d["prince"]["known_answer_ok"] is True
+
+
+def dense_config4_case(args, B, seed):
+    """inputs of the dense-key test and what the ORACLE makes of them (CPU only; timed here so that the GPU test's budget is
+    known): dense random evaluation keys (every word random, below q0), B distinct operand pairs with uniformly random
+    residues, the oracle's cAnd + relin of every pair (orc_nc_mul_relin_crt_batch: the reference's chain CuHE.cu:101,570-581
+    per prime through the negacyclic restatement, OpenMP over the primes)."""
+    import oracle_lib as O
+    O.set_threads(0)
+    o = O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, n, npr = q.numEvalKey, o.words(0), q.modLen, o.np_(0)
+        rng = np.random.default_rng(seed)
+        ek_raw = rng.integers(0, 1 << 32, (K, q.rawLen, W0), dtype=np.uint32)
+        ek_raw[:, :, W0 - 1] &= np.uint32((1 << (o.logq(0) - 32 * (W0 - 1) - 1)) - 1)      # every coefficient below 2^(logq0 - 1) < q0
+        ek_raw[:, n:, :] = 0
+        a = np.stack([np.stack([rng.integers(0, p, q.crtLen, dtype=np.uint32) for p in o.primes[:npr]]) for _ in range(B)])
+        b = np.stack([np.stack([rng.integers(0, p, q.crtLen, dtype=np.uint32) for p in o.primes[:npr]]) for _ in range(B)])
+        a[0, :, 0] = o.primes[:npr] - 1                                                    # an edge value in every row of the first pair
+        want = o.nc_mul_relin_crt_batch(a, b, 0, o.key_residues(ek_raw))
+        return ek_raw, a, b, want
+    finally:
+        o.close()
+
+
+@pytest.mark.parametrize("ring", list(RINGS))
+def test_dense_keys_at_config4_shape_vs_oracle(gu, ring):
+    """the BENCHMARKED shape (48 primes, 72 / 69 keys, level 0) with DENSE random keys against the oracle --
+    three distinct ciphertext pairs through cuhe_hip_mul_relin_batch on the matrix cores (batch of 5: the three pairs + two
+    repeats, the smallest batch that takes k_relin_mac_mfma), through the VALU batch kernels (batch of 3) and through the
+    single chain (ct_mul ; ct_intt ; icrt ; relinearization ; ct_intt); every prime, every coefficient."""
+    lib, ck = gu.lib, gu.ck
+    B = 3
+    ek_raw, a, b, want = dense_config4_case(RINGS[ring], B, 0xC4 + len(ring))
+    g = gu.GpuCtx(*RINGS[ring])
+    try:
+        q = g.prm
+        npr, ctlen = g.np_(0), lib.cuhe_hip_ct_len()
+        assert (q.numCrtPrime, npr) == (48, 48) and q.numEvalKey in (72, 69) and g.nc
+        assert [int(p) for p in g.crt_primes()] == [int(p) for p in oracle_primes(RINGS[ring])]
+        g.init_relin(ek_raw)
+        for t in range(B):                                       # the single chain
+            assert np.array_equal(g.mul_relin_crt(a[t], b[t], 0), want[t]), (ring, "single", t)
+        order = [0, 1, 2, 1, 0]                                  # 5 ciphertexts: the matrix-core inner product (default from 5 on)
+        na, nb = gu.empty_u64(len(order) * npr, ctlen), gu.empty_u64(len(order) * npr, ctlen)
+        for s, t in enumerate(order):
+            ck(lib.cuhe_hip_ct_ntt(na[s * npr:].data_ptr(), gu.to_dev(a[t]).data_ptr(), g.logq(0), 0, None))
+            ck(lib.cuhe_hip_ct_ntt(nb[s * npr:].data_ptr(), gu.to_dev(b[t]).data_ptr(), g.logq(0), 0, None))
+        out = gu.empty_u32(len(order) * npr, q.crtLen)
+        ck(lib.cuhe_hip_set_relin_mfma(5))
+        ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, len(order), 0, None))
+        got = gu.host_u32(out).reshape(len(order), npr, q.crtLen)
+        for s, t in enumerate(order):
+            assert np.array_equal(got[s], want[t]), (ring, "batch of 5 (matrix cores)", s)
+        out.zero_()
+        ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, B, 0, None))          # 3 < 5: the VALU batch kernels
+        got = gu.host_u32(out).reshape(len(order), npr, q.crtLen)
+        for t in range(B):
+            assert np.array_equal(got[t], want[t]), (ring, "batch of 3 (VALU)", t)
+    finally:
+        lib.cuhe_hip_set_relin_mfma(5)
+        g.close()
+
+
+def oracle_primes(args):
+    import oracle_lib as O
+    return O.gen_crt_primes(O.set_param(*args))

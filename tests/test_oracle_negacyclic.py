@@ -110,3 +110,35 @@ def test_gmp_kronecker_baseline_equals_the_oracle_path():
             O.set_threads(1)
     finally:
         O.set_threads(1); o.close()
+
+
+def test_batched_chain_equals_the_cyclic_chain_of_the_oracle():
+    """orc_nc_mul_relin_crt_batch (cAnd + relin per prime through the negacyclic restatement, the form that fits BASELINE
+    config 4) against orc_mul_relin_crt (the reference-shaped chain: zero-padded cyclic transforms, exact remainder,
+    np x K x nttLen key table; cuhe/CuHE.cu:101,570-581) on x^8192 + 1 with dense random keys, two levels, three pairs."""
+    args = (3, 2, 16, 50, 25, 16384)
+    o = O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xD100 + j)[0] for j in range(K)])
+        ek, ekc = o.init_relin(ek_raw), o.key_residues(ek_raw)
+        assert ekc.shape == (K, q.numCrtPrime, q.crtLen)
+        for lvl in (0, 1):
+            npr = o.np_(lvl)
+            xs = [o.crt(O.random_raw(q.rawLen, q.modLen, o.words(lvl), o.coeff_modulus(lvl), 0xD200 + 16 * lvl + i)[0], lvl) for i in range(6)]
+            a, b = np.stack(xs[0::2]), np.stack(xs[1::2])
+            got = o.nc_mul_relin_crt_batch(a, b, lvl, ekc)
+            for t in range(3):
+                assert np.array_equal(got[t], o.mul_relin_crt(a[t], b[t], lvl, ek)), (lvl, t)
+    finally:
+        o.close()
+    # a ring that is not x^n + 1 is refused
+    o = O.Ctx(3, 2, 8, 40, 20, 1155)
+    try:
+        z = np.zeros((1, o.np_(0), o.prm.crtLen), dtype=np.uint32)
+        out = np.empty_like(z)
+        ekc = np.zeros((o.prm.numEvalKey, o.prm.numCrtPrime, o.prm.crtLen), dtype=np.uint32)
+        assert O.lib().orc_nc_mul_relin_crt_batch(o.h, O._p(out), O._p(z), O._p(z), 1, 0, O._p(ekc)) == -1
+    finally:
+        o.close()
