@@ -120,6 +120,8 @@ SIGNATURES = {
     "cuhe_hip_crt_mod_switch_batch": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_ct_binop_list": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_crt_add_list": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_crt_mod_switch_list": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cuhe_hip_crt_add_int_list": (i32, [vp, vp, u32, i32, i32, i32, vp]),
     "cuhe_hip_copy_list": (i32, [vp, vp, i32, sz, i32, vp]),
     "cuhe_hip_intt_batch": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_gather_blocks": (i32, [vp, vp, i32, sz, i32, vp]),

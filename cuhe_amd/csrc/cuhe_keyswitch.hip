@@ -674,6 +674,49 @@ int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *cons
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
+// modSwitch of `count` separately owned CRT-domain ciphertexts of level lvl (np rows each): dst[i] <- src[i] one level down (np - 1 rows);
+// dst[i] == src[i] switches a ciphertext inside its own block (CuCtxt::modSwitch, CuHE.cu:583-594, over a list: one launch per 64)
+int cuhe_hip_crt_mod_switch_list(void *const *dst, const void *const *src, int lvl, int count, int dev, void *st) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl + 1 >= q.depth) return fail(CUHE_EINVAL, "modSwitch from level %d", lvl);
+    if (count < 1) return fail(CUHE_EINVAL, "count %d", count);
+    const int np = q.numCrtPrimeAt(lvl);
+    if (np < 2) return fail(CUHE_EINVAL, "modSwitch needs >= 2 primes");
+    DevCtx &D = G_.dev[dev];
+    const int groups = (np - 1 + kModswPrimes - 1) / kModswPrimes;
+    for (int c0 = 0; c0 < count; c0 += kPtrListMax) {
+        const int n = std::min(kPtrListMax, count - c0);
+        PtrList Dl, Sl;
+        CHK(fill_list(Dl, (const void *const *)dst, c0, n)); CHK(fill_list(Sl, src, c0, n));
+        if (rows_vec4(nullptr, nullptr, 0, 0))           // (fill_list has checked every block for 16-byte alignment)
+            hipLaunchKernelGGL(k_modswitch_list<4>, dim3((q.modLen / 4 + 255) / 256, groups, n), dim3(256), 0, S(st), Dl, Sl, prime_tab(D), D.invp, np, q.modLen, q.crtLen, q.modMsg);
+        else
+            hipLaunchKernelGGL(k_modswitch_list<1>, dim3((q.modLen + 255) / 256, groups, n), dim3(256), 0, S(st), Dl, Sl, prime_tab(D), D.invp, np, q.modLen, q.crtLen, q.modMsg);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
+// cNot over a list: z[i] = x[i] + a on the constant coefficient of every row (mod p), the other coefficients copied when z[i] != x[i]
+// (cNot of CuCtxt, CuHE.cu:176-187 with crt_add_int, Base.cu:1096-1100: one launch per 64 ciphertexts)
+int cuhe_hip_crt_add_int_list(void *const *z, const void *const *x, unsigned a, int count, int logq, int dev, void *st) {
+    CHK(need_init(dev));
+    int lvl, np, W; CHK(level_of(logq, &lvl, &np, &W));
+    if (count < 1) return fail(CUHE_EINVAL, "count %d", count);
+    const Params &q = G_.prm;
+    DevCtx &D = G_.dev[dev];
+    for (int c0 = 0; c0 < count; c0 += kPtrListMax) {
+        const int n = std::min(kPtrListMax, count - c0);
+        PtrList Z, X;
+        CHK(fill_list(Z, (const void *const *)z, c0, n)); CHK(fill_list(X, x, c0, n));
+        bool copies = false;
+        for (int t = 0; t < n; ++t) copies = copies || Z.p[t] != X.p[t];
+        const int gx = copies ? (int)std::min<long>(((long)np * q.modLen + 255) / 256, 128) : (np + 255) / 256;
+        hipLaunchKernelGGL(k_crt_add_int_list, dim3(gx, n), dim3(256), 0, S(st), Z, X, a, prime_tab(D), np, q.modLen, q.crtLen);
+    }
+    HIPCHK(hipGetLastError());
+    return CUHE_OK;
+}
 // dst[i] = src[i] for `count` separately owned blocks of `bytes` bytes (copy() of CuCtxt, CuHE.cu:81: one launch for the list)
 int cuhe_hip_copy_list(void *const *dst, const void *const *src, int count, size_t bytes, int dev, void *st) {
     CHK(need_init(dev));

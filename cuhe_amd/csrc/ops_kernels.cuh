@@ -145,11 +145,8 @@ static __global__ void k_crt_mul_int(u32 *__restrict__ z, const u32 *__restrict_
 // Round 4: the one-element-per-thread form ran at 1 TB/s on arrays of 64 ciphertexts (profiles/r04_elementwise_ab.txt).
 static constexpr int kModswPrimes = 4;
 template <int VEC>
-__global__ __launch_bounds__(256)
-void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt,
-                 const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg, long src_ct_stride, long dst_ct_stride) {
-    src += (long)blockIdx.z * src_ct_stride;         // blockIdx.z: ciphertext of a batched call (the result has np-1 rows,
-    dst += (long)blockIdx.z * dst_ct_stride;         // so a packed result array has a smaller stride than its source)
+__device__ __forceinline__ void modswitch_body(u32 *__restrict__ dst, const u32 *__restrict__ src, const PrimeTab &pt,
+                                               const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg) {
     const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (idx >= mlen) return;
     const u32 ptl = pt.p[np - 1];
@@ -181,6 +178,13 @@ void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt
         if (VEC == 4) *reinterpret_cast<uint4 *>(dst + (long)i * clen + idx) = make_uint4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
         else dst[(long)i * clen + idx] = r[0];
     }
+}
+template <int VEC>
+__global__ __launch_bounds__(256)
+void k_modswitch(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt,
+                 const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg, long src_ct_stride, long dst_ct_stride) {
+    // blockIdx.z: ciphertext of a batched call (the result has np-1 rows, so a packed result array has a smaller stride than its source)
+    modswitch_body<VEC>(dst + (long)blockIdx.z * dst_ct_stride, src + (long)blockIdx.z * src_ct_stride, pt, invp, np, mlen, clen, modmsg);
 }
 
 // ---------------------------------------------------------------- polynomial Barrett pieces
@@ -1006,7 +1010,7 @@ void k_icrt(u32 *__restrict__ dst, const u32 *__restrict__ src, PrimeTab pt, Icr
 // ---- gather / scatter of equally sized blocks through a pointer list passed BY VALUE (no table in device memory): the
 // gate scheduler of the C++ layer (cuhe_amd/cxx/Scheduler.h) runs ready gates of one kind as ONE batched call on contiguous
 // arrays, while every ciphertext of the client owns its own block.  16 bytes per lane and step; bytes is a multiple of 16.
-constexpr int kPtrListMax = 32;
+constexpr int kPtrListMax = 64;       // 512 bytes per list; kernels take up to three (the kernel-argument segment holds 4 KB)
 struct PtrList { void *p[kPtrListMax]; };
 // elementwise gates on LISTS of separately owned ciphertexts (blockIdx.y / z = item): z[i] = x[i] (*|+) y[i] on ct rows, z[i] = (a[i] + b[i]) mod p on CRT rows
 template <bool MUL>
@@ -1037,6 +1041,34 @@ void k_crt_add_list(PtrList zl, PtrList al, PtrList bl, PrimeTab pt, int mlen, i
         *reinterpret_cast<uint4 *>(z + o) = make_uint4(mod_small((u64)x.x + y.x, p, m), mod_small((u64)x.y + y.y, p, m),
                                                        mod_small((u64)x.z + y.z, p, m), mod_small((u64)x.w + y.w, p, m));
     } else z[o] = mod_small((u64)a[o] + b[o], p, m);
+}
+// modSwitch over a list of separately owned ciphertexts (blockIdx.z = item): dst[i] may be src[i] (row r only depends on rows r and
+// np - 1, and row np - 1 is never written), which is how the gate scheduler switches CRT-domain ciphertexts in their own blocks
+template <int VEC>
+__global__ __launch_bounds__(256)
+void k_modswitch_list(PtrList dl, PtrList sl, PrimeTab pt, const u32 *__restrict__ invp, int np, int mlen, int clen, int modmsg) {
+    modswitch_body<VEC>((u32 *)dl.p[blockIdx.z], (const u32 *)sl.p[blockIdx.z], pt, invp, np, mlen, clen, modmsg);
+}
+// cNot over a list (blockIdx.y = item): z[i] = x[i] with (modMsg - 1) added to the constant coefficient of every row (crt_add_int,
+// Base.cu:1096-1100); z[i] == x[i]: only the np constant terms are touched, otherwise the other coefficients are copied as well
+static __global__ __launch_bounds__(256)
+void k_crt_add_int_list(PtrList zl, PtrList xl, unsigned a, PrimeTab pt, int np, int mlen, int clen) {
+    u32 *z = (u32 *)zl.p[blockIdx.y];
+    const u32 *x = (const u32 *)xl.p[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z != x) {
+        const long total = (long)np * mlen;
+        for (long e = t; e < total; e += (long)gridDim.x * blockDim.x) {
+            const int row = (int)(e / mlen), idx = (int)(e - (long)row * mlen);
+            const long o = (long)row * clen + idx;
+            u32 v = x[o];
+            if (idx == 0) { const u32 p = pt.p[row]; const u64 m = pt.pinv[row]; v = mod_small((u64)v + mod_small(a, p, m), p, m); }
+            z[o] = v;
+        }
+    } else if (t < np) {
+        const u32 p = pt.p[t]; const u64 m = pt.pinv[t];
+        z[(long)t * clen] = mod_small((u64)x[(long)t * clen] + mod_small(a, p, m), p, m);
+    }
 }
 static __global__ __launch_bounds__(256)
 void k_copy_list(PtrList dl, PtrList sl, long bytes) {

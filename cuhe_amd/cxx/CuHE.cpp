@@ -522,7 +522,7 @@ void CuPolynomial::n2c(cudaStream_t st) {
 	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }); } while (0)
 // ... as a BATCHABLE gate (Scheduler.h): ready gates of one kind on ciphertexts of one level / domain / device run as one call of
 // the array entry points (batchRunner below).  Ciphertexts only; the key says what the closure would find in the object.
-enum { kBatchX2C = 1, kBatchX2N = 2, kBatchRelin = 3, kBatchModSwitch = 4, kBatchAnd = 5, kBatchXor = 6, kBatchCopy = 7 };
+enum { kBatchX2C = 1, kBatchX2N = 2, kBatchRelin = 3, kBatchModSwitch = 4, kBatchAnd = 5, kBatchXor = 6, kBatchCopy = 7, kBatchNot = 8 };
 static long batchKey(int level, int domain, bool prod) { return (long)level | (long)domain << 8 | (long)(prod ? 1 : 0) << 12; }
 #define RECORD_SELF_BATCH(call, kind, key) do { sched::Node *n_ = schedAttach(); \
 	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }, false, kind, key, n_); } while (0)
@@ -822,7 +822,8 @@ void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
 	if (in.domain() != 2) misuse("Error: cNot of non-CRT domain!");
 	if (recordGate(out, in)) {
 		sched::Node *ni = in.schedAttach(), *no = out.schedAttach();
-		sched::submit(in.device(), Nodes(1, ni), Nodes(1, no), [ni, no](void *s) { SchedAccess::stream(*no->obj) = s; cNot(OBJ(no), OBJ(ni), s); });
+		sched::submit(in.device(), Nodes(1, ni), Nodes(1, no), [ni, no](void *s) { SchedAccess::stream(*no->obj) = s; cNot(OBJ(no), OBJ(ni), s); },
+		              false, kBatchNot, batchKey(in.level(), 2, false), no, ni, NULL);
 		if (&out != &in) { const bool prod = in.isProd(); const int terms = in.prodTerms(); SchedAccess::shapeLike(out, in, 2); SchedAccess::setProd(out, prod, terms); }
 		return;
 	}
@@ -838,6 +839,10 @@ void cNot(CuCtxt &out, CuCtxt &in, cudaStream_t st) {
 // The destination block is written by a copy on `st`, a stream of the SOURCE device: it must not be a block that is
 // only parked in the order of one of the destination's streams (work enqueued there may still touch it), so it comes
 // from the settled pool (cuhe_hip_malloc), never from the stream-ordered one.
+// the eager call returns with the copy finished (cuhe/CuHE.cu:217-256).  Inside a recorded task nothing waits on the host: the tasks
+// that use the moved ciphertext on the destination device are ordered behind this one by the scheduler's events, the source block is
+// released in the order of the copying stream, and the destination block comes from the settled pool
+static void moveSync(int srcDev, cudaStream_t st) { if (!sched::inWorker()) CSC(cuhe_hip_stream_sync(srcDev, st)); }
 static void *peerAlloc(int dev, size_t bytes) { void *p = cuhe_hip_malloc(dev, bytes); if (!p) CSC(CUHE_EHIP); return p; }
 void moveTo(CuCtxt &tar, int dstDev, cudaStream_t st) {
 	if (dstDev == tar.device()) return;
@@ -853,17 +858,17 @@ void moveTo(CuCtxt &tar, int dstDev, cudaStream_t st) {
 	if (tar.domain() == 1) {
 		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.rRepSize());
 		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.rRep(), srcDev, tar.rRepSize(), st));
-		CSC(cuhe_hip_stream_sync(srcDev, st));
+		moveSync(srcDev, st);
 		tar.rRepFree(); tar.rRep((uint32 *)p);
 	} else if (tar.domain() == 2) {
 		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.cRepSize());
 		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.cRep(), srcDev, tar.cRepSize(), st));
-		CSC(cuhe_hip_stream_sync(srcDev, st));
+		moveSync(srcDev, st);
 		tar.cRepFree(); tar.cRep((uint32 *)p);
 	} else if (tar.domain() == 3) {
 		void *p = peerAlloc(dstDev, deviceAllocatorIsOn() ? poolBlock() : tar.nRepSize());
 		CSC(cuhe_hip_memcpy_peer(p, dstDev, tar.nRep(), srcDev, tar.nRepSize(), st));
-		CSC(cuhe_hip_stream_sync(srcDev, st));
+		moveSync(srcDev, st);
 		tar.nRepFree(); tar.nRep((uint64 *)p);
 	}
 	tar.device(dstDev);
@@ -938,6 +943,18 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		CSC(cuhe_hip_copy_list(ptr, ps, n, bytes, dev, st));
 		return;
 	}
+	if (kind == kBatchNot) {                                     // out[i] = NOT a[i] (CRT domain): one launch for the list, in place where out[i] is a[i]
+		const void *ps[kMaxGateBatch];
+		CuCtxt &first = ct(op1[0]);
+		const int dev = first.device_, logq = first.logq_;
+		for (int i = 0; i < n; ++i) {
+			CuCtxt &src = ct(op1[i]);
+			if (c[i] != &src) { c[i]->reset(); c[i]->stream_ = st; c[i]->setLevelForOutput(src.level_, 2, dev, st); c[i]->isProd_ = src.isProd_; c[i]->prodTerms_ = src.prodTerms_; }
+			ptr[i] = c[i]->cRep_; ps[i] = src.cRep_;
+		}
+		CSC(cuhe_hip_crt_add_int_list(ptr, ps, (unsigned)param.modMsg - 1, n, logq, dev, st));
+		return;
+	}
 	if (kind == kBatchAnd || kind == kBatchXor) {                // out[i] = a[i] (x) b[i]: one launch for the list
 		CuCtxt *a[kMaxGateBatch], *b[kMaxGateBatch];
 		const void *pa[kMaxGateBatch], *pb[kMaxGateBatch];
@@ -973,6 +990,13 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		for (int i = 0; i < n; ++i) { c[i]->cRepFree(); c[i]->domain_ = 3; }
 		return;
 	}
+	static const bool listForms = !(getenv("CUHE_SCHED_LISTS") && atoi(getenv("CUHE_SCHED_LISTS")) == 0);     // (A/B: 0 = gather / array call / scatter everywhere)
+	if (kind == kBatchModSwitch && !fromNtt && listForms) {      // CRT-domain ciphertexts switch inside their own blocks: no gather, no scatter, no scratch
+		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
+		CSC(cuhe_hip_crt_mod_switch_list(ptr, ptr, lvl, n, dev, st));
+		for (int i = 0; i < n; ++i) { c[i]->logq_ -= param.logCoeffCut; c[i]->level_++; }
+		return;
+	}
 	// the other three start from reduced CRT rows of every ciphertext in one array
 	uint32 *rows = (uint32 *)tlsBatchScratch.get(dev, 0, cScratch, st);
 	// (kernels that produce CRT rows write the modLen coefficients of the ring: on a ring shorter than the row the rest has to read as zero)
@@ -993,6 +1017,12 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 	if (kind == kBatchRelin) {
 		CSC(cuhe_hip_relin_batch(rows, rows, lvl, n, dev, st));
 		for (int i = 0; i < n; ++i) { c[i]->isProd_ = false; c[i]->prodTerms_ = 0; }
+	} else if (kind == kBatchModSwitch && listForms) {             // (from the NTT domain) rows of the array -> the ciphertexts' new blocks: no scatter
+		const void *ps[kMaxGateBatch];
+		for (int i = 0; i < n; ++i) { ptr[i] = c[i]->cRep_; ps[i] = rows + (size_t)i * cRows; }
+		CSC(cuhe_hip_crt_mod_switch_list(ptr, ps, lvl, n, dev, st));
+		for (int i = 0; i < n; ++i) { c[i]->logq_ -= param.logCoeffCut; c[i]->level_++; }
+		return;
 	} else if (kind == kBatchModSwitch) {
 		next = (uint32 *)tlsBatchScratch.get(dev, 2, cScratch, st);
 		if (shortRing()) CSC(cuhe_hip_memset_async(dev, next, 0, n * cBytes, st));

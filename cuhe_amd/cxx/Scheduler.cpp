@@ -1,12 +1,30 @@
 // Scheduler.cpp -- task graph and worker threads of the gate scheduler (see Scheduler.h).
 //
+// Round 5: the state is PER DEVICE.  Every device of multiGPUs(n) has its own workers (CUHE_SCHED_THREADS per device, default
+// 3), its own ready queues, staging groups and lock; a worker is bound to one device and owns one stream there.  The graph
+// itself needs no global lock: a task counts its unissued dependencies in an atomic, the successor list and the "issued"
+// flag of a task are guarded by the lock of the task's OWN device, reference counts are atomics, and what only the
+// recording side touches (a node's last writer and readers) is guarded by the recording lock, which no worker ever takes.
+// With 8 devices that is 24 host threads feeding 8 sets of hardware queues instead of three threads and one mutex
+// ("the scheduler will not scale to the machine as written").
+//
 // Ordering on the GPU.  A task runs on the stream of the worker that picked it; a task it depends on may have run on another
-// worker's stream.  hipEventRecord is the expensive call here (5 us of host time with four threads launching, 18 us with
-// eight: tools/ubench_launch.hip, profiles/r04_sched_prince.txt), so no task records an event of its own.  Every worker
-// stream counts the tasks it has issued (`seq`) and owns ONE event; a consumer on another stream that needs "task #k of
-// that stream has finished" records that event on the producer's stream only if its last record does not cover #k yet --
-// the record lands behind #k (and possibly behind later tasks: more ordering than asked for, never less) -- and waits for
-// it.  With the per-worker queues below most dependencies stay on one stream and need nothing at all.
+// worker's stream (of this or of another device).  hipEventRecord is the expensive call here (5 us of host time with four
+// threads launching, 18 us with eight: tools/ubench_launch.hip, profiles/r04_sched_prince.txt), so no task records an event of
+// its own.  Every worker stream counts the tasks it has issued (`seq`) and owns ONE event; a consumer on another stream that
+// needs "task #k of that stream has finished" records that event on the producer's stream only if its last record does not
+// cover #k yet -- the record lands behind #k (and possibly behind later tasks: more ordering than asked for, never less) --
+// and waits for it.  With the per-worker queues below most dependencies stay on one stream and need nothing at all.
+//
+// Batches.  A batchable gate whose dependencies have been issued waits in a staging group keyed by (kind, key); a worker
+// that finds no regular task takes a group and runs it as ONE call of the batch runner.  Which group, and when, is the
+// policy (CUHE_SCHED_POLICY): 0 = round 4 (the fullest group as soon as no regular task is in flight); 1 = groups that
+// cannot grow any more first -- every recorded gate of that (kind, key) has arrived -- and an incomplete group only when
+// nothing else on the device can make progress, the OLDEST one (the most upstream in the client's program order, so that
+// the groups downstream fill up); 2 = as 1, but an incomplete group does not wait for workers that are inside batches.
+// Under 1 and 2 a group whose gates are ready as the client records them (nothing is pending then: the first layer of a circuit)
+// is taken only once the client has added nothing to it for CUHE_SCHED_QUIET_US (default 100); and a worker counts as busy
+// until it has published the successors of what it ran.
 #include "Scheduler.h"
 #include "CuHE.h"
 #include "Debug.h"
@@ -16,8 +34,10 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -25,7 +45,7 @@
 namespace cuHE {
 namespace sched {
 
-// one worker's stream on one device
+// one worker's stream (on the worker's device)
 struct StreamState {
 	void *stream = nullptr, *event = nullptr;
 	int dev = 0;
@@ -36,63 +56,78 @@ struct StreamState {
 struct Task {
 	std::function<void(void *)> fn;
 	int dev = 0;
-	std::vector<Task *> deps;              // every task this one is ordered after (references held until it has run)
-	std::vector<Task *> succ;              // tasks that wait for this one to be issued
+	long id = 0;                           // recording order (all devices)
+	std::vector<Task *> deps;              // every task this one is ordered after (references held until it has run); written before the task is published
+	std::vector<Task *> succ;              // tasks that wait for this one to be issued        -- guarded by the lock of device `dev`
 	std::vector<Node *> nodes;             // references held until it has run
-	int pending = 0;                       // dependencies not issued yet
-	bool issued = false;
+	std::atomic<int> pending{1};           // dependencies not issued yet (+ 1 while submit() is still linking)
+	std::atomic<bool> issued{false};       // set under the lock of device `dev`, after ss / seq
 	StreamState *ss = nullptr; long seq = 0;     // where it ran: task #seq of that stream
 	int kind = 0; long key = 0; Node *subject = nullptr, *op1 = nullptr, *op2 = nullptr;      // batchable gate (Scheduler.h)
-	int refs = 1;                          // the graph itself until the task has run; + nodes, successors, waiters
+	std::atomic<int> refs{1};              // the graph itself until the task has run; + nodes, successors, waiters
 };
 
 namespace {
-std::mutex mu;                             // guards the whole graph: tasks are ~25k per PRINCE block, each touched a few times
-std::condition_variable cvReady, cvDone;
-std::deque<Task *> ready;                  // tasks that were ready when the client recorded them
-std::vector<std::deque<Task *>> local;     // per worker: tasks its own tasks made ready (newest at the back; thieves take the oldest)
-int stealing = 1;                          // CUHE_SCHED_LOCAL=0: one shared queue
-// batchable ready tasks by (kind, key, device); they run when the workers have no other ready task (the gates that FEED a
-// group -- the products before the relinearisations of a layer -- are issued first, so that the group is as large as the circuit allows)
-struct GroupKey { int kind, dev; long key; bool operator<(const GroupKey &o) const { return kind != o.kind ? kind < o.kind : dev != o.dev ? dev < o.dev : key < o.key; } };
-std::map<GroupKey, std::deque<Task *>> staged;
-long stagedCount = 0, batchesRun = 0, batchedTasks = 0;
-int busyRegular = 0;                       // workers inside a non-batch task: more members of a group may still appear
-BatchRunner batchRunner = nullptr; int maxBatch = 1;
-std::vector<std::thread> workers;
-bool active = false, stopping = false;
-long outstanding = 0, totalTasks = 0, totalWaits = 0, totalRecords = 0, maxQueued = 0;
-std::vector<char> devUsed;                      // devices some task has run on
-double busySeconds = 0, idleSeconds = 0, gateSeconds = 0, orderSeconds = 0;       // summed over the workers (CUHE_SCHED_STATS=1 prints them at stop())
-int startedWorkers = 0;
 typedef std::chrono::steady_clock clk;
+constexpr int kMaxDevices = 64;
+
+struct GroupKey { int kind; long key; bool operator<(const GroupKey &o) const { return kind != o.kind ? kind < o.kind : key < o.key; } };
+struct Group { std::deque<Task *> q; clk::time_point lastArrival; bool fromClient = false; };     // lastArrival: of a gate that was ready when the client recorded it
+// everything a device's workers share
+struct DevState {
+	int dev = 0;
+	std::mutex m;                          // queues below + succ / issued of this device's tasks
+	std::condition_variable cv;
+	std::deque<Task *> ready;              // tasks that were ready when the client recorded them, or that another device's worker made ready
+	std::vector<std::deque<Task *>> local; // per worker: tasks its own tasks made ready (newest at the back; thieves take the oldest)
+	std::map<GroupKey, Group> staged;      // batchable ready tasks by (kind, key)
+	std::map<GroupKey, long> groupPending; // batchable tasks of that (kind, key) recorded but not staged yet
+	long stagedCount = 0;
+	int busyRegular = 0, busyBatch = 0;    // workers inside a regular task / inside a batch
+	std::vector<std::thread> workers;
+	int started = 0;
+	bool used = false;
+	// statistics (under m)
+	long batchesRun = 0, batchedTasks = 0, loneTasks = 0, waits = 0, records = 0, incompleteTaken = 0;
+	double busySeconds = 0, idleSeconds = 0, gateSeconds = 0, orderSeconds = 0;
+	std::map<int, std::map<int, long>> sizeHist;     // kind -> batch size -> count (CUHE_SCHED_TRACE)
+};
+DevState *devs[kMaxDevices];               // created on first use, never destroyed (tasks and idle streams point into them)
+std::mutex devsMu;                         // creation of DevStates / workers
+std::mutex recMu;                          // the recording side: node state (lastWrite, readers), task ids.  Never taken by a worker.
+std::mutex doneMu;                         // waiters for "issued" / "outstanding == 0"
+std::condition_variable cvDone;
+std::atomic<long> outstanding{0}, totalTasks{0}, maxQueued{0}, nextId{0};
+std::atomic<bool> active{false}, stopping{false};
+int workersPerDev = 3, stealing = 1, policy = 1, trace = 0;
+long quietNs = 100000;                     // policies 1, 2: a group the CLIENT is adding ready gates to right now is taken only after it has been quiet for this long (CUHE_SCHED_QUIET_US)
+BatchRunner batchRunner = nullptr; int maxBatch = 1;
 thread_local bool tlsWorker = false;
 thread_local void *tlsStream = nullptr;
-thread_local std::vector<StreamState *> tlsStreams;    // this worker's stream per device (never freed: tasks point at them)
+thread_local StreamState *tlsSS = nullptr;         // this worker's stream (never freed: tasks point at it)
+thread_local int tlsDev = -1, tlsIndex = -1;
 
-void unrefTask(Task *t) {                  // mu held
-	if (--t->refs > 0) return;
-	delete t;
-}
-// mu held; objects whose node died are handed back to be deleted outside the lock (their destructors call into the library)
+void unrefTask(Task *t) { if (t->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete t; }
+// objects whose node died are handed back to be deleted by the caller (their destructors call into the library)
 void unrefNode(Node *n, std::vector<CuPolynomial *> &dead) {
-	if (--n->refs > 0) return;
-	if (n->lastWrite) unrefTask(n->lastWrite);
+	if (n->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+	if (n->lastWrite) unrefTask(n->lastWrite);           // nobody else holds the node any more
 	for (Task *r : n->readers) unrefTask(r);
 	if (n->obj) dead.push_back(n->obj);
 	delete n;
 }
 // readers of a node that is never written (a key bit read by every round) would pile up: of the readers that have been
 // issued, the last one per stream stands for the earlier ones of that stream
-void pruneReaders(Node *n) {               // mu held
+void pruneReaders(Node *n) {               // recMu held
 	const std::vector<Task *> all = n->readers;
-	std::vector<char> shadowed(all.size(), 0);
+	std::vector<char> isIssued(all.size(), 0), shadowed(all.size(), 0);
+	for (size_t i = 0; i < all.size(); ++i) isIssued[i] = all[i]->issued.load(std::memory_order_acquire) ? 1 : 0;    // (ss / seq are final once it reads true)
 	for (size_t i = 0; i < all.size(); ++i) {
+		if (!isIssued[i]) continue;
 		Task *r = all[i];
-		if (!r->issued) continue;
 		for (size_t j = 0; j < all.size() && !shadowed[i]; ++j) {
 			Task *o = all[j];
-			shadowed[i] = j != i && o->issued && o->ss == r->ss && (o->seq > r->seq || (o->seq == r->seq && j > i));
+			shadowed[i] = j != i && isIssued[j] && o->ss == r->ss && (o->seq > r->seq || (o->seq == r->seq && j > i));
 		}
 	}
 	// one reference per ENTRY (submit() enters a task once per node, but the count must not depend on that: ADVICE r04)
@@ -117,114 +152,162 @@ int orderAfter(int dev, void *s, StreamState *from, long seq) {
 // block freed on one stream to another stream only behind everything enqueued on the first; here a released block carries
 // "task #k of stream S" -- its last use -- and the taker is ordered behind exactly that, usually an event record of long ago.
 struct Block { void *ptr; StreamState *ss; long seq; };
-std::mutex cacheMu;
-std::vector<std::unordered_map<size_t, std::deque<Block>>> cache;       // per device, by size
-std::unordered_map<void *, size_t> cacheSize;                           // blocks handed out by taskAlloc
-long cacheHits = 0, cacheForeign = 0, cacheMisses = 0;
-unsigned long long cacheGeneration = 0;    // cuhe_hip_generation() the cached blocks belong to
-void cacheCheckGeneration() {              // cacheMu held: a cuhe_hip_shutdown since took every block with it
-	const unsigned long long g = cuhe_hip_generation();
-	if (g != cacheGeneration) { cache.clear(); cacheSize.clear(); cacheGeneration = g; }
-}
-void flushCache() {                        // the device has been synchronised: everything goes back to the library's pool
-	std::lock_guard<std::mutex> lk(cacheMu);
-	cacheCheckGeneration();
-	for (size_t d = 0; d < cache.size(); ++d)
-		for (auto &bySize : cache[d])
-			for (Block &b : bySize.second) { cacheSize.erase(b.ptr); CSC(cuhe_hip_free((int)d, b.ptr)); }
-	cache.clear();
+struct BlockCache {                        // per device
+	std::mutex m;
+	std::unordered_map<size_t, std::deque<Block>> bySize;
+	std::unordered_map<void *, size_t> sizeOf;           // blocks handed out by taskAlloc
+	long hits = 0, foreign = 0, misses = 0;
+	unsigned long long generation = 0;     // cuhe_hip_generation() the cached blocks belong to
+	void checkGeneration() {               // m held: a cuhe_hip_shutdown since took every block with it
+		const unsigned long long g = cuhe_hip_generation();
+		if (g != generation) { bySize.clear(); sizeOf.clear(); generation = g; }
+	}
+};
+BlockCache caches[kMaxDevices];
+void flushCache() {                        // the devices have been synchronised: everything goes back to the library's pool
+	for (int d = 0; d < kMaxDevices; ++d) {
+		BlockCache &C = caches[d];
+		std::lock_guard<std::mutex> lk(C.m);
+		C.checkGeneration();
+		for (auto &bs : C.bySize)
+			for (Block &b : bs.second) { C.sizeOf.erase(b.ptr); CSC(cuhe_hip_free(d, b.ptr)); }
+		C.bySize.clear();
+	}
 }
 
-// mu held: this worker's newest task, else the oldest the client recorded, else the oldest of the fullest other worker
-Task *takeTask(int me) {
-	if (!local[me].empty()) { Task *t = local[me].back(); local[me].pop_back(); return t; }
-	if (!ready.empty()) { Task *t = ready.front(); ready.pop_front(); return t; }
+// D.m held: this worker's newest task, else the oldest the client recorded, else the oldest of the fullest other worker of the device
+Task *takeTask(DevState &D, int me) {
+	if (!D.local[me].empty()) { Task *t = D.local[me].back(); D.local[me].pop_back(); return t; }
+	if (!D.ready.empty()) { Task *t = D.ready.front(); D.ready.pop_front(); return t; }
 	size_t best = 0; int from = -1;
-	for (size_t w = 0; w < local.size(); ++w) if (local[w].size() > best) { best = local[w].size(); from = (int)w; }
+	for (size_t w = 0; w < D.local.size(); ++w) if (D.local[w].size() > best) { best = D.local[w].size(); from = (int)w; }
 	if (from < 0) return nullptr;
-	Task *t = local[from].front(); local[from].pop_front();
+	Task *t = D.local[from].front(); D.local[from].pop_front();
 	return t;
 }
-// mu held: the fullest staged group, up to maxBatch of its tasks (oldest first) -- only when it is full or no worker is inside a
-// regular task any more (what such a task makes ready may belong to the group)
-bool takeBatch(std::vector<Task *> &batch) {
-	if (stagedCount == 0) return false;
-	auto best = staged.end();
-	for (auto it = staged.begin(); it != staged.end(); ++it) if (best == staged.end() || it->second.size() > best->second.size()) best = it;
-	if (best == staged.end() || best->second.empty()) return false;
-	if ((int)best->second.size() < maxBatch && busyRegular > 0) return false;
-	while (!best->second.empty() && (int)batch.size() < maxBatch) { batch.push_back(best->second.front()); best->second.pop_front(); --stagedCount; }
-	if (best->second.empty()) staged.erase(best);
+// D.m held: a staged group, up to maxBatch of its tasks (oldest first).  See the policies at the top of the file.
+bool takeBatch(DevState &D, std::vector<Task *> &batch, long *retryNs) {
+	*retryNs = 0;
+	if (D.stagedCount == 0) return false;
+	auto pick = D.staged.end();
+	bool incomplete = false;
+	if (policy == 0) {
+		for (auto it = D.staged.begin(); it != D.staged.end(); ++it) if (pick == D.staged.end() || it->second.q.size() > pick->second.q.size()) pick = it;
+		if (pick == D.staged.end() || pick->second.q.empty()) return false;
+		if ((int)pick->second.q.size() < maxBatch && D.busyRegular > 0) return false;
+	} else {
+		// a full group goes at once
+		for (auto it = D.staged.begin(); it != D.staged.end(); ++it) if ((int)it->second.q.size() >= maxBatch) { pick = it; break; }
+		if (pick == D.staged.end()) {
+			// complete groups (nothing recorded for them is still on its way, so they cannot grow): the fullest
+			for (auto it = D.staged.begin(); it != D.staged.end(); ++it) {
+				if (it->second.q.empty()) continue;
+				auto gp = D.groupPending.find(it->first);
+				if (gp != D.groupPending.end() && gp->second > 0) continue;
+				if (pick == D.staged.end() || it->second.q.size() > pick->second.q.size()) pick = it;
+			}
+		}
+		if (pick == D.staged.end()) {
+			// only incomplete groups.  What a regular task in flight makes ready may belong to any of them; so may what the
+			// batch in flight on another worker makes ready (policy 1 waits for that too)
+			if (D.busyRegular > 0) return false;
+			if (policy == 1 && D.busyBatch > 0) return false;
+			for (auto it = D.staged.begin(); it != D.staged.end(); ++it) {
+				if (it->second.q.empty()) continue;
+				if (pick == D.staged.end() || it->second.q.front()->id < pick->second.q.front()->id) pick = it;
+			}
+			incomplete = true;
+		}
+		if (pick == D.staged.end()) return false;
+		// the client is recording this very group (its gates are ready as they are recorded, so nothing is "pending" -- the first layers
+		// of a circuit, before the client is ahead of the workers): a group that is not full waits until it has been quiet for quietNs
+		if ((int)pick->second.q.size() < maxBatch && quietNs > 0 && pick->second.fromClient) {
+			const long age = (long)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - pick->second.lastArrival).count();
+			if (age < quietNs) { *retryNs = quietNs - age; return false; }
+		}
+	}
+	std::deque<Task *> &q = pick->second.q;
+	while (!q.empty() && (int)batch.size() < maxBatch) { batch.push_back(q.front()); q.pop_front(); --D.stagedCount; }
+	if (q.empty()) D.staged.erase(pick);
+	if (incomplete) ++D.incompleteTaken;
 	return true;
 }
-// mu held: a task whose dependencies have all been issued
-void makeReady(Task *t, int me, Task **next) {
+DevState &deviceState(int dev);
+// a task whose dependencies have all been issued.  `me` / `next`: the calling worker's index on ITS device and its chain slot
+void makeReady(Task *t, Task **next) {
+	DevState &D = deviceState(t->dev);
 	if (t->kind && batchRunner && maxBatch > 1) {
-		staged[GroupKey{t->kind, t->dev, t->key}].push_back(t); ++stagedCount;
-		cvReady.notify_one();
+		std::lock_guard<std::mutex> lk(D.m);
+		const GroupKey k{t->kind, t->key};
+		Group &G = D.staged[k];
+		G.q.push_back(t); ++D.stagedCount;
+		if (!tlsWorker) { G.lastArrival = clk::now(); G.fromClient = true; }
+		auto gp = D.groupPending.find(k);
+		if (gp != D.groupPending.end() && --gp->second <= 0) D.groupPending.erase(gp);
+		D.cv.notify_one();
 		return;
 	}
-	if (next && !*next) { *next = t; return; }            // follow the chain on this stream: no event wait, warm scratch
-	if (me >= 0 && stealing) local[me].push_back(t); else ready.push_back(t);
-	cvReady.notify_one();
+	if (next && !*next && t->dev == tlsDev) { *next = t; return; }      // follow the chain on this stream: no event wait, warm scratch
+	std::lock_guard<std::mutex> lk(D.m);
+	if (tlsWorker && t->dev == tlsDev && stealing && tlsIndex >= 0 && tlsIndex < (int)D.local.size()) D.local[tlsIndex].push_back(t);
+	else D.ready.push_back(t);
+	D.cv.notify_one();
 }
 // streams of workers that have gone (setScheduled(false) ; setScheduled(true) cycles): a stream costs ~10 ms to create, and issued
 // tasks keep pointing at their StreamState, so the states are never destroyed -- the next workers take them over
 std::mutex idleMu;
-std::vector<std::vector<StreamState *>> idleStreams;     // per device
-StreamState *streamOf(int dev) {
-	if ((int)tlsStreams.size() <= dev) tlsStreams.resize(dev + 1, nullptr);
-	if (!tlsStreams[dev]) {
-		StreamState *ns = nullptr;
-		{
-			std::lock_guard<std::mutex> lk(idleMu);
-			if ((int)idleStreams.size() > dev && !idleStreams[dev].empty()) { ns = idleStreams[dev].back(); idleStreams[dev].pop_back(); }
-		}
-		if (!ns) {
-			ns = new StreamState;
-			ns->dev = dev;
-			CSC(cuhe_hip_stream_create(dev, &ns->stream));
-			CSC(cuhe_hip_event_create(dev, &ns->event));
-		}
-		tlsStreams[dev] = ns;
+std::vector<StreamState *> idleStreams[kMaxDevices];
+StreamState *acquireStream(int dev) {
+	{
+		std::lock_guard<std::mutex> lk(idleMu);
+		if (!idleStreams[dev].empty()) { StreamState *s = idleStreams[dev].back(); idleStreams[dev].pop_back(); return s; }
 	}
-	return tlsStreams[dev];
+	StreamState *ns = new StreamState;
+	ns->dev = dev;
+	CSC(cuhe_hip_stream_create(dev, &ns->stream));
+	CSC(cuhe_hip_event_create(dev, &ns->event));
+	return ns;
 }
-struct ReturnStreams { ~ReturnStreams() {                 // at worker exit
+struct ReturnStream { ~ReturnStream() {                   // at worker exit
+	if (!tlsSS) return;
 	std::lock_guard<std::mutex> lk(idleMu);
-	for (size_t d = 0; d < tlsStreams.size(); ++d) if (tlsStreams[d]) { if (idleStreams.size() <= d) idleStreams.resize(d + 1); idleStreams[d].push_back(tlsStreams[d]); }
-	tlsStreams.clear();
+	idleStreams[tlsSS->dev].push_back(tlsSS);
+	tlsSS = nullptr;
 } };
-void workerMain(int me) {
-	tlsWorker = true;
-	ReturnStreams giveBack;
-	// a stream costs ~10 ms to create: before the first task, not inside it
-	if (cuhe_hip_is_initialised()) for (int d = 0; d < cuhe_hip_num_gpus(); ++d) streamOf(d);
-	std::unique_lock<std::mutex> lk(mu);
-	++startedWorkers; cvDone.notify_all();
+
+void workerMain(DevState *Dp, int me) {
+	DevState &D = *Dp;
+	tlsWorker = true; tlsDev = D.dev; tlsIndex = me;
+	ReturnStream giveBack;
+	// a stream costs ~10 ms to create: before the first task, not inside it (when the library is up already)
+	if (cuhe_hip_is_initialised() && D.dev < cuhe_hip_num_gpus()) tlsSS = acquireStream(D.dev);
+	std::unique_lock<std::mutex> lk(D.m);
+	++D.started; D.cv.notify_all();
+	{ std::lock_guard<std::mutex> dl(doneMu); }
+	cvDone.notify_all();
 	Task *next = nullptr;
-	std::vector<Task *> batch;
+	std::vector<Task *> batch, succAll;
 	for (;;) {
 		batch.clear();
 		if (next) { batch.push_back(next); next = nullptr; }
 		else {
 			const auto w0 = clk::now();
 			for (;;) {
-				if (Task *t = takeTask(me)) { batch.push_back(t); break; }
-				if (takeBatch(batch)) break;
-				if (stopping) return;
-				cvReady.wait(lk);
+				if (Task *t = takeTask(D, me)) { batch.push_back(t); break; }
+				long retryNs = 0;
+				if (takeBatch(D, batch, &retryNs)) break;
+				if (stopping.load()) return;
+				if (retryNs > 0) D.cv.wait_for(lk, std::chrono::nanoseconds(retryNs)); else D.cv.wait(lk);
 			}
-			idleSeconds += std::chrono::duration<double>(clk::now() - w0).count();
+			D.idleSeconds += std::chrono::duration<double>(clk::now() - w0).count();
 		}
 		const auto b0 = clk::now();
-		const bool regular = batch.size() == 1 && !(batch[0]->kind && batchRunner && maxBatch > 1);
-		if (regular) ++busyRegular;
-		const int dev = batch[0]->dev;
-		if ((int)devUsed.size() <= dev) devUsed.resize(dev + 1, 0);
-		devUsed[dev] = 1;
+		const bool asBatch = batch[0]->kind && batchRunner && maxBatch > 1;       // (a group of one member still counts as a batch in flight)
+		if (asBatch) ++D.busyBatch; else ++D.busyRegular;
+		D.used = true;
 		lk.unlock();
-		StreamState *ss = streamOf(dev);
+		if (!tlsSS) tlsSS = acquireStream(D.dev);
+		StreamState *ss = tlsSS;
 		void *s = ss->stream;
 		long waits = 0, records = 0;
 		// one wait per foreign stream: behind the latest of the dependencies that ran there
@@ -236,7 +319,7 @@ void workerMain(int me) {
 				for (auto &e : latest) if (e.first == d->ss) { if (d->seq > e.second) e.second = d->seq; found = true; }
 				if (!found) latest.push_back({d->ss, d->seq});
 			}
-		for (auto &e : latest) { records += orderAfter(dev, s, e.first, e.second); ++waits; }
+		for (auto &e : latest) { records += orderAfter(D.dev, s, e.first, e.second); ++waits; }
 		tlsStream = s;
 		const auto f0 = clk::now();
 		if (batch.size() == 1) batch[0]->fn(s);
@@ -245,90 +328,130 @@ void workerMain(int me) {
 			for (Task *t : batch) { subjects.push_back(t->subject); o1.push_back(t->op1); o2.push_back(t->op2); }
 			batchRunner(batch[0]->kind, subjects.data(), o1.data(), o2.data(), (int)subjects.size(), s);
 		}
-		for (Task *t : batch) t->fn = nullptr;      // the closures' captures go before the graph lock is taken again
+		for (Task *t : batch) t->fn = nullptr;      // the closures' captures go before any lock is taken again
 		const auto f1 = clk::now();
-		std::vector<CuPolynomial *> dead;
 		const long seq = ss->seq.load(std::memory_order_relaxed) + 1;
 		ss->seq.store(seq, std::memory_order_release);
+		// publish: successors recorded from now on find the tasks issued; those recorded before are collected
+		succAll.clear();
 		lk.lock();
-		if (regular) --busyRegular;
-		if (batch.size() > 1) { ++batchesRun; batchedTasks += (long)batch.size(); }
-		totalWaits += waits; totalRecords += records;
-		busySeconds += std::chrono::duration<double>(clk::now() - b0).count();
-		gateSeconds += std::chrono::duration<double>(f1 - f0).count();
-		orderSeconds += std::chrono::duration<double>(f0 - b0).count();
 		for (Task *t : batch) {
-			t->ss = ss; t->seq = seq; t->issued = true;
+			t->ss = ss; t->seq = seq;
+			t->issued.store(true, std::memory_order_release);
+			succAll.insert(succAll.end(), t->succ.begin(), t->succ.end());
+			t->succ.clear();
+		}
+		if (batch.size() > 1) { ++D.batchesRun; D.batchedTasks += (long)batch.size(); } else ++D.loneTasks;
+		if (trace && batch[0]->kind) ++D.sizeHist[batch[0]->kind][(int)batch.size()];
+		D.waits += waits; D.records += records;
+		D.busySeconds += std::chrono::duration<double>(clk::now() - b0).count();
+		D.gateSeconds += std::chrono::duration<double>(f1 - f0).count();
+		D.orderSeconds += std::chrono::duration<double>(f0 - b0).count();
+		lk.unlock();
+		std::vector<CuPolynomial *> dead;
+		for (Task *t : batch) {
 			for (Task *d : t->deps) unrefTask(d);
 			t->deps.clear();
 			for (Node *n : t->nodes) unrefNode(n, dead);
 			t->nodes.clear();
-			for (Task *x : t->succ) if (--x->pending == 0) makeReady(x, me, &next);
-			t->succ.clear();
-			--outstanding;
-			unrefTask(t);
 		}
-		if (stagedCount && busyRegular == 0) cvReady.notify_all();     // a group that waited for the regular work to drain
+		for (Task *x : succAll) if (x->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) makeReady(x, &next);
+		outstanding.fetch_sub((long)batch.size(), std::memory_order_acq_rel);
+		{ std::lock_guard<std::mutex> dl(doneMu); }
 		cvDone.notify_all();
-		if (!dead.empty()) {
-			lk.unlock();
-			for (CuPolynomial *p : dead) delete p;
-			lk.lock();
-		}
+		for (Task *t : batch) unrefTask(t);
+		for (CuPolynomial *p : dead) delete p;
+		lk.lock();
+		if (asBatch) --D.busyBatch; else --D.busyRegular;                // (only now: what this task made ready has been staged)
+		if (D.stagedCount && D.busyRegular == 0) D.cv.notify_all();     // groups that waited for the work in flight to drain
 	}
+}
+
+DevState &deviceState(int dev) {
+	if (dev < 0) dev = 0;
+	if (dev >= kMaxDevices) { fprintf(stderr, "scheduler: device %d out of range\n", dev); exit(-1); }
+	DevState *D = devs[dev];
+	if (D) return *D;
+	std::lock_guard<std::mutex> lk(devsMu);
+	if (!devs[dev]) { DevState *n = new DevState; n->dev = dev; devs[dev] = n; }
+	return *devs[dev];
+}
+// workers of a device: started when the mode is switched on (devices known then) or at the first task recorded for the device
+void ensureWorkers(int dev) {
+	DevState &D = deviceState(dev);
+	{
+		std::lock_guard<std::mutex> lk(D.m);
+		if (!D.workers.empty()) return;
+	}
+	std::lock_guard<std::mutex> cl(devsMu);
+	std::unique_lock<std::mutex> lk(D.m);
+	if (!D.workers.empty()) return;
+	D.local.assign(workersPerDev, std::deque<Task *>());
+	D.started = 0;
+	for (int i = 0; i < workersPerDev; ++i) D.workers.emplace_back(workerMain, &D, i);
+	const int n = workersPerDev;
+	D.cv.wait(lk, [&D, n] { return D.started == n; });      // their streams exist
 }
 
 struct AtExit { ~AtExit() {                 // idle workers must not outlive the process's static state
-	if (tlsWorker) { for (auto &w : workers) w.detach(); return; }      // exit(-1) from a failed call inside a task: nothing to wait for
-	{ std::lock_guard<std::mutex> lk(mu); stopping = true; }
-	cvReady.notify_all();
-	for (auto &w : workers) if (w.joinable()) w.join();
-	workers.clear();
+	if (tlsWorker) { for (DevState *D : devs) if (D) for (auto &w : D->workers) w.detach(); return; }      // exit(-1) from a failed call inside a task: nothing to wait for
+	stopping.store(true);
+	for (DevState *D : devs) if (D) { { std::lock_guard<std::mutex> lk(D->m); } D->cv.notify_all(); }
+	for (DevState *D : devs) if (D) { for (auto &w : D->workers) if (w.joinable()) w.join(); D->workers.clear(); }
 } } atExit;
 } // namespace
 
-bool on() { return active; }
+bool on() { return active.load(std::memory_order_acquire); }
 bool inWorker() { return tlsWorker; }
 void *workerStream() { return tlsStream; }
-int threads() { return (int)workers.size(); }
+int threads() { int n = 0; for (DevState *D : devs) if (D) n += (int)D->workers.size(); return n; }
 
 void start(int n) {
-	std::unique_lock<std::mutex> lk(mu);
-	if (active) return;
+	if (active.load()) return;
+	std::lock_guard<std::mutex> rl(recMu);
+	if (active.load()) return;
 	if (n <= 0) { const char *e = getenv("CUHE_SCHED_THREADS"); n = e ? atoi(e) : 0; }
-	if (n <= 0) n = 3;                          // PRINCE gate by gate: 0.114-0.121 s with 3 workers, 0.126-0.133 with 4 (ready gates in batches of up to 64; profiles/r04_sched_prince.txt)
-	stopping = false; startedWorkers = 0;
+	if (n <= 0) n = 3;                          // per device.  PRINCE gate by gate on one device: profiles/r05_sched_prince.txt
+	workersPerDev = n;
+	stopping.store(false);
 	if (getenv("CUHE_SCHED_LOCAL")) stealing = atoi(getenv("CUHE_SCHED_LOCAL"));
-	local.assign(n, std::deque<Task *>());
-	for (int i = 0; i < n; ++i) workers.emplace_back(workerMain, i);
-	cvDone.wait(lk, [n] { return startedWorkers == n; });      // their streams exist
-	active = true;
+	if (getenv("CUHE_SCHED_POLICY")) policy = atoi(getenv("CUHE_SCHED_POLICY"));
+	if (getenv("CUHE_SCHED_QUIET_US")) quietNs = 1000L * atol(getenv("CUHE_SCHED_QUIET_US"));
+	trace = getenv("CUHE_SCHED_TRACE") ? atoi(getenv("CUHE_SCHED_TRACE")) : 0;
+	const int nd = std::max(1, std::min(cuhe_hip_num_gpus(), kMaxDevices));
+	for (int d = 0; d < nd; ++d) ensureWorkers(d);
+	active.store(true, std::memory_order_release);
 }
 void drain() {
-	std::vector<char> used;
 	{
-		std::unique_lock<std::mutex> lk(mu);
-		cvDone.wait(lk, [] { return outstanding == 0; });
-		used = devUsed;
+		std::unique_lock<std::mutex> lk(doneMu);
+		cvDone.wait(lk, [] { return outstanding.load(std::memory_order_acquire) == 0; });
 	}
-	for (size_t d = 0; d < used.size(); ++d) if (used[d]) CSC(cuhe_hip_device_sync((int)d));
+	for (int d = 0; d < kMaxDevices; ++d) {
+		DevState *D = devs[d];
+		if (!D) continue;
+		bool used;
+		{ std::lock_guard<std::mutex> lk(D->m); used = D->used; }
+		if (used && cuhe_hip_is_initialised() && d < cuhe_hip_num_gpus()) CSC(cuhe_hip_device_sync(d));
+	}
 	flushCache();
 }
 void *taskAlloc(int dev, size_t bytes) {
-	StreamState *me = (int)tlsStreams.size() > dev ? tlsStreams[dev] : nullptr;
+	StreamState *me = tlsSS && tlsSS->dev == dev ? tlsSS : nullptr;
+	if (dev < 0 || dev >= kMaxDevices) return cuhe_hip_malloc(dev, bytes);
+	BlockCache &C = caches[dev];
 	Block b{nullptr, nullptr, 0};
 	{
-		std::lock_guard<std::mutex> lk(cacheMu);
-		cacheCheckGeneration();
-		if ((int)cache.size() <= dev) cache.resize(dev + 1);
-		auto it = cache[dev].find(bytes);
-		if (it != cache[dev].end() && !it->second.empty()) {
+		std::lock_guard<std::mutex> lk(C.m);
+		C.checkGeneration();
+		auto it = C.bySize.find(bytes);
+		if (it != C.bySize.end() && !it->second.empty()) {
 			std::deque<Block> &q = it->second;
 			size_t pick = q.size();
 			for (size_t i = q.size(); i-- > 0 && q.size() - i <= 8;) if (q[i].ss == me) { pick = i; break; }     // one of this stream's own: nothing to wait for
-			if (pick == q.size()) { pick = 0; ++cacheForeign; } else ++cacheHits;                              // else the one released longest ago
+			if (pick == q.size()) { pick = 0; ++C.foreign; } else ++C.hits;                                    // else the one released longest ago
 			b = q[pick]; q.erase(q.begin() + pick);
-		} else ++cacheMisses;
+		} else ++C.misses;
 	}
 	if (b.ptr) {
 		if (b.ss != me && me) orderAfter(dev, me->stream, b.ss, b.seq);
@@ -336,51 +459,86 @@ void *taskAlloc(int dev, size_t bytes) {
 	}
 	void *p = cuhe_hip_malloc(dev, bytes);
 	if (!p) return nullptr;
-	std::lock_guard<std::mutex> lk(cacheMu);
-	cacheSize[p] = bytes;
+	std::lock_guard<std::mutex> lk(C.m);
+	C.sizeOf[p] = bytes;
 	return p;
 }
 void forgetBlock(void *p) {                // released outside a task (the client thread, after a detach): the library owns it again
-	std::lock_guard<std::mutex> lk(cacheMu);
-	if (!cacheSize.empty()) cacheSize.erase(p);
+	for (int d = 0; d < kMaxDevices; ++d) {
+		if (!devs[d]) continue;               // (blocks are only ever handed out on devices that have run tasks)
+		BlockCache &C = caches[d];
+		std::lock_guard<std::mutex> lk(C.m);
+		if (!C.sizeOf.empty()) C.sizeOf.erase(p);
+	}
 }
 bool taskFree(int dev, void *p) {
-	StreamState *me = (int)tlsStreams.size() > dev ? tlsStreams[dev] : nullptr;
-	std::lock_guard<std::mutex> lk(cacheMu);
-	cacheCheckGeneration();
-	auto it = cacheSize.find(p);
-	if (it == cacheSize.end() || !me) return false;                 // not one of ours (allocated before the object was attached)
-	if ((int)cache.size() <= dev) cache.resize(dev + 1);
-	cache[dev][it->second].push_back(Block{p, me, me->seq.load(std::memory_order_relaxed) + 1});     // last use: the running task
+	StreamState *me = tlsSS && tlsSS->dev == dev ? tlsSS : nullptr;
+	if (dev < 0 || dev >= kMaxDevices) return false;
+	BlockCache &C = caches[dev];
+	std::lock_guard<std::mutex> lk(C.m);
+	C.checkGeneration();
+	auto it = C.sizeOf.find(p);
+	if (it == C.sizeOf.end() || !me) return false;                 // not one of ours (allocated before the object was attached)
+	C.bySize[it->second].push_back(Block{p, me, me->seq.load(std::memory_order_relaxed) + 1});     // last use: the running task
 	return true;
 }
 void stop() {
-	if (!active) return;
+	if (!active.load()) return;
 	drain();
-	{ std::lock_guard<std::mutex> lk(mu); stopping = true; active = false; }
-	cvReady.notify_all();
-	for (auto &w : workers) w.join();       // (their streams stay with the library: blocks parked on them settle as they go idle)
-	if (getenv("CUHE_SCHED_STATS")) {
+	active.store(false, std::memory_order_release);
+	stopping.store(true);
+	for (DevState *D : devs) if (D) { { std::lock_guard<std::mutex> lk(D->m); } D->cv.notify_all(); }
+	int nworkers = 0, ndev = 0;
+	for (DevState *D : devs) if (D) {
+		for (auto &w : D->workers) w.join();       // (their streams stay with the library: blocks parked on them settle as they go idle)
+		nworkers += (int)D->workers.size(); if (!D->workers.empty()) ++ndev;
+		D->workers.clear();
+	}
+	if (getenv("CUHE_SCHED_STATS") && atoi(getenv("CUHE_SCHED_STATS")) != 0) {
 		long long ac[4] = {0, 0, 0, 0};
 		cuhe_hip_alloc_counters(ac);
 		printf("allocator: %lld hipMalloc, %lld pool hits, %lld stream hits, %lld cross-stream hand-overs\n", ac[0], ac[1], ac[2], ac[3]);
-		printf("task blocks: %ld from the same stream, %ld from another stream (ordered behind their last use), %ld from the library\n", cacheHits, cacheForeign, cacheMisses);
-		printf("batches: %ld calls of the batch runner for %ld gates\n", batchesRun, batchedTasks);
-		printf("scheduler: %ld tasks, %ld cross-stream waits on %ld event records, at most %ld tasks recorded ahead; %zu workers busy %.3f s (%.3f in the gates, %.3f ordering streams), idle %.3f s in total\n",
-		       totalTasks, totalWaits, totalRecords, maxQueued, workers.size(), busySeconds, gateSeconds, orderSeconds, idleSeconds);
+		long hits = 0, foreign = 0, misses = 0;
+		for (BlockCache &C : caches) { hits += C.hits; foreign += C.foreign; misses += C.misses; }
+		printf("task blocks: %ld from the same stream, %ld from another stream (ordered behind their last use), %ld from the library\n", hits, foreign, misses);
+		long batches = 0, batched = 0, lone = 0, waits = 0, records = 0, incomplete = 0;
+		double busy = 0, gate = 0, order = 0, idle = 0;
+		for (DevState *D : devs) if (D) {
+			batches += D->batchesRun; batched += D->batchedTasks; lone += D->loneTasks; waits += D->waits; records += D->records; incomplete += D->incompleteTaken;
+			busy += D->busySeconds; gate += D->gateSeconds; order += D->orderSeconds; idle += D->idleSeconds;
+		}
+		printf("batches: %ld calls of the batch runner for %ld gates (%.1f per call; %ld groups taken before they were complete); %ld tasks ran alone; policy %d\n",
+		       batches, batched, batches ? (double)batched / batches : 0.0, incomplete, lone, policy);
+		printf("scheduler: %ld tasks, %ld cross-stream waits on %ld event records, at most %ld tasks recorded ahead; %d workers on %d device(s) busy %.3f s (%.3f in the gates, %.3f ordering streams), idle %.3f s in total\n",
+		       totalTasks.load(), waits, records, maxQueued.load(), nworkers, ndev, busy, gate, order, idle);
+		if (trace) {
+			static const char *names[] = {"-", "x2c", "x2n", "relin", "modSwitch", "cAnd", "cXor", "copy", "cNot"};
+			for (DevState *D : devs) if (D) for (auto &kh : D->sizeHist) {
+				long calls = 0, members = 0;
+				for (auto &sc : kh.second) { calls += sc.second; members += (long)sc.first * sc.second; }
+				printf("  device %d %-9s %5ld calls %6ld gates:", D->dev, kh.first >= 0 && kh.first <= 8 ? names[kh.first] : "?", calls, members);
+				for (auto &sc : kh.second) printf(" %dx%ld", sc.first, sc.second);
+				printf("\n");
+			}
+		}
 	}
-	workers.clear();
+	for (DevState *D : devs) if (D) {
+		D->batchesRun = D->batchedTasks = D->loneTasks = D->waits = D->records = D->incompleteTaken = 0;
+		D->busySeconds = D->idleSeconds = D->gateSeconds = D->orderSeconds = 0; D->sizeHist.clear(); D->used = false;
+	}
+	for (BlockCache &C : caches) C.hits = C.foreign = C.misses = 0;
+	totalTasks.store(0); maxQueued.store(0);
 }
 
 Node *newNode(CuPolynomial *obj) { Node *n = new Node; n->obj = obj; return n; }
 void releaseNode(Node *n) {
 	std::vector<CuPolynomial *> dead;
-	{ std::lock_guard<std::mutex> lk(mu); unrefNode(n, dead); }
+	unrefNode(n, dead);
 	for (CuPolynomial *p : dead) delete p;
 }
 
 void setBatchRunner(BatchRunner r, int mb) {
-	std::lock_guard<std::mutex> lk(mu);
+	std::lock_guard<std::mutex> lk(recMu);
 	const char *e = getenv("CUHE_SCHED_BATCH");
 	batchRunner = (e && atoi(e) == 0) ? nullptr : r;
 	maxBatch = e && atoi(e) > 1 ? atoi(e) : mb;
@@ -389,67 +547,79 @@ void setBatchRunner(BatchRunner r, int mb) {
 Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep, int kind, long key, Node *subject,
              Node *op1, Node *op2) {
 	if (dev < 0) dev = 0;                       // (an object that was never placed: its task only releases host state)
+	ensureWorkers(dev);
 	Task *t = new Task;
 	t->fn = std::move(fn); t->dev = dev; t->kind = kind; t->key = key; t->subject = subject; t->op1 = op1; t->op2 = op2;
-	std::lock_guard<std::mutex> lk(mu);
-	auto after = [&](Task *d) {
-		if (!d) return;
-		for (Task *e : t->deps) if (e == d) return;
-		++d->refs; t->deps.push_back(d);
-		if (!d->issued) { d->succ.push_back(t); ++t->pending; }
-	};
-	auto written = [&](Node *n) { return std::find(writes.begin(), writes.end(), n) != writes.end(); };
-	auto held = [&](Node *n) { return std::find(t->nodes.begin(), t->nodes.end(), n) != t->nodes.end(); };
-	for (Node *r : reads) after(r->lastWrite);
-	for (Node *w : writes) { after(w->lastWrite); for (Task *r : w->readers) after(r); }
-	for (Node *r : reads) {
-		if (written(r)) continue;
-		if (!r->readers.empty() && r->readers.back() == t) continue;      // listed twice (cAnd(out, x, x)): one entry, one reference
-		if (r->readers.size() >= 24) pruneReaders(r);
-		r->readers.push_back(t); ++t->refs;
+	const bool batchable = kind && batchRunner && maxBatch > 1;
+	{
+		std::lock_guard<std::mutex> lk(recMu);
+		t->id = nextId.fetch_add(1) + 1;
+		auto after = [&](Task *d) {
+			if (!d) return;
+			for (Task *e : t->deps) if (e == d) return;
+			d->refs.fetch_add(1, std::memory_order_relaxed); t->deps.push_back(d);
+			DevState &P = deviceState(d->dev);
+			std::lock_guard<std::mutex> dl(P.m);
+			if (!d->issued.load(std::memory_order_acquire)) { d->succ.push_back(t); t->pending.fetch_add(1, std::memory_order_relaxed); }
+		};
+		auto written = [&](Node *n) { return std::find(writes.begin(), writes.end(), n) != writes.end(); };
+		auto held = [&](Node *n) { return std::find(t->nodes.begin(), t->nodes.end(), n) != t->nodes.end(); };
+		for (Node *r : reads) after(r->lastWrite);
+		for (Node *w : writes) { after(w->lastWrite); for (Task *r : w->readers) after(r); }
+		for (Node *r : reads) {
+			if (written(r)) continue;
+			if (!r->readers.empty() && r->readers.back() == t) continue;      // listed twice (cAnd(out, x, x)): one entry, one reference
+			if (r->readers.size() >= 24) pruneReaders(r);
+			r->readers.push_back(t); t->refs.fetch_add(1, std::memory_order_relaxed);
+		}
+		for (Node *w : writes) {
+			if (held(w)) continue;                  // (listed twice)
+			for (Task *r : w->readers) unrefTask(r);
+			w->readers.clear();
+			if (w->lastWrite) unrefTask(w->lastWrite);
+			w->lastWrite = t; t->refs.fetch_add(1, std::memory_order_relaxed);
+			w->refs.fetch_add(1, std::memory_order_relaxed); t->nodes.push_back(w);
+		}
+		for (Node *r : reads) if (!held(r)) { r->refs.fetch_add(1, std::memory_order_relaxed); t->nodes.push_back(r); }
+		if (keep) t->refs.fetch_add(1, std::memory_order_relaxed);
 	}
-	for (Node *w : writes) {
-		if (held(w)) continue;                  // (listed twice)
-		for (Task *r : w->readers) unrefTask(r);
-		w->readers.clear();
-		if (w->lastWrite) unrefTask(w->lastWrite);
-		w->lastWrite = t; ++t->refs;
-		++w->refs; t->nodes.push_back(w);
+	const long out = outstanding.fetch_add(1, std::memory_order_acq_rel) + 1;
+	totalTasks.fetch_add(1, std::memory_order_relaxed);
+	long mq = maxQueued.load(std::memory_order_relaxed);
+	while (out > mq && !maxQueued.compare_exchange_weak(mq, out)) {}
+	if (batchable) {                            // one more gate of this (kind, key) is on its way to the device's staging area
+		DevState &D = deviceState(dev);
+		std::lock_guard<std::mutex> dl(D.m);
+		++D.groupPending[GroupKey{kind, key}];
 	}
-	for (Node *r : reads) if (!held(r)) { ++r->refs; t->nodes.push_back(r); }
-	if (keep) ++t->refs;
-	++outstanding; ++totalTasks;
-	if (outstanding > maxQueued) maxQueued = outstanding;
-	if (t->pending == 0) makeReady(t, -1, nullptr);
+	if (t->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) makeReady(t, nullptr);       // (the linking guard goes: the task is published)
 	return t;
 }
 
 // the client needs the task's device work finished: an event of its own behind the task on the task's stream
 void wait(Task *t) {
-	StreamState *ss;
 	{
-		std::unique_lock<std::mutex> lk(mu);
-		cvDone.wait(lk, [t] { return t->issued; });
-		ss = t->ss;
+		std::unique_lock<std::mutex> lk(doneMu);
+		cvDone.wait(lk, [t] { return t->issued.load(std::memory_order_acquire); });
 	}
+	StreamState *ss = t->ss;
 	thread_local std::vector<void *> mine;      // per client thread and device
 	if ((int)mine.size() <= ss->dev) mine.resize(ss->dev + 1, nullptr);
 	if (!mine[ss->dev]) CSC(cuhe_hip_event_create(ss->dev, &mine[ss->dev]));
 	CSC(cuhe_hip_event_record(ss->dev, mine[ss->dev], ss->stream));
 	CSC(cuhe_hip_event_sync(ss->dev, mine[ss->dev]));
-	std::lock_guard<std::mutex> lk(mu);
 	unrefTask(t);
 }
 void waitNode(Node *n) {
 	std::vector<Task *> ts;
 	{
-		std::lock_guard<std::mutex> lk(mu);
-		if (n->lastWrite) { ++n->lastWrite->refs; ts.push_back(n->lastWrite); }
-		for (Task *r : n->readers) { ++r->refs; ts.push_back(r); }
+		std::lock_guard<std::mutex> lk(recMu);
+		if (n->lastWrite) { n->lastWrite->refs.fetch_add(1, std::memory_order_relaxed); ts.push_back(n->lastWrite); }
+		for (Task *r : n->readers) { r->refs.fetch_add(1, std::memory_order_relaxed); ts.push_back(r); }
 	}
 	for (Task *t : ts) wait(t);
 }
-Stats stats() { std::lock_guard<std::mutex> lk(mu); return Stats{totalTasks, totalWaits, maxQueued}; }
+Stats stats() { return Stats{totalTasks.load(), 0, maxQueued.load()}; }
 
 } // namespace sched
 } // namespace cuHE

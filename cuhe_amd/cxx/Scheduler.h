@@ -5,13 +5,14 @@
 // kernel at a time although, e.g., the six products and sixteen S-boxes of a PRINCE layer are independent.  In scheduled
 // mode (setScheduled(true) or CUHE_SCHED=1 in the environment) a public gate only RECORDS a task: which polynomials it
 // reads, which it writes, and the gate itself as a closure over their scheduler-side objects.  A small pool of worker
-// threads owned by the library issues the tasks, each worker on its own stream per device (and, like every host thread of
-// this library, with its own scratch): a task is issued as soon as the tasks it depends on have been issued, ordered on
+// threads owned by the library issues the tasks -- every device of multiGPUs(n) has its own workers, queues and lock, each
+// worker on its own stream of its device (and, like every host thread of this library, with its own scratch): a task is issued as soon as the tasks it depends on have been issued, ordered on
 // the GPU by events (stream-wait on the event of every dependency that ran on another stream).  The client thread blocks
 // only where it needs a value on the host (x2z), a raw device pointer, or calls synchronize().
 //
 // This header is the graph half: tasks, nodes, workers.  CuHE.cpp binds the gates to it.
 #pragma once
+#include <atomic>
 #include <functional>
 #include <vector>
 
@@ -25,15 +26,15 @@ struct Task;
 // on the node, reads after the last write).
 struct Node {
 	CuPolynomial *obj = nullptr;
-	Task *lastWrite = nullptr;             // graph state, guarded by the scheduler's mutex
+	Task *lastWrite = nullptr;             // graph state, guarded by the scheduler's recording lock (only the recording side touches it)
 	std::vector<Task *> readers;
-	int refs = 1;                          // the client object + every task that has not run yet (same mutex)
+	std::atomic<int> refs{1};              // the client object + every task that has not run yet
 };
 
 bool on();                                 // scheduled mode is in effect
 bool inWorker();                           // the calling thread is one of the scheduler's workers
 void *workerStream();                      // inside a task: the stream the task runs on
-void start(int threads);                   // idempotent; threads <= 0: CUHE_SCHED_THREADS or the default
+void start(int threads);                   // idempotent; threads = workers PER DEVICE (<= 0: CUHE_SCHED_THREADS or the default, 3)
 void stop();                               // drains, joins the workers, leaves scheduled mode
 int threads();
 

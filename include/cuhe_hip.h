@@ -260,11 +260,16 @@ int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, i
    ready gates of one kind on separately owned ciphertexts as one call of the array entry points above and below. */
 int cuhe_hip_gather_blocks(void *dst, const void *const *srcs, int count, size_t bytes, int dev, void *stream);
 int cuhe_hip_scatter_blocks(void *const *dsts, const void *src, int count, size_t bytes, int dev, void *stream);
-/* elementwise gates over LISTS of separately owned ciphertexts of one level, one launch per 32: ct rows z = x * y (mul != 0) or
+/* elementwise gates over LISTS of separately owned ciphertexts of one level, one launch per 64: ct rows z = x * y (mul != 0) or
    x + y modulo P (cAnd / cXor in the NTT domain), CRT rows z = (a + b) mod p (cXor in the CRT domain); lists in host memory */
 int cuhe_hip_ct_binop_list(int mul, void *const *z, const void *const *x, const void *const *y, int count, int logq, int dev, void *stream);
 int cuhe_hip_crt_add_list(void *const *z, const void *const *a, const void *const *b, int count, int logq, int dev, void *stream);
-/* dst[i] = src[i] for `count` separately owned blocks of `bytes` bytes (a multiple of 16): copy() over a list, one launch per 32 */
+/* modSwitch over a list: dst[i] <- src[i] one level down (np -> np - 1 rows), dst[i] == src[i] allowed (in place, in the ciphertext's own
+   block: CuCtxt::modSwitch, CuHE.cu:583-594); cNot over a list: z[i] = x[i] + a on the constant coefficient of every row, other
+   coefficients copied when z[i] != x[i] (cNot, CuHE.cu:176-187; crt_add_int, Base.cu:1096-1100).  One launch per 64 ciphertexts. */
+int cuhe_hip_crt_mod_switch_list(void *const *dst, const void *const *src, int lvl, int count, int dev, void *stream);
+int cuhe_hip_crt_add_int_list(void *const *z, const void *const *x, unsigned a, int count, int logq, int dev, void *stream);
+/* dst[i] = src[i] for `count` separately owned blocks of `bytes` bytes (a multiple of 16): copy() over a list, one launch per 64 */
 int cuhe_hip_copy_list(void *const *dst, const void *const *src, int count, size_t bytes, int dev, void *stream);
 /* n2c of `batch` NON-product ciphertexts of one level in one array (intt_mod_batch is the form for products) */
 int cuhe_hip_intt_batch(uint32_t *dst_crt, const uint64_t *src_ntt, int lvl, int batch, int dev, void *stream);

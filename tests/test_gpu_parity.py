@@ -1256,13 +1256,15 @@ def test_list_block_and_event_entry_points(gu, name):
     generalises: gather / scatter / copy of separately owned blocks through pointer lists, cAnd / cXor over lists
     (cuhe_hip_ct_binop_list, cuhe_hip_crt_add_list) against cuhe_hip_ct_mul / ct_add / crt_add per ciphertext, the array form of
     n2c for non-products (cuhe_hip_intt_batch) against cuhe_hip_ct_intt, the event calls, and the diagnostics
-    (allocator counters, generation, transform scratch, dispatch info).  A cyclic and a negacyclic ring; 37 ciphertexts (two launches of the list kernels)."""
+    (allocator counters, generation, transform scratch, dispatch info); round 5: modSwitch and cNot over lists (cuhe_hip_crt_mod_switch_list,
+    cuhe_hip_crt_add_int_list), in place and into other blocks, against cuhe_hip_crt_mod_switch / crt_add_int per ciphertext.  A cyclic and a
+    negacyclic ring; 70 ciphertexts (two launches of the list kernels)."""
     import ctypes as C
     lib, ck = gu.lib, gu.ck
     g = gu.GpuCtx(*PSETS[name])
     try:
         q = g.prm
-        lvl, n = 1, 37
+        lvl, n = 1, 70
         npr, logq, ctlen = g.np_(lvl), g.logq(lvl), g.ctlen
         rng = np.random.default_rng(77)
         crt = [np.zeros((npr, q.crtLen), dtype=np.uint32) for _ in range(2 * n)]
@@ -1291,19 +1293,48 @@ def test_list_block_and_event_entry_points(gu, name):
             z = [gu.empty_u64(npr, ctlen) for _ in range(n)]
             ck(lib.cuhe_hip_ct_binop_list(mul, plist(z), plist(dntt[:n]), plist(dntt[n:]), n, logq, 0, None))
             want = gu.empty_u64(npr, ctlen)
-            for i in (0, 17, 31, 32, 36):
+            for i in (0, 17, 63, 64, 69):
                 ck(single(want.data_ptr(), dntt[i].data_ptr(), dntt[n + i].data_ptr(), logq, 0, None))
                 assert np.array_equal(gu.host_u64(z[i]), gu.host_u64(want)), (mul, i)
         zc = [gu.empty_u32(npr, q.crtLen) for _ in range(n)]
         ck(lib.cuhe_hip_crt_add_list(plist(zc), plist(dcrt[:n]), plist(dcrt[n:]), n, logq, 0, None))
         wantc = gu.empty_u32(npr, q.crtLen)
-        for i in (0, 31, 32, 36):
+        for i in (0, 63, 64, 69):
             ck(lib.cuhe_hip_crt_add(wantc.data_ptr(), dcrt[i].data_ptr(), dcrt[n + i].data_ptr(), logq, 0, None))
             assert np.array_equal(gu.host_u32(zc[i]), gu.host_u32(wantc)), i
         # in place (out = first operand), as cXor(out, out, term) records it
         ck(lib.cuhe_hip_crt_add_list(plist(zc), plist(zc), plist(dcrt[n:]), n, logq, 0, None))
-        ck(lib.cuhe_hip_crt_add(wantc.data_ptr(), wantc.data_ptr(), dcrt[n + 36].data_ptr(), logq, 0, None))
-        assert np.array_equal(gu.host_u32(zc[36]), gu.host_u32(wantc))
+        ck(lib.cuhe_hip_crt_add(wantc.data_ptr(), wantc.data_ptr(), dcrt[n + 69].data_ptr(), logq, 0, None))
+        assert np.array_equal(gu.host_u32(zc[69]), gu.host_u32(wantc))
+        # ---- cNot over a list: into other blocks (every coefficient copied) and in place (constant terms only)
+        a_not = q.modMsg - 1
+        zn = [gu.empty_u32(npr, q.crtLen) for _ in range(n)]
+        for t in zn: t.zero_()
+        ck(lib.cuhe_hip_crt_add_int_list(plist(zn), plist(dcrt[:n]), a_not, n, logq, 0, None))
+        for i in (0, 63, 64, 69):
+            wn = gu.to_dev(crt[i])
+            ck(lib.cuhe_hip_crt_add_int(wn.data_ptr(), wn.data_ptr(), a_not, logq, 0, None))
+            assert np.array_equal(gu.host_u32(zn[i]), gu.host_u32(wn)), i
+            assert np.array_equal(gu.host_u32(zn[i])[:, 0], (crt[i][:, 0].astype(np.uint64) + a_not) % g.primes[:npr].astype(np.uint64)), i
+        ck(lib.cuhe_hip_crt_add_int_list(plist(zn), plist(zn), a_not, n, logq, 0, None))            # in place: + 2 (modMsg - 1) in all
+        for i in (0, 64, 69):
+            want2 = crt[i].copy(); want2[:, 0] = (crt[i][:, 0].astype(np.uint64) + 2 * a_not) % g.primes[:npr].astype(np.uint64)
+            assert np.array_equal(gu.host_u32(zn[i]), want2), i
+        # ---- modSwitch over a list: into other blocks and inside the ciphertexts' own blocks, against the single entry point
+        if npr >= 2 and lvl + 1 < q.depth:
+            zm = [gu.empty_u32(npr, q.crtLen) for _ in range(n)]
+            for t in zm: t.zero_()
+            ck(lib.cuhe_hip_crt_mod_switch_list(plist(zm), plist(dcrt[:n]), lvl, n, 0, None))
+            wm = gu.empty_u32(npr, q.crtLen); wm.zero_()
+            for i in (0, 17, 63, 64, 69):
+                ck(lib.cuhe_hip_crt_mod_switch(wm.data_ptr(), dcrt[i].data_ptr(), logq, 0, None))
+                assert np.array_equal(gu.host_u32(zm[i])[:npr - 1], gu.host_u32(wm)[:npr - 1]), i
+            own = [gu.to_dev(c) for c in crt[:n]]
+            ck(lib.cuhe_hip_crt_mod_switch_list(plist(own), plist(own), lvl, n, 0, None))
+            for i in range(n):
+                assert np.array_equal(gu.host_u32(own[i])[:npr - 1], gu.host_u32(zm[i])[:npr - 1]), i
+                assert np.array_equal(gu.host_u32(own[i])[npr - 1], crt[i][npr - 1]), i                 # the dropped row is never written
+            assert lib.cuhe_hip_crt_mod_switch_list(plist(own), plist(own), q.depth - 1, n, 0, None) != 0
         # ---- n2c of non-products over an array
         nbytes = npr * ctlen * 8
         narr = gu.empty_u64(n, npr, ctlen)
