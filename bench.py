@@ -831,12 +831,17 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
     ck(lib.cuhe_hip_ct_ntt(na.data_ptr(), a.data_ptr(), logq, 0, None))
     ck(lib.cuhe_hip_ct_ntt(nb.data_ptr(), b.data_ptr(), logq, 0, None))
 
+    fused = True          # what CuCtxt::relin does since round 5; the two-call form is timed beside it below
+
     def one():
         ck(lib.cuhe_hip_ct_mul(nc.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))       # cAnd
         ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), nc.data_ptr(), logq, 1, 0, None))                   # relin: x2r
         ck(lib.cuhe_hip_icrt(raw.data_ptr(), cr.data_ptr(), logq, 0, None))
-        ck(lib.cuhe_hip_relinearization(nc.data_ptr(), raw.data_ptr(), 0, 0, None))
-        ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), nc.data_ptr(), logq, 1, 0, None))                   # n2c
+        if fused:       # relinearization ; n2c as the one call CuCtxt::relin makes (round 5): the key stream beside the transforms
+            ck(lib.cuhe_hip_relin_crt(cr.data_ptr(), raw.data_ptr(), 0, 0, None))
+        else:
+            ck(lib.cuhe_hip_relinearization(nc.data_ptr(), raw.data_ptr(), 0, 0, None))
+            ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), nc.data_ptr(), logq, 1, 0, None))                   # n2c
 
     for _ in range(3):
         one()
@@ -848,6 +853,24 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     single_dispatch = dispatch_info(lib)              # (of the chain's last transform call: the inverse rows of the result)
+    # the same chain with relinearization and n2c as two calls on one stream (rounds 1-4), and the fused call without its overlap: same results
+    single_variants = {}
+    try:
+        ref = cr.clone()
+        for label, fz, ov in (("two_calls", False, 1), ("fused_no_overlap", True, 0), ("fused", True, 1)):
+            fused = fz
+            ck(lib.cuhe_hip_set_relin_overlap(ov))
+            one(); torch.cuda.synchronize()
+            assert torch.equal(cr, ref), "single chain (%s) differs" % label
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                one()
+            torch.cuda.synchronize()
+            single_variants[label + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    except Exception as ex:
+        single_variants["error"] = repr(ex)[:200]
+    fused = True
+    ck(lib.cuhe_hip_set_relin_overlap(1))
     key_bytes = 8 * K * npn * L
     # ---- the same chain for B independent ciphertexts per call (cuhe_hip_mul_relin_batch): every stage runs over
     # B*np rows and a key value fetched from HBM serves four ciphertexts; results are bit-identical (checked below)
@@ -948,6 +971,7 @@ def bench_mulrelin(lib, ck, torch, np, dev, args, params):
             "params": {"setParameters": [d, p, w, mn, cut, m], "ring_degree": q.modLen, "numCrtPrime": npn, "numEvalKey": K, "transform": rep},
             "algorithmic_bytes": key_bytes, "achieved_GBs": round(key_bytes / dt / 1e9, 1),
             "frac_hbm": round(key_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "key_upload_s": round(init_s, 2), "dispatch_last_transform": single_dispatch,
+            "chain": "ct_mul ; ct_intt ; icrt ; relin_crt (relinearization + n2c as one call: the key stream beside the transforms)", "variants": single_variants,
             "batched": batched, "concurrent": concurrent}
 
 

@@ -80,6 +80,8 @@ struct Workspace {
     hipEvent_t ev = nullptr;             // orders this thread's work when it moves to another stream
     // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
     hipStream_t lane_stream = nullptr; hipEvent_t ev_lane = nullptr, ev_in = nullptr;
+    // the single-ciphertext relinearisation chain with its key stream beside the transforms (cuhe_hip_relin_crt): sums, events
+    u64 *rc_acc = nullptr; std::vector<hipEvent_t> rc_ev;
 };
 struct IcrtLevel {
     u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0;

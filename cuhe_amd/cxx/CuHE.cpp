@@ -650,14 +650,15 @@ void CuCtxt::relin(cudaStream_t st) {
 		return;
 	}
 	{
+		// x2r ; relinearization ; n2c (cuhe/CuHE.cu:570-581) -- the last two as one call of the library, which runs the key stream
+		// beside the window / inverse transforms (cuhe_hip_relin_crt); the ciphertext ends reduced, in the CRT domain, as before
 		GateScope chain;
 		x2r(st);
-		nRepAlloc(st);
-		relinearization(nRep_, rRep_, level_, device_, st);
+		cRepAlloc(st);
+		CSC(cuhe_hip_relin_crt(cRep_, rRep_, level_, device_, st));
 		rRepFree();
-		isProd_ = true;
-		domain_ = 3;
-		n2c(st);
+		isProd_ = false; prodTerms_ = 0;
+		domain_ = 2;
 	}
 	GATE_SYNC(device_, st);
 }

@@ -224,8 +224,9 @@ class GpuCtx:
         ck(lib.cuhe_hip_icrt(out.data_ptr(), ca.data_ptr(), logq, 0, None))
         return host_u32(out)
 
-    def mul_relin_crt(self, a_crt, b_crt, lvl):
-        """cAnd + relin (cuhe/CuHE.cu:101,570-581), operands and result in the CRT domain."""
+    def mul_relin_crt(self, a_crt, b_crt, lvl, fused=False):
+        """cAnd + relin (cuhe/CuHE.cu:101,570-581), operands and result in the CRT domain.  fused: relinearization ; n2c as the ONE
+        call CuCtxt::relin makes since round 5 (cuhe_hip_relin_crt)."""
         logq = self.logq(lvl)
         np_, q = self.np_(lvl), self.prm
         ca, cb = to_dev(a_crt), to_dev(b_crt)
@@ -237,6 +238,9 @@ class GpuCtx:
         ck(lib.cuhe_hip_ct_mul(na.data_ptr(), na.data_ptr(), nb.data_ptr(), logq, 0, None))
         ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), na.data_ptr(), logq, 1, 0, None))
         ck(lib.cuhe_hip_icrt(raw.data_ptr(), cr.data_ptr(), logq, 0, None))
+        if fused:
+            ck(lib.cuhe_hip_relin_crt(cr.data_ptr(), raw.data_ptr(), lvl, 0, None))
+            return host_u32(cr)
         ck(lib.cuhe_hip_relinearization(na.data_ptr(), raw.data_ptr(), lvl, 0, None))
         ck(lib.cuhe_hip_ct_intt(cr.data_ptr(), na.data_ptr(), logq, 1, 0, None))
         return host_u32(cr)
