@@ -158,7 +158,6 @@ SIGNATURES = {
     "cuhe_hip_comm_info": (i32, [vp, sz]),
     "cuhe_hip_comm_force_exchange": (i32, [i32]),
     "cuhe_hip_relin_crt": (i32, [vp, vp, i32, i32, vp]),
-    "cuhe_hip_set_relin_overlap": (i32, [i32]),
     "cuhe_hip_exchange_path": (i32, [i32, i32, i32]),
     "cuhe_hip_allgather_rows": (i32, [vp, i32, i32, vp]),
     "cuhe_hip_mul_relin_sharded": (i32, [vp, vp, vp, i32, i32, vp]),

@@ -100,17 +100,41 @@ int ws_relin(Workspace &w, int cts) {
     const Params &q = G_.prm;
     if (w.n_relin >= (size_t)cts && w.relin) return CUHE_OK;
     size_t a = 0, b = 0;
-    if (w.relin) { HIPCHK(hipFree(w.relin)); w.relin = nullptr; }
-    if (w.win) { HIPCHK(hipFree(w.win)); w.win = nullptr; }
+    if (w.relin) { ws_retire(w.relin); w.relin = nullptr; }
+    if (w.win) { ws_retire(w.win); w.win = nullptr; }
     CHK(ws_grow(&w.relin, &a, (size_t)cts * q.numEvalKey * q.nttLen)); CHK(ws_grow(&w.win, &b, (size_t)cts * q.numEvalKey * q.crtLen));
     w.n_relin = cts;
     return CUHE_OK;
 }
+static std::mutex g_retired_mu;
+static std::vector<std::pair<int, void *>> g_retired;              // (physical device, pointer)
+void ws_retire(void *p) {
+    if (!p) return;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = -1; }
+    std::lock_guard<std::mutex> lk(g_retired_mu);
+    g_retired.push_back({d, p});
+}
+// the device `phys` is idle (or everything goes: phys < 0, at shutdown): the retired buffers can be freed
+static void free_retired(int phys) {
+    std::vector<std::pair<int, void *>> take;
+    {
+        std::lock_guard<std::mutex> lk(g_retired_mu);
+        for (size_t i = 0; i < g_retired.size();)
+            if (phys < 0 || g_retired[i].first == phys || g_retired[i].first < 0) { take.push_back(g_retired[i]); g_retired[i] = g_retired.back(); g_retired.pop_back(); } else ++i;
+    }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto &e : take) {
+        if (e.first >= 0 && (!have || e.first != cur)) { if (hipSetDevice(e.first) != hipSuccess) (void)hipGetLastError(); else cur = e.first; }
+        if (hipFree(e.second) != hipSuccess) (void)hipGetLastError();
+    }
+}
 int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        // grow-only
     if (w.slab_bytes[li][which] < bytes) {
-        // hipFree waits for the whole device: grow geometrically, so that a caller whose row counts creep up (the gate scheduler's
-        // batches) pays for a handful of re-allocations, not one per new maximum
-        if (w.slab[li][which]) { HIPCHK(hipFree(w.slab[li][which])); bytes = std::max(bytes, 2 * w.slab_bytes[li][which]); }
+        // grow geometrically, so that a caller whose row counts creep up (the gate scheduler's batches) pays for a handful of
+        // re-allocations, not one per new maximum; the outgrown slab is retired (ws_retire), not freed
+        if (w.slab[li][which]) { ws_retire(w.slab[li][which]); bytes = std::max(bytes, 2 * w.slab_bytes[li][which]); }
         w.slab[li][which] = nullptr; w.slab_bytes[li][which] = 0;
         HIPCHK(hipMalloc((void **)&w.slab[li][which], bytes));
         w.slab_bytes[li][which] = bytes;
@@ -122,7 +146,6 @@ void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
     void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->mr_ntt, w->mr_crt,
                     w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out, w->pair_cnt, w->rc_acc};
-    for (hipEvent_t e : w->rc_ev) hipEventDestroy(e);
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     if (w->ev_lane) hipEventDestroy(w->ev_lane);
@@ -437,6 +460,7 @@ int cuhe_hip_shutdown(void) {
         D = DevCtx();
         D.ownStreams.swap(keep);
     }
+    free_retired(-1);
     G_.inited = false; G_.relin_ready = false; G_.allocator_on = false;
     ++G_.generation;
     return CUHE_OK;
@@ -727,6 +751,7 @@ int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_in
 int cuhe_hip_device_sync(int dev) {
     CHK(set_dev(dev));
     HIPCHK(hipDeviceSynchronize());
+    { int phys = 0; if (hipGetDevice(&phys) == hipSuccess) free_retired(phys); else (void)hipGetLastError(); }
     DevCtx &D = G_.dev[dev];
     std::lock_guard<std::mutex> lk(G_.mu);
     for (auto &sb : D.streamBlocks) for (auto &kv : sb.second) D.freeBlocks.insert(kv);

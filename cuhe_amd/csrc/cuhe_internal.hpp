@@ -80,8 +80,7 @@ struct Workspace {
     hipEvent_t ev = nullptr;             // orders this thread's work when it moves to another stream
     // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
     hipStream_t lane_stream = nullptr; hipEvent_t ev_lane = nullptr, ev_in = nullptr;
-    // the single-ciphertext relinearisation chain with its key stream beside the transforms (cuhe_hip_relin_crt): sums, events
-    u64 *rc_acc = nullptr; std::vector<hipEvent_t> rc_ev;
+    u64 *rc_acc = nullptr;               // the sums of the single-ciphertext relinearisation chain (cuhe_hip_relin_crt)
 };
 struct IcrtLevel {
     u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0;
@@ -224,10 +223,15 @@ int ws_buffer(T **ptr, size_t count) {           // lazily allocated, fixed-size
     if (!*ptr) HIPCHK(hipMalloc((void **)ptr, std::max<size_t>(count, 1) * sizeof(T)));
     return CUHE_OK;
 }
+// A scratch buffer that has been outgrown is RETIRED, not freed: hipFree waits for the whole device, and under the gate scheduler
+// that wait sat in the middle of the first block of a process (481 hipFree calls, 146 ms: profiles/r05_sched_prince.txt).  Work already
+// enqueued may still use a retired buffer; it is freed at the next cuhe_hip_device_sync / shutdown.  Growth is geometric, so the
+// retired buffers of a workspace member add up to less than its final size.
+void ws_retire(void *p);
 template <typename T>
-int ws_grow(T **ptr, size_t *have, size_t count) {           // grow-only (re-allocation synchronises: sizes settle at once)
+int ws_grow(T **ptr, size_t *have, size_t count) {           // grow-only, geometric
     if (*have >= count && *ptr) return CUHE_OK;
-    if (*ptr) { HIPCHK(hipFree(*ptr)); count = std::max(count, 2 * *have); }      // (hipFree waits for the device: geometric growth)
+    if (*ptr) { ws_retire(*ptr); count = std::max(count, 2 * *have); }
     *ptr = nullptr; *have = 0;
     HIPCHK(hipMalloc((void **)ptr, std::max<size_t>(count, 1) * sizeof(T)));
     *have = count;

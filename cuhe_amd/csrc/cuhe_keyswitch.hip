@@ -367,22 +367,21 @@ int cuhe_hip_relin_import(const void *src, size_t bytes) {
     G_.relin_ready = true;
     return CUHE_OK;
 }
-// key-switch inner product of ONE ciphertext over the primes [prime0, prime0 + count) and the windows [j0, j1): dst rows u64[count][L]
-// (accumulate: added to what dst holds), win = the transformed windows u64[k][L].
+// key-switch inner product of ONE ciphertext over the primes [prime0, prime0 + count): dst rows u64[count][L], win = the k transformed windows u64[k][L].
 // primes per workgroup (each window value fetched from cache serves PB key streams): as many as still leave ~6 workgroups per CU -- the
 // kernel streams the keys from HBM and needs that many loads in flight (12 waves per CU reach 4.3 TB/s, 24 reach 6 TB/s: profiles/r02_experiments_log.txt)
-static int launch_mac_single(u64 *dst, const u64 *win, const DevCtx &D, int prime0, int count, int j0, int j1, int accumulate, hipStream_t st) {
+static int launch_mac_single(u64 *dst, const u64 *win, const DevCtx &D, int prime0, int count, int k, hipStream_t st) {
     const Params &q = G_.prm;
     const int L = ct_len();
     const u64 *ekp = D.ek + (size_t)(prime0 - D.ek_first) * q.numEvalKey * L;
     const long target = 6L * 256;
     auto blocks = [&](int pb) { return (long)(L / 512) * ((count + pb - 1) / pb); };
     if (blocks(4) >= target || count <= 1)
-        hipLaunchKernelGGL((k_relin_mac<4, 1>), dim3((unsigned)blocks(4)), dim3(256), 0, st, dst, win, ekp, j1, (long)q.numEvalKey * L, L, count, 0L, 0L, 1, j0, accumulate);
+        hipLaunchKernelGGL((k_relin_mac<4, 1>), dim3((unsigned)blocks(4)), dim3(256), 0, st, dst, win, ekp, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
     else if (blocks(2) >= target || count <= 2)
-        hipLaunchKernelGGL((k_relin_mac<2, 1>), dim3((unsigned)blocks(2)), dim3(256), 0, st, dst, win, ekp, j1, (long)q.numEvalKey * L, L, count, 0L, 0L, 1, j0, accumulate);
+        hipLaunchKernelGGL((k_relin_mac<2, 1>), dim3((unsigned)blocks(2)), dim3(256), 0, st, dst, win, ekp, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
     else
-        hipLaunchKernelGGL((k_relin_mac<1, 1>), dim3((unsigned)blocks(1)), dim3(256), 0, st, dst, win, ekp, j1, (long)q.numEvalKey * L, L, count, 0L, 0L, 1, j0, accumulate);
+        hipLaunchKernelGGL((k_relin_mac<1, 1>), dim3((unsigned)blocks(1)), dim3(256), 0, st, dst, win, ekp, k, (long)q.numEvalKey * L, L, count, 0L, 0L, 1);
     HIPCHK(hipGetLastError());
     return CUHE_OK;
 }
@@ -405,83 +404,31 @@ static int relin_range(uint64_t *dst, const uint32_t *src, int lvl, int prime0, 
     CHK(ct_forward(Wp->relin, Wp->win, k, dev, S(st)));
     if (prime0 < D.ek_first || prime0 + count > D.ek_first + D.ek_count)
         return fail(CUHE_EINVAL, "keys of primes [%d, %d) wanted, device %d holds [%d, %d)", prime0, prime0 + count, dev, D.ek_first, D.ek_first + D.ek_count);
-    return launch_mac_single((u64 *)dst, Wp->relin, D, prime0, count, 0, k, 0, S(st));
+    return launch_mac_single((u64 *)dst, Wp->relin, D, prime0, count, k, S(st));
 }
 int cuhe_hip_relinearization(uint64_t *dst, const uint32_t *src, int lvl, int dev, void *st) {
     return relin_range(dst, src, lvl, 0, G_.prm.numCrtPrimeAt(lvl < 0 ? 0 : lvl), dev, st);
 }
 
 // ---- CuCtxt::relin from the raw domain on -- relinearization ; n2c (cuhe/CuHE.cu:574-580) -- as ONE call: raw coefficients ->
-// reduced CRT rows, with the two kinds of work of the chain BESIDE each other instead of one after the other.  The key stream is
-// HBM-bound (1.7 GB at 6 TB/s: 0.29 of the 0.44 ms of a chain on x^65536+1), the k window transforms before it and the np inverse
-// transforms after it are bound by vector issue and, at 48-69 rows, do not fill the chip (profiles/r04_single_chain_bisect.txt).
-// So: the windows are transformed in groups on a helper stream of the calling thread; the caller's stream adds up the inner product
-// group by group as the transforms arrive (partial sums: k_relin_mac's [j0, j1) / accumulate form), the LAST group in blocks of
-// primes, and the helper stream takes each block of sums back (inverse transform, lift, mod p_i) while the next one is still being
-// summed.  Same arithmetic as the two calls (the sums are exact in Z_P either way): bit-identical, tested.  CUHE_RELIN_OVERLAP=0 /
-// cuhe_hip_set_relin_overlap(0): the two calls one after the other on the caller's stream.
-static int g_relin_overlap = getenv("CUHE_RELIN_OVERLAP") ? atoi(getenv("CUHE_RELIN_OVERLAP")) : 1;
-int cuhe_hip_set_relin_overlap(int on) { g_relin_overlap = on != 0; return CUHE_OK; }
+// reduced CRT rows, the sums kept in the calling thread's scratch (no NTT-domain result buffer on the caller's side, one call instead
+// of two: 0.475 -> 0.451 ms per multiply + relinearise on x^65536+1, 0.258 -> 0.256 on x^32768+1).  Round 5 also built the form with
+// the HBM-bound key stream BESIDE the instruction-bound transforms (window groups on a helper stream, partial inner products as they
+// arrive, the last group in blocks of primes whose sums are taken back while the next block is summed): bit-identical and SLOWER --
+// 0.547 / 0.354 ms -- five inner-product launches instead of one (the blocks of primes re-read the windows), transform calls of 16-23
+// rows, eight cross-stream events per chain; removed again (profiles/EXPERIMENTS.md section 0, profiles/r05_relin_overlap_ab.txt).
 int cuhe_hip_relin_crt(uint32_t *dst, const uint32_t *src, int lvl, int dev, void *st_) {
     CHK(need_init(dev));
     if (!G_.relin_ready) return fail(CUHE_ENOTINIT, "initRelinearization has not been called");
     const Params &q = G_.prm;
     if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
-    const int k = q.numEvalKeyAt(lvl), np = q.numCrtPrimeAt(lvl), L = ct_len(), cl = q.crtLen, W = q.wordsCoeff(lvl);
+    const int np = q.numCrtPrimeAt(lvl);
     hipStream_t st = S(st_);
-    DevCtx &D = G_.dev[dev];
-    if (0 < D.ek_first || np > D.ek_first + D.ek_count)
-        return fail(CUHE_EINVAL, "keys of primes [0, %d) wanted, device %d holds [%d, %d)", np, dev, D.ek_first, D.ek_first + D.ek_count);
     Workspace *W0 = nullptr;
     CHK(workspace(dev, st, &W0));
-    CHK(ws_relin(*W0));
-    CHK(ws_buffer(&W0->rc_acc, (size_t)q.numCrtPrime * L));
-    hipLaunchKernelGGL(k_extract_windows, dim3((cl + kWinCoef - 1) / kWinCoef), dim3(kWinCoef * kWinGroups), (size_t)W * kWinCoef * 4, st, W0->win, src, W, q.logRelin, k, cl, cl,
-                       0L, 0L);
-    HIPCHK(hipGetLastError());
-    constexpr int G = 3, PG = 3;                             // window groups; prime blocks of the last group
-    if (!g_relin_overlap || k < 2 * G || np < 2 * PG) {
-        CHK(ct_forward(W0->relin, W0->win, k, dev, st));
-        CHK(launch_mac_single(W0->rc_acc, W0->relin, D, 0, np, 0, k, 0, st));
-        return ct_inverse(dst, W0->rc_acc, np, 0, 0, true, dev, st);
-    }
-    while (W0->rc_ev.size() < (size_t)(G + PG + 2)) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); W0->rc_ev.push_back(e); }
-    hipEvent_t *evF = W0->rc_ev.data(), *evM = evF + G, evIn = evF[G + PG], evEnd = evF[G + PG + 1];
-    // the helper lane: its own scratch (transform slabs) and stream
-    LaneReset reset;
-    tls_lane = 1;
-    Workspace *W1 = nullptr;
-    CHK(workspace_of_thread(dev, &W1));
-    if (!W1->lane_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&W1->lane_stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&W1->ev_lane, hipEventDisableTiming));
-    }
-    hipStream_t s2 = W1->lane_stream;
-    HIPCHK(hipEventRecord(evIn, st));                        // the window rows are in place (and everything the caller enqueued before)
-    HIPCHK(hipStreamWaitEvent(s2, evIn, 0));
-    int jb[G + 1];
-    for (int g = 0; g <= G; ++g) jb[g] = (int)((long)k * g / G);
-    for (int g = 0; g < G; ++g) {                            // window transforms, group by group, on the helper stream
-        CHK(ct_forward(W0->relin + (size_t)jb[g] * L, W0->win + (size_t)jb[g] * cl, jb[g + 1] - jb[g], dev, s2));
-        HIPCHK(hipEventRecord(evF[g], s2));
-    }
-    tls_lane = 0;
-    for (int g = 0; g < G; ++g) {                            // the key stream on the caller's stream, as the groups arrive
-        HIPCHK(hipStreamWaitEvent(st, evF[g], 0));
-        if (g + 1 < G) { CHK(launch_mac_single(W0->rc_acc, W0->relin, D, 0, np, jb[g], jb[g + 1], g > 0, st)); continue; }
-        for (int b = 0; b < PG; ++b) {
-            const int p0 = (int)((long)np * b / PG), p1 = (int)((long)np * (b + 1) / PG);
-            CHK(launch_mac_single(W0->rc_acc + (size_t)p0 * L, W0->relin, D, p0, p1 - p0, jb[g], jb[g + 1], 1, st));
-            HIPCHK(hipEventRecord(evM[b], st));
-            HIPCHK(hipStreamWaitEvent(s2, evM[b], 0));
-            tls_lane = 1;
-            CHK(ct_inverse(dst + (size_t)p0 * cl, W0->rc_acc + (size_t)p0 * L, p1 - p0, p0, 0, true, dev, s2));
-            tls_lane = 0;
-        }
-    }
-    HIPCHK(hipEventRecord(evEnd, s2));
-    HIPCHK(hipStreamWaitEvent(st, evEnd, 0));
-    return CUHE_OK;
+    CHK(ws_buffer(&W0->rc_acc, (size_t)q.numCrtPrime * ct_len()));
+    CHK(relin_range((uint64_t *)W0->rc_acc, src, lvl, 0, np, dev, st_));
+    return ct_inverse(dst, W0->rc_acc, np, 0, 0, true, dev, st);
 }
 
 // ---- key digits for the inner product on the matrix cores (k_relin_mac_mfma): built on the first batched call that
@@ -529,9 +476,9 @@ static int relin_batch_run(uint32_t *dst, const uint64_t *a, const uint64_t *b, 
     Workspace &Ws = *Wp;
     if (Ws.n_bt < (size_t)batch) {
         size_t x = 0, y = 0;
-        const size_t cap = std::max<size_t>(batch, 2 * Ws.n_bt);      // geometric: every re-allocation waits for the device (hipFree)
-        if (Ws.bt_ntt) { HIPCHK(hipFree(Ws.bt_ntt)); Ws.bt_ntt = nullptr; }
-        if (Ws.bt_crt) { HIPCHK(hipFree(Ws.bt_crt)); Ws.bt_crt = nullptr; }
+        const size_t cap = std::max<size_t>(batch, 2 * Ws.n_bt);      // geometric; the outgrown buffers are retired (ws_retire)
+        if (Ws.bt_ntt) { ws_retire(Ws.bt_ntt); Ws.bt_ntt = nullptr; }
+        if (Ws.bt_crt) { ws_retire(Ws.bt_crt); Ws.bt_crt = nullptr; }
         CHK(ws_grow(&Ws.bt_ntt, &x, cap * q.numCrtPrime * L));
         CHK(ws_grow(&Ws.bt_crt, &y, cap * q.numCrtPrime * cl));
         Ws.n_bt = cap;
@@ -877,8 +824,8 @@ int cuhe_hip_mul_raw_batch(uint32_t *dst, const uint32_t *a, const uint32_t *b, 
     // scratch: CRT rows of both operands (2*rows), their transforms (2*rows)
     if (Ws.n_mr < (size_t)batch) {
         size_t x = 0, y = 0;
-        if (Ws.mr_ntt) { HIPCHK(hipFree(Ws.mr_ntt)); Ws.mr_ntt = nullptr; }
-        if (Ws.mr_crt) { HIPCHK(hipFree(Ws.mr_crt)); Ws.mr_crt = nullptr; }
+        if (Ws.mr_ntt) { ws_retire(Ws.mr_ntt); Ws.mr_ntt = nullptr; }
+        if (Ws.mr_crt) { ws_retire(Ws.mr_crt); Ws.mr_crt = nullptr; }
         CHK(ws_grow(&Ws.mr_ntt, &x, (size_t)2 * batch * q.numCrtPrime * L));
         CHK(ws_grow(&Ws.mr_crt, &y, (size_t)2 * batch * q.numCrtPrime * cl));
         Ws.n_mr = batch;

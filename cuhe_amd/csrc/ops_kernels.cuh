@@ -291,9 +291,7 @@ __device__ __forceinline__ u64 fold192(u64 lo, u64 hi, u32 top) {
 template <int PB, int BB, int MAP = 0>
 __global__ __launch_bounds__(256)
 void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__restrict__ ek,
-                 int k, long ek_prime_stride, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts, int j0 = 0, int accumulate = 0) {
-    // [j0, k): the windows this launch sums over; accumulate: the sums are added to what dst holds (the partial sums of earlier windows) --
-    // how the single-ciphertext chain lets the key stream of the first windows run beside the transforms of the later ones (cuhe_hip_relin_crt)
+                 int k, long ek_prime_stride, int L, int np, long c_ct_stride, long dst_ct_stride, int ncts) {
     const int b0 = blockIdx.z * BB;
     const int ny = (np + PB - 1) / PB;
     int xt, i0;
@@ -322,7 +320,7 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
     for (int b = 0; b < BB; ++b)
 #pragma unroll
         for (int q = 0; q < PB; ++q) { lo0[b][q] = hi0[b][q] = lo1[b][q] = hi1[b][q] = 0; top0[b][q] = top1[b][q] = 0; }
-    for (int j = j0; j < k; ++j) {
+    for (int j = 0; j < k; ++j) {
         u64x2 a[BB];
 #pragma unroll
         for (int b = 0; b < BB; ++b) a[b] = cc[b][(long)j * L2];
@@ -344,9 +342,7 @@ void k_relin_mac(u64 *__restrict__ dst, const u64 *__restrict__ c, const u64 *__
                 u64x2 r;
                 r.x = fold192(lo0[b][q], hi0[b][q], top0[b][q]);
                 r.y = fold192(lo1[b][q], hi1[b][q], top1[b][q]);
-                u64x2 *out = reinterpret_cast<u64x2 *>(dst + (long)(b0 + b) * dst_ct_stride + (long)(i0 + q) * L) + idx2;
-                if (accumulate) { const u64x2 o = *out; r.x = addp(r.x, o.x); r.y = addp(r.y, o.y); }
-                *out = r;
+                reinterpret_cast<u64x2 *>(dst + (long)(b0 + b) * dst_ct_stride + (long)(i0 + q) * L)[idx2] = r;
             }
         }
 }

@@ -100,6 +100,7 @@ std::condition_variable cvDone;
 std::atomic<long> outstanding{0}, totalTasks{0}, maxQueued{0}, nextId{0};
 std::atomic<bool> active{false}, stopping{false};
 int workersPerDev = 3, stealing = 1, policy = 1, trace = 0;
+int batchWorkers = 0;                      // how many of a device's workers take staged groups (0 = all).  CUHE_SCHED_BATCH_WORKERS; see start()
 long quietNs = 100000;                     // policies 1, 2: a group the CLIENT is adding ready gates to right now is taken only after it has been quiet for this long (CUHE_SCHED_QUIET_US)
 BatchRunner batchRunner = nullptr; int maxBatch = 1;
 thread_local bool tlsWorker = false;
@@ -244,7 +245,7 @@ void makeReady(Task *t, Task **next) {
 		if (!tlsWorker) { G.lastArrival = clk::now(); G.fromClient = true; }
 		auto gp = D.groupPending.find(k);
 		if (gp != D.groupPending.end() && --gp->second <= 0) D.groupPending.erase(gp);
-		D.cv.notify_one();
+		if (batchWorkers > 0) D.cv.notify_all(); else D.cv.notify_one();      // (the one woken must be a worker that takes groups)
 		return;
 	}
 	if (next && !*next && t->dev == tlsDev) { *next = t; return; }      // follow the chain on this stream: no event wait, warm scratch
@@ -295,7 +296,7 @@ void workerMain(DevState *Dp, int me) {
 			for (;;) {
 				if (Task *t = takeTask(D, me)) { batch.push_back(t); break; }
 				long retryNs = 0;
-				if (takeBatch(D, batch, &retryNs)) break;
+				if ((batchWorkers <= 0 || me < batchWorkers) && takeBatch(D, batch, &retryNs)) break;
 				if (stopping.load()) return;
 				if (retryNs > 0) D.cv.wait_for(lk, std::chrono::nanoseconds(retryNs)); else D.cv.wait(lk);
 			}
@@ -363,7 +364,7 @@ void workerMain(DevState *Dp, int me) {
 		for (CuPolynomial *p : dead) delete p;
 		lk.lock();
 		if (asBatch) --D.busyBatch; else --D.busyRegular;                // (only now: what this task made ready has been staged)
-		if (D.stagedCount && D.busyRegular == 0) D.cv.notify_all();     // groups that waited for the work in flight to drain
+		if (D.stagedCount && (D.busyRegular == 0 || batchWorkers > 0)) D.cv.notify_all();     // groups that waited for the work in flight to drain
 	}
 }
 
@@ -417,6 +418,7 @@ void start(int n) {
 	if (getenv("CUHE_SCHED_LOCAL")) stealing = atoi(getenv("CUHE_SCHED_LOCAL"));
 	if (getenv("CUHE_SCHED_POLICY")) policy = atoi(getenv("CUHE_SCHED_POLICY"));
 	if (getenv("CUHE_SCHED_QUIET_US")) quietNs = 1000L * atol(getenv("CUHE_SCHED_QUIET_US"));
+	if (getenv("CUHE_SCHED_BATCH_WORKERS")) batchWorkers = atoi(getenv("CUHE_SCHED_BATCH_WORKERS"));
 	trace = getenv("CUHE_SCHED_TRACE") ? atoi(getenv("CUHE_SCHED_TRACE")) : 0;
 	const int nd = std::max(1, std::min(cuhe_hip_num_gpus(), kMaxDevices));
 	for (int d = 0; d < nd; ++d) ensureWorkers(d);

@@ -296,12 +296,9 @@ int cuhe_hip_relin_range(uint64_t *dst, const uint32_t *raw, int lvl, int prime0
 int cuhe_hip_crt_range(uint32_t *dst, const uint32_t *src, int logq, int prime0, int count, int dev, void *stream);
 
 /* CuCtxt::relin from the raw domain on -- relinearization ; n2c (cuhe/CuHE.cu:574-580) -- as ONE call: raw coefficients u32[rawLen][W] of
- * level lvl -> reduced CRT rows u32[np][crtLen].  The HBM-bound key stream runs beside the instruction-bound window / inverse transforms
- * (window groups on a helper stream of the calling thread, partial inner products as they arrive, the last group in blocks of primes whose
- * sums are taken back while the next block is summed).  Bit-identical to cuhe_hip_relinearization followed by cuhe_hip_ct_intt(is_prod = 1).
- * cuhe_hip_set_relin_overlap(0) / CUHE_RELIN_OVERLAP=0: the same steps one after the other on the caller's stream. */
+ * level lvl -> reduced CRT rows u32[np][crtLen]; the sums live in the calling thread's scratch.  Bit-identical to
+ * cuhe_hip_relinearization followed by cuhe_hip_ct_intt(is_prod = 1). */
 int cuhe_hip_relin_crt(uint32_t *dst_crt, const uint32_t *src_raw, int lvl, int dev, void *stream);
-int cuhe_hip_set_relin_overlap(int on);
 
 /* ---- multi-GPU: cAnd + relin of ONE ciphertext with the level's CRT primes sharded over GPUs (new; the reference's
  * multi-GPU mode is whole ciphertexts per GPU, cuhe/CuHE.cu:217-256, which the dev argument of every call above already

@@ -287,12 +287,8 @@ def test_dense_keys_at_config4_shape_vs_oracle(gu, ring):
         g.init_relin(ek_raw)
         for t in range(B):                                       # the single chain
             assert np.array_equal(g.mul_relin_crt(a[t], b[t], 0), want[t]), (ring, "single", t)
-        # the single chain with relinearization ; n2c as ONE call (cuhe_hip_relin_crt: key stream beside the transforms), overlap on and off
-        for overlap in (1, 0):
-            ck(lib.cuhe_hip_set_relin_overlap(overlap))
-            for t in range(B):
-                assert np.array_equal(g.mul_relin_crt(a[t], b[t], 0, fused=True), want[t]), (ring, "single, fused, overlap %d" % overlap, t)
-        ck(lib.cuhe_hip_set_relin_overlap(1))
+        for t in range(B):                                       # relinearization ; n2c as the ONE call CuCtxt::relin makes (cuhe_hip_relin_crt)
+            assert np.array_equal(g.mul_relin_crt(a[t], b[t], 0, fused=True), want[t]), (ring, "single, one call", t)
         order = [0, 1, 2, 1, 0]                                  # 5 ciphertexts: the matrix-core inner product (default from 5 on)
         na, nb = gu.empty_u64(len(order) * npr, ctlen), gu.empty_u64(len(order) * npr, ctlen)
         for s, t in enumerate(order):
@@ -311,7 +307,6 @@ def test_dense_keys_at_config4_shape_vs_oracle(gu, ring):
             assert np.array_equal(got[t], want[t]), (ring, "batch of 3 (VALU)", t)
     finally:
         lib.cuhe_hip_set_relin_mfma(5)
-        lib.cuhe_hip_set_relin_overlap(1)
         g.close()
 
 

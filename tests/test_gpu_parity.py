@@ -340,21 +340,15 @@ def test_relin_vs_oracle(gu):
             a, b = _rand_crt(o, np_, 31), _rand_crt(o, np_, 32)
             want = o.mul_relin_crt(a, b, lvl, ek)
             assert np.array_equal(g.mul_relin_crt(a, b, lvl), want)
-            # relinearization ; n2c as one call (round 5: the key stream beside the transforms), with the overlap and without
-            for overlap in (1, 0):
-                gu.ck(gu.lib.cuhe_hip_set_relin_overlap(overlap))
-                assert np.array_equal(g.mul_relin_crt(a, b, lvl, fused=True), want), (lvl, overlap)
-            gu.ck(gu.lib.cuhe_hip_set_relin_overlap(1))
+            assert np.array_equal(g.mul_relin_crt(a, b, lvl, fused=True), want), lvl          # relinearization ; n2c as one call (round 5)
     finally:
-        gu.lib.cuhe_hip_set_relin_overlap(1)
         g.close(); o.close()
 
 
 @pytest.mark.parametrize("name", ["toy1155", "pow2_16384", "pow2_32768"])
 def test_fused_relin_chain_equals_the_two_calls(gu, name):
-    """cuhe_hip_relin_crt (raw -> reduced CRT rows: window groups on a helper stream, partial inner products, the last group in blocks of
-    primes) against cuhe_hip_relinearization ; cuhe_hip_ct_intt on cyclic and negacyclic rings, every level that has at least six keys and
-    primes (below that the call runs its steps one after the other), repeated (buffer and event reuse), on a caller's own stream too."""
+    """cuhe_hip_relin_crt (raw -> reduced CRT rows in one call, what CuCtxt::relin uses since round 5) against cuhe_hip_relinearization ;
+    cuhe_hip_ct_intt on cyclic and negacyclic rings, every level, repeated (scratch reuse), on a caller's own stream too."""
     import ctypes as C
     import oracle_lib as O
     lib, ck = gu.lib, gu.ck
@@ -374,17 +368,15 @@ def test_fused_relin_chain_equals_the_two_calls(gu, name):
             ck(lib.cuhe_hip_relinearization(acc.data_ptr(), d_raw.data_ptr(), lvl, 0, None))
             ck(lib.cuhe_hip_ct_intt(want.data_ptr(), acc.data_ptr(), g.logq(lvl), 1, 0, None))
             w = gu.host_u32(want)
-            for overlap in (1, 0, 1):
-                ck(lib.cuhe_hip_set_relin_overlap(overlap))
+            for rep in range(2):
                 for stream in (None, st):
                     got = gu.empty_u32(npr, q.crtLen); got.zero_()
                     ck(lib.cuhe_hip_relin_crt(got.data_ptr(), d_raw.data_ptr(), lvl, 0, stream))
                     ck(lib.cuhe_hip_stream_sync(0, stream))
-                    assert np.array_equal(gu.host_u32(got)[:, :q.modLen], w[:, :q.modLen]), (name, lvl, overlap, stream is not None)
+                    assert np.array_equal(gu.host_u32(got)[:, :q.modLen], w[:, :q.modLen]), (name, lvl, rep, stream is not None)
         assert lib.cuhe_hip_relin_crt(want.data_ptr(), d_raw.data_ptr(), q.depth, 0, None) != 0
         ck(lib.cuhe_hip_stream_destroy(0, st))
     finally:
-        lib.cuhe_hip_set_relin_overlap(1)
         g.close()
 
 
