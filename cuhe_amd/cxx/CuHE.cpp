@@ -134,6 +134,8 @@ struct SchedAccess {
 typedef std::vector<sched::Node *> Nodes;
 #define GATE_SYNC(dev, st) do { if (!streamOrdered()) CSC(cuhe_hip_stream_sync(dev, st)); } while (0)
 
+// (A/B: CUHE_KEEP_CRT=0 frees the CRT rows at c2n as rounds 1-4 did)
+static bool keepCrtRows() { static const bool on = !(getenv("CUHE_KEEP_CRT") && atoi(getenv("CUHE_KEEP_CRT")) == 0); return on; }
 static void *devAlloc(int dev, size_t bytes, cudaStream_t st = 0) {
 	void *p = sched::inWorker() ? sched::taskAlloc(dev, bytes) : streamOrdered() ? cuhe_hip_malloc_stream(dev, bytes, st) : cuhe_hip_malloc(dev, bytes);
 	if (!p) CSC(CUHE_EHIP);
@@ -296,7 +298,7 @@ void initCuHE(ZZ *coeffMod_, ZZX modulus) {
 // ------------------------------------------------------------------ CuPolynomial
 static void misuse(const char *msg) { cout << msg << endl; terminate(); }
 
-CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), prodTerms_(0), rRep_(NULL), cRep_(NULL), nRep_(NULL), stream_(0), node_(NULL), exposed_(false) { clear(zRep_); }
+CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), prodTerms_(0), rRep_(NULL), cRep_(NULL), nRep_(NULL), cKeep_(NULL), stream_(0), node_(NULL), exposed_(false) { clear(zRep_); }
 CuPolynomial::~CuPolynomial() { reset(); }
 // ---- attached / detached (scheduled mode)
 bool CuPolynomial::scheduled() {
@@ -309,8 +311,8 @@ bool CuPolynomial::scheduled() {
 void CuPolynomial::moveStateFrom(CuPolynomial &o) {
 	logq_ = o.logq_; domain_ = o.domain_; device_ = o.device_; isProd_ = o.isProd_; prodTerms_ = o.prodTerms_;
 	{ using std::swap; clear(zRep_); swap(zRep_, o.zRep_); }
-	rRep_ = o.rRep_; cRep_ = o.cRep_; nRep_ = o.nRep_; stream_ = o.stream_;
-	o.rRep_ = NULL; o.cRep_ = NULL; o.nRep_ = NULL;
+	rRep_ = o.rRep_; cRep_ = o.cRep_; nRep_ = o.nRep_; cKeep_ = o.cKeep_; stream_ = o.stream_;
+	o.rRep_ = NULL; o.cRep_ = NULL; o.nRep_ = NULL; o.cKeep_ = NULL;
 }
 void CuCtxt::moveStateFrom(CuPolynomial &o) { CuPolynomial::moveStateFrom(o); level_ = static_cast<CuCtxt &>(o).level_; }
 sched::Node *CuPolynomial::schedAttach() {
@@ -345,6 +347,7 @@ void CuPolynomial::schedRelease() {
 void CuPolynomial::reset() {
 	if (node_ && !sched::inWorker()) { if (sched::on()) schedRelease(); else schedDetach(); }
 	clear(zRep_);
+	dropKeep();
 	if (rRep_ != NULL) rRepFree();
 	if (cRep_ != NULL) cRepFree();
 	if (nRep_ != NULL) nRepFree();
@@ -359,7 +362,7 @@ void CuPolynomial::isProd(bool val) { DETACHED(); isProd_ = val; prodTerms_ = va
 void CuPolynomial::zRep(ZZX val) { DETACHED(); zRep_ = std::move(val); }
 void CuPolynomial::rRep(uint32 *val) { DETACHED(); rRep_ = val; }
 void CuPolynomial::cRep(uint32 *val) { DETACHED(); cRep_ = val; }
-void CuPolynomial::nRep(uint64 *val) { DETACHED(); nRep_ = val; }
+void CuPolynomial::nRep(uint64 *val) { DETACHED(); dropKeep(); nRep_ = val; }
 int CuPolynomial::logq() { return logq_; }
 int CuPolynomial::domain() { return domain_; }
 int CuPolynomial::device() { return device_; }
@@ -371,7 +374,8 @@ void CuPolynomial::swapZRep(ZZX &other) { DETACHED(); using std::swap; swap(zRep
 #define EXPOSED() do { if (!sched::inWorker()) { if (node_) schedDetach(); if (sched::on()) exposed_ = true; } } while (0)
 uint32 *CuPolynomial::rRep() { EXPOSED(); return rRep_; }
 uint32 *CuPolynomial::cRep() { EXPOSED(); return cRep_; }
-uint64 *CuPolynomial::nRep() { EXPOSED(); return nRep_; }
+uint64 *CuPolynomial::nRep() { EXPOSED(); dropKeep(); return nRep_; }        // (the caller may write through it)
+const uint64 *CuPolynomial::nRepRead() { EXPOSED(); return nRep_; }
 // (inside a recorded gate the operands that are only read may be shared with gates running on other workers: their
 // buffers are ordered by the tasks' events, not by this field; written operands get the task's stream from the task)
 void CuPolynomial::stream(cudaStream_t st) { if (sched::inWorker()) return; DETACHED(); stream_ = st; }
@@ -412,6 +416,7 @@ static void devFree(int dev, void *p, cudaStream_t st) {
 	else sched::forgetBlock(p);
 	CSC(streamOrdered() ? cuhe_hip_free_stream(dev, p, st) : cuhe_hip_free(dev, p));
 }
+void CuPolynomial::dropKeep() { if (cKeep_) { devFree(device_, cKeep_, stream_); cKeep_ = NULL; } }
 void CuPolynomial::rRepFree() { devFree(device_, rRep_, stream_); rRep_ = NULL; }
 void CuPolynomial::cRepFree() { devFree(device_, cRep_, stream_); cRep_ = NULL; }
 void CuPolynomial::nRepFree() { devFree(device_, nRep_, stream_); nRep_ = NULL; }
@@ -504,11 +509,21 @@ void CuPolynomial::c2n(cudaStream_t st) {
 	// when the modulus is x^n + 1 (include/cuhe_hip.h, cuhe_hip_ct_*); every NTT-domain gate below works on either
 	CSC(cuhe_hip_ct_ntt(U64P(nRep_), cRep_, logq_, device_, st));
 	GATE_SYNC(device_, st);
-	cRepFree();
+	dropKeep();
+	if (keepCrtRows()) { cKeep_ = cRep_; cRep_ = NULL; } else cRepFree();       // the rows it came from: the way back is free while nobody writes the NTT rows
 	domain_ = 3;
 }
 void CuPolynomial::n2c(cudaStream_t st) {
 	if (domain_ != 3) { printf("Error: Not in domain NTT!\n"); terminate(); }
+	if (cKeep_ && !isProd_) {                                   // unmodified since c2n: the CRT rows are still there
+		stream_ = st;
+		cRep_ = cKeep_; cKeep_ = NULL;
+		prodTerms_ = 0;
+		nRepFree();
+		domain_ = 2;
+		return;
+	}
+	dropKeep();
 	cRepAlloc(st);
 	CSC(cuhe_hip_ct_intt(cRep_, U64P(nRep_), logq_, isProd_ ? 1 : 0, device_, st));    // inttMod for products, intt otherwise
 	GATE_SYNC(device_, st);
@@ -595,6 +610,7 @@ void CuCtxt::setLevel(int lvl, int domain, int device, cudaStream_t st) {
 		sched::submit(device_, Nodes(), Nodes(1, n), [n, lvl, domain, device](void *s) { SchedAccess::ct(n).setLevel(lvl, domain, device, s); });
 		return;
 	}
+	dropKeep();
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
@@ -607,6 +623,7 @@ void CuCtxt::setLevelForOutput(int lvl, int domain, int device, cudaStream_t st)
 		sched::submit(device_, Nodes(), Nodes(1, n), [n, lvl, domain, device](void *s) { SchedAccess::ct(n).setLevelForOutput(lvl, domain, device, s); });
 		return;
 	}
+	dropKeep();
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_);
 	else if (domain_ == 1) rRepAlloc(st);
@@ -615,6 +632,7 @@ void CuCtxt::setLevelForOutput(int lvl, int domain, int device, cudaStream_t st)
 }
 void CuCtxt::setLevel(int lvl, int device, ZZX val) {
 	if (scheduled()) schedRelease();
+	dropKeep();
 	level_ = lvl; logq_ = param._logCoeff(lvl); domain_ = 0; device_ = device; zRep_ = std::move(val);
 }
 int CuCtxt::level() { return level_; }
@@ -671,10 +689,11 @@ void CuPtxt::setLogq(int logq, int domain, int device, cudaStream_t st) {
 		sched::submit(device_, Nodes(), Nodes(1, n), [n, logq, domain, device](void *s) { SchedAccess::pt(n).setLogq(logq, domain, device, s); });
 		return;
 	}
+	dropKeep();
 	logq_ = logq; domain_ = domain; device_ = device;
 	if (domain_ == 0) clear(zRep_); else createRep(*this, domain_, st);
 }
-void CuPtxt::setLogq(int logq, int device, ZZX val) { if (scheduled()) schedRelease(); logq_ = logq; domain_ = 0; device_ = device; zRep_ = std::move(val); }
+void CuPtxt::setLogq(int logq, int device, ZZX val) { if (scheduled()) schedRelease(); dropKeep(); logq_ = logq; domain_ = 0; device_ = device; zRep_ = std::move(val); }
 size_t CuPtxt::cRepSize() { return (size_t)param.crtLen * sizeof(uint32); }
 size_t CuPtxt::nRepSize() { return (size_t)cuhe_hip_ct_len() * sizeof(uint64); }
 
@@ -703,7 +722,7 @@ void copy(CuCtxt &dst, CuCtxt &src, cudaStream_t st) {
 	if (dst.domain() == 0) dst.zRep(src.zRep());
 	else if (dst.domain() == 1) CSC(cuhe_hip_memcpy_d2d(dev, dst.rRep(), src.rRep(), dst.rRepSize(), st));
 	else if (dst.domain() == 2) CSC(cuhe_hip_memcpy_d2d(dev, dst.cRep(), src.cRep(), dst.cRepSize(), st));
-	else if (dst.domain() == 3) CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(), src.nRep(), dst.nRepSize(), st));
+	else if (dst.domain() == 3) CSC(cuhe_hip_memcpy_d2d(dev, dst.nRep(), src.nRepRead(), dst.nRepSize(), st));
 	if (dev >= 0) GATE_SYNC(dev, st);
 }
 static void prepareOut(CuCtxt &out, CuCtxt &like, int domain, cudaStream_t st) {
@@ -726,7 +745,7 @@ void cAnd(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	}
 	prepareOut(out, in0, 3, st);
 	in0.stream(st); in1.stream(st); out.stream(st);
-	CSC(cuhe_hip_ct_mul(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
+	{ const uint64 *x = in0.nRepRead(), *y = in1.nRepRead(); CSC(cuhe_hip_ct_mul(U64P(out.nRep()), U64P(x), U64P(y), out.logq(), out.device(), st)); }
 	out.isProd(true); out.prodTerms(1);
 	GATE_SYNC(out.device(), st);
 }
@@ -742,7 +761,7 @@ void cAnd(CuCtxt &out, CuCtxt &inc, CuPtxt &inp, cudaStream_t st) {
 	}
 	prepareOut(out, inc, 3, st);
 	inc.stream(st); inp.stream(st); out.stream(st);
-	CSC(cuhe_hip_ct_mul_nx1(U64P(out.nRep()), U64P(inc.nRep()), U64P(inp.nRep()), out.logq(), out.device(), st));
+	{ const uint64 *x = inc.nRepRead(), *y = inp.nRepRead(); CSC(cuhe_hip_ct_mul_nx1(U64P(out.nRep()), U64P(x), U64P(y), out.logq(), out.device(), st)); }
 	out.isProd(true); out.prodTerms(1);
 	GATE_SYNC(out.device(), st);
 }
@@ -787,7 +806,7 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 		} else {
 			const bool prod = in0.isProd() || in1.isProd();
 			if (&out != &in0) { prepareOut(out, in0, 3, st); }
-			CSC(cuhe_hip_ct_add(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
+			{ const uint64 *x = in0.nRepRead(), *y = in1.nRepRead(); CSC(cuhe_hip_ct_add(U64P(out.nRep()), U64P(x), U64P(y), out.logq(), out.device(), st)); }
 			out.isProd(prod); out.prodTerms(prod ? (terms > 0 ? terms : 1) : 0);
 		}
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
@@ -814,7 +833,7 @@ void cXor(CuCtxt &out, CuCtxt &in0, CuPtxt &in1, cudaStream_t st) {
 		crtAddNX1(out.cRep(), in0.cRep(), in1.cRep(), out.logq(), out.device(), st);
 	} else if (in0.domain() == 3 && in1.domain() == 3) {
 		if (&out != &in0) prepareOut(out, in0, 3, st);
-		CSC(cuhe_hip_ct_add_nx1(U64P(out.nRep()), U64P(in0.nRep()), U64P(in1.nRep()), out.logq(), out.device(), st));
+		{ const uint64 *x = in0.nRepRead(), *y = in1.nRepRead(); CSC(cuhe_hip_ct_add_nx1(U64P(out.nRep()), U64P(x), U64P(y), out.logq(), out.device(), st)); }
 		out.isProd(prodSum); out.prodTerms(termSum);
 	} else misuse("Error: Addition of non-CRT-nor-NTT domain!");
 	GATE_SYNC(out.device(), st);
@@ -886,7 +905,7 @@ void cAndRelinSharded(CuCtxt &out, CuCtxt &in0, CuCtxt &in1, cudaStream_t st) {
 	in0.stream(st); in1.stream(st);
 	out.reset();
 	out.setLevelForOutput(in0.level(), 2, in0.device(), st);
-	CSC(cuhe_hip_mul_relin_sharded_inproc(out.cRep(), U64P(in0.nRep()), U64P(in1.nRep()), in0.level(), in0.device(), st));
+	CSC(cuhe_hip_mul_relin_sharded_inproc(out.cRep(), U64P(in0.nRepRead()), U64P(in1.nRepRead()), in0.level(), in0.device(), st));
 	out.isProd(false);
 	GATE_SYNC(out.device(), st);
 }
@@ -966,6 +985,7 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 			if (c[i] != a[i]) { c[i]->reset(); c[i]->stream_ = st; c[i]->setLevelForOutput(a[i]->level_, dom, dev, st); }
 			if (kind == kBatchAnd) { c[i]->isProd_ = true; c[i]->prodTerms_ = 1; }
 			else if (dom == 3) { c[i]->isProd_ = prod; c[i]->prodTerms_ = prod ? (terms > 0 ? terms : 1) : 0; }
+			if (dom == 3) c[i]->dropKeep();                          // (written in place when it is its own first operand)
 			ptr[i] = dom == 3 ? (void *)c[i]->nRep_ : (void *)c[i]->cRep_;
 			pa[i] = dom == 3 ? (void *)a[i]->nRep_ : (void *)a[i]->cRep_;
 			pb[i] = dom == 3 ? (void *)b[i]->nRep_ : (void *)b[i]->cRep_;
@@ -975,7 +995,19 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		return;
 	}
 	const int dev = c[0]->device_, lvl = c[0]->level_, np = param._numCrtPrime(lvl);
-	const bool fromNtt = c[0]->domain_ == 3, prod = c[0]->isProd_;
+	bool fromNtt = c[0]->domain_ == 3;
+	const bool prod = c[0]->isProd_;
+	if (fromNtt && !prod && kind != kBatchX2N) {
+		// NTT-domain members that were only READ since their c2n still have the CRT rows they came from (CuPolynomial::cKeep_): when
+		// every member has, the way back is free -- no gather, no inverse transform (the a, b, c, d of a PRINCE S-box at modSwitch)
+		bool all = true;
+		for (int i = 0; i < n; ++i) all = all && c[i]->cKeep_ != NULL;
+		if (all) {
+			for (int i = 0; i < n; ++i) { c[i]->cRep_ = c[i]->cKeep_; c[i]->cKeep_ = NULL; c[i]->nRepFree(); c[i]->domain_ = 2; c[i]->prodTerms_ = 0; }
+			if (kind == kBatchX2C) return;
+			fromNtt = false;
+		} else for (int i = 0; i < n; ++i) c[i]->dropKeep();
+	}
 	int cls = 2; while (cls < n) cls *= 2;                       // few scratch sizes (the block cache is keyed by size): level-0 rows, 2 / 4 / .. / 64 ciphertexts
 	const size_t cRows = (size_t)np * param.crtLen, nRows = (size_t)np * cuhe_hip_ct_len();
 	const size_t cBytes = cRows * sizeof(uint32), nBytes = nRows * sizeof(uint64);
@@ -988,7 +1020,11 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		CSC(cuhe_hip_ntt_rows(U64P(nout), cin, n * np, dev, st));
 		for (int i = 0; i < n; ++i) { c[i]->nRepAlloc(st); ptr[i] = c[i]->nRep_; }
 		CSC(cuhe_hip_scatter_blocks(ptr, nout, n, nBytes, dev, st));
-		for (int i = 0; i < n; ++i) { c[i]->cRepFree(); c[i]->domain_ = 3; }
+		for (int i = 0; i < n; ++i) {
+			c[i]->dropKeep();
+			if (keepCrtRows()) { c[i]->cKeep_ = c[i]->cRep_; c[i]->cRep_ = NULL; } else c[i]->cRepFree();      // (as c2n does)
+			c[i]->domain_ = 3;
+		}
 		return;
 	}
 	static const bool listForms = !(getenv("CUHE_SCHED_LISTS") && atoi(getenv("CUHE_SCHED_LISTS")) == 0);     // (A/B: 0 = gather / array call / scatter everywhere)

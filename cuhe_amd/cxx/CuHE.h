@@ -53,6 +53,7 @@ public:
 	uint32 *rRep();
 	uint32 *cRep();
 	uint64 *nRep();
+	const uint64 *nRepRead();        // (addition) the NTT-domain rows for READING: unlike nRep() it leaves the kept CRT rows (below) alone
 	void stream(cudaStream_t st);    // (addition) the stream whose work last touched the device representation;
 	cudaStream_t stream();           //            buffers are released in that stream's order in asynchronous mode
 	// any domain -> the named domain
@@ -106,6 +107,11 @@ protected:
 	uint32 *rRep_;
 	uint32 *cRep_;
 	uint64 *nRep_;
+	// (addition) the CRT rows this polynomial was transformed FROM (c2n), kept while its NTT-domain rows stay unmodified: going back
+	// (n2c of a non-product: x2c, modSwitch, relin of an operand that was only read) then costs nothing.  Not part of the state a client
+	// sees: cRep() is NULL in the NTT domain as in the reference; dropped by everything that writes or hands out the NTT-domain rows.
+	uint32 *cKeep_;
+	void dropKeep();
 	cudaStream_t stream_;
 	sched::Node *node_;
 	bool exposed_;                   // a raw device pointer was handed out in scheduled mode

@@ -100,7 +100,9 @@ std::condition_variable cvDone;
 std::atomic<long> outstanding{0}, totalTasks{0}, maxQueued{0}, nextId{0};
 std::atomic<bool> active{false}, stopping{false};
 int workersPerDev = 3, stealing = 1, policy = 1, trace = 0;
-int batchWorkers = 0;                      // how many of a device's workers take staged groups (0 = all).  CUHE_SCHED_BATCH_WORKERS; see start()
+int batchWorkers = 1;                      // how many of a device's workers take staged groups (0 = all; CUHE_SCHED_BATCH_WORKERS).  ONE: the batches of a device
+                                           // follow each other on one stream with one set of batch scratch, the other workers run the regular tasks --
+                                           // PRINCE gate by gate 0.074-0.085 s against 0.090-0.110 s with every worker taking groups (profiles/r05_sched_prince.txt)
 long quietNs = 100000;                     // policies 1, 2: a group the CLIENT is adding ready gates to right now is taken only after it has been quiet for this long (CUHE_SCHED_QUIET_US)
 BatchRunner batchRunner = nullptr; int maxBatch = 1;
 thread_local bool tlsWorker = false;

@@ -88,6 +88,32 @@ int main() {
 		ca.x2z();
 		CHECK(ca.zRep() == a, "ZZX -> RAW -> CRT -> NTT -> CRT -> RAW -> ZZX round trip");
 	}
+	// ---- the CRT rows a polynomial was transformed from are kept while its NTT rows are only read (round 5): the way back must give
+	//      the same rows, and every write to the NTT rows must end the shortcut
+	{
+		ZZX a = randomPoly(n, q[0]), b = randomPoly(n, q[0]);
+		CuCtxt ca, cb;
+		ca.setLevel(0, 0, a); cb.setLevel(0, 0, b);
+		ca.x2n(); cb.x2n();
+		CuCtxt prod; cAnd(prod, ca, cb);                       // ca, cb only read
+		ca.x2c(); CHECK(ca.cRep() != NULL && ca.domain() == 2, "x2n ; (read) ; x2c comes back to the CRT domain");
+		ca.x2z(); CHECK(ca.zRep() == a, "x2n ; (read) ; x2c returns the rows it started from");
+		cb.x2c(); cb.x2n();                                    // back and forth again
+		cXor(cb, cb, cb);                                      // written in place in the NTT domain: 2 b
+		cb.x2z(); CHECK(cb.zRep() == reduceCoeffs(b + b, q[0], n), "a sum written into NTT rows is not shadowed by the rows kept from before");
+		CuCtxt cc; cc.setLevel(0, 0, a); cc.x2n();
+		CHECK(cc.cRep() == NULL, "cRep() is NULL in the NTT domain, as in the reference");
+		uint64 *raw = cc.nRep();                               // a raw pointer was handed out: the library must assume it is written through
+		CHECK(raw != NULL, "nRep() in the NTT domain");
+		cAnd(cc, cc, cc);                                      // in place: a * a
+		cc.x2z(); CHECK(cc.zRep() == hostMul(a, a, phi, q[0], n), "a product formed in place is what x2z returns");
+		CuCtxt cd; cd.setLevel(0, 0, a); cd.x2n();
+		CuCtxt ce; cAnd(ce, cd, cd);                           // cd only read
+		cd.modSwitch();                                        // from the NTT domain, through the kept rows
+		CuCtxt cf; cf.setLevel(0, 0, a); cf.x2c(); cf.modSwitch();
+		cd.x2z(); cf.x2z();
+		CHECK(cd.zRep() == cf.zRep() && cd.level() == 1, "modSwitch from the NTT domain equals modSwitch from the CRT domain");
+	}
 	// ---- cNot (simple_DHS.cu:98) : adds modMsg-1 to the constant term
 	{
 		ZZX a = randomPoly(n, q[0]);
