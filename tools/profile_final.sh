@@ -4,9 +4,9 @@
 # HBM counters of the batched multiply + relinearise call.  Text summaries land in gpurun_out/final/;
 # tools/make_traffic_json.py turns the PMC passes into profiles/traffic_rNN.json (bytes and VALU lane-instructions per
 # transform, tagged with the hash of the kernel sources bench.py checks).  Every step runs under its own timeout.
-# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r04]
+# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r05]
 export TMPDIR=/tmp
-tag=${2:-r04}
+tag=${2:-r05}
 out=$PWD/gpurun_out/final; mkdir -p $out
 if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q --durations=8 --timeout 400 2>&1 | tail -40 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
 timeout 600 python bench.py 2>/dev/null | tail -1 > $out/bench_n1.json
@@ -19,10 +19,10 @@ PY
 R=$PWD
 cd /tmp
 rm -rf /tmp/pf_*
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-prince > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-prince --no-limiter > /dev/null 2>&1
 python $R/tools/rocpd_summary.py /tmp/pf_stats/s_results.db > $out/kernel_trace_stats.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pf_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-mulrelin --no-cpu --no-prince > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pf_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-mulrelin --no-cpu --no-prince --no-limiter > /dev/null 2>&1
   python $R/tools/rocpd_summary.py /tmp/pf_$c/p_results.db 2>&1 | grep -E "^==|^kernel|ntt_pass|ntt_onewg" > $out/pmc_$c.txt
 done
 # the batched multiply + relinearise call alone (config 4, 32 ciphertexts per call): per-kernel time, then the HBM
