@@ -137,6 +137,58 @@ class SmiSampler:
         return {"samples": len(samples), "sclk_mhz": stat([c for c, _ in samples]), "socket_power_w": stat([w for _, w in samples])}
 
 
+def measure_traffic_live(L, B, chunk):
+    """HBM-side traffic and VALU lane-instructions of the headline kernel(s), measured IN THIS RUN: three child runs of this script
+    (--pmc-child: 3 launches of the same batch) under `rocprofv3 --kernel-trace --pmc <one counter>` -- separate passes, no other
+    trace domain, as MI355X_MICROARCH.md prescribes -- read back from the rocpd databases.  Units and corrections as in
+    tools/make_traffic_json.py: FETCH_SIZE / WRITE_SIZE are KB per dispatch, FETCH_SIZE counts wide streaming reads at half their
+    bytes on gfx950 (x 2), SQ_INSTS_VALU is wave-instructions summed per shader engine (32 samples per dispatch, x 64 lanes).
+    Returns None when rocprofv3 is not there or a pass fails (the committed record is used then)."""
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="cuhe_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                   "--batch", str(B), "--len", str(L), "--chunk", str(chunk), "--no-cpu", "--no-mulrelin", "--no-prince", "--no-limiter", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            rows = db.execute("select s.display_name, count(*), avg(e.value) from rocpd_pmc_event e join rocpd_info_pmc i on e.pmc_id = i.id"
+                              " join rocpd_kernel_dispatch d on d.event_id = e.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id"
+                              " where i.name = ? group by s.display_name", (counter,)).fetchall()
+            for name, n, avg in rows:
+                for key in ("ntt_onewg_stream<15, 0, 0>", "ntt_pass1w<16, 0>", "ntt_pass2w<16, 0>"):
+                    if key in name:
+                        per.setdefault(key, {})[counter] = (int(n), float(avg))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    ow, p1, p2 = "ntt_onewg_stream<15, 0, 0>", "ntt_pass1w<16, 0>", "ntt_pass2w<16, 0>"
+    full = lambda k: k in per and len(per[k]) == 3
+    if full(ow):
+        c = per[ow]
+        return {"one_launch": True, "kernel": ow, "dispatches_sampled": c["FETCH_SIZE"][0], "transforms_per_launch": B,
+                "bytes_per_launch": int(1024.0 * (2 * c["FETCH_SIZE"][1] + c["WRITE_SIZE"][1])),
+                "fetch_bytes_per_launch_x2": int(2048.0 * c["FETCH_SIZE"][1]), "write_bytes_per_launch": int(1024.0 * c["WRITE_SIZE"][1]),
+                "valu_lane_instructions_per_transform": int(c["SQ_INSTS_VALU"][1] * 32 * 64 / B)}
+    if full(p1) and full(p2):
+        per_pair = min(B, chunk if chunk else (256 << 20) // (L * 8))
+        b = 1024.0 * (2 * (per[p1]["FETCH_SIZE"][1] + per[p2]["FETCH_SIZE"][1]) + per[p1]["WRITE_SIZE"][1] + per[p2]["WRITE_SIZE"][1])
+        return {"one_launch": False, "kernel": p1 + " + " + p2, "dispatches_sampled": per[p1]["FETCH_SIZE"][0], "transforms_per_launch": per_pair, "bytes_per_launch": int(b),
+                "valu_lane_instructions_per_transform": int((per[p1]["SQ_INSTS_VALU"][1] + per[p2]["SQ_INSTS_VALU"][1]) * 32 * 64 / per_pair)}
+    return None
+
+
 def measure_limiter(lib, ck, torch, step, local_rank, seconds=1.0):
     """what the chip does under (a) the timed step itself and (b) a dense stream of the 64-bit integer instructions the field
     arithmetic lowers to, both for about `seconds`: shader clock and socket power from the SMI, the dense stream's sustained
@@ -200,6 +252,8 @@ def main():
                          "the other ring is reported beside it unless --one-ring")
     ap.add_argument("--one-ring", action="store_true")
     ap.add_argument("--no-prince", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic then comes from the committed profiles/traffic_r*.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)       # the process the live PMC passes profile: 1 + 2 steps of the headline batch
     ap.add_argument("--no-limiter", action="store_true", help="skip the ~3 s clock / power / dense-stream measurement (roofline.valu_ceiling.live)")
     ap.add_argument("--perf-table", default="", help="write the bundle-size table of doc/Perf_NTT.txt (tests/test_ntt.cu:140-151) to this file and exit")
     args = ap.parse_args()
@@ -254,6 +308,12 @@ def main():
 
     def step():
         ck(lib.cuhe_hip_ntt_fwd_batched(dst.data_ptr(), src.data_ptr(), L, B, L // 2, 0, None))
+
+    if args.pmc_child:               # profiled by measure_traffic_live(): nothing but the headline kernel, three launches
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,8 +391,11 @@ def main():
         one_launch = ms1.value < 0.02 * mst.value
         per_launch = B if one_launch else min(B, args.chunk if args.chunk else (256 << 20) // (L * 8))
         # PMC-derived figures (HBM-side bytes, VALU lane-instructions per transform) cannot be collected inside the timed
-        # process: they come from the committed rocprofv3 passes of this same command (profiles/traffic_r*.json), and only
-        # if that file was measured on the kernels that are running now (hash of the kernel sources); otherwise null.
+        # process.  They are MEASURED IN THIS RUN by child processes under rocprofv3 --pmc (measure_traffic_live, below); if that
+        # is not possible (no rocprofv3, N > 1, --no-pmc) they come from the committed passes of this same command
+        # (profiles/traffic_r*.json), and only if that file was measured on the kernels that are running now (hash of the kernel
+        # sources); otherwise null.
+        rec = {}
         traffic, lane_instr, pmc_note = None, None, "no profiles/traffic_r*.json for this transform length"
         try:
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
@@ -347,6 +410,20 @@ def main():
                     pmc_note = "%s was measured on other kernel sources (%s, now %s): re-run tools/profile_final.sh" % (os.path.basename(tf[-1]), rec.get("kernel_sha16"), kernel_sha16())
         except Exception as ex:
             pmc_note = "traffic file unreadable: %r" % (ex,)
+        committed = {"traffic": traffic, "note": pmc_note}
+        live = None
+        if world == 1 and L == 65536 and not args.no_pmc:
+            try:
+                live = measure_traffic_live(L, B, args.chunk)
+            except Exception:
+                live = None
+        if live and bool(live["one_launch"]) == one_launch and live["transforms_per_launch"] == per_launch:
+            traffic, lane_instr = live["bytes_per_launch"], live["valu_lane_instructions_per_transform"]
+            rec = dict(rec)
+            rec.setdefault("dense_stream_ceiling_T_per_s", 36.5)           # (profiles/r02_valu_cost_model.txt; re-measured below as valu_ceiling.live)
+            pmc_note = ("MEASURED IN THIS RUN: rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: one counter per pass) of a child process that launches "
+                        "the same batch three times; HBM-side bytes per launch = 2 x FETCH_SIZE (gfx950 counts wide streaming reads at half their bytes) + WRITE_SIZE = %d + %d; "
+                        "algorithmic = %d" % (live.get("fetch_bytes_per_launch_x2", 0), live.get("write_bytes_per_launch", 0), per_launch * alg_bytes))
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "dispatch": dispatch_info(lib),
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": pmc_note,
                     "kernel": ("ntt_onewg_stream<kOutU64> (persistent one-workgroup transform: two 32K-point halves per row, one launch per call)" if one_launch
@@ -354,6 +431,9 @@ def main():
                     "algorithmic_bytes_per_transform": alg_bytes,
                     "pipelined_ms_per_batch": round(mst.value / iters, 4),
                     "pass1_ms_per_batch": round(ms1.value / iters, 4), "pass2_ms_per_batch": round(ms2.value / iters, 4)}
+        if live:
+            roofline["traffic_live"] = live
+            roofline["traffic_committed_record"] = committed
         limiter = None
         if not args.no_limiter:
             try:
