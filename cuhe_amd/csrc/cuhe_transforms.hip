@@ -256,23 +256,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         // onewg_split = 2 (tests, A/B): also the forward rows of 32K points (measured equal: 519 vs 512 us per 2304 rows -- the
         // pre-add and the sample twist cost what the overlap wins) and the inverse rows of 64K points (slower than the two passes)
         const bool split_inv = mode == kSrcU64Neg || mode == kSrcU64NegMul;
-        // round 5: the inverse rows of 64K points as PERSISTENT split halves with the rendezvous (onewg_split = 3)
-        if (LG == 16 && split_inv && nstore == kNcInverse && G_.onewg && G_.onewg_split == 3 && !(ep && ep->kind) && grid64 >= 16 && grid64 / 2 <= kOwPairCounters &&
-            (G_.onewg == 2 || 2L * batch >= 2L * grid64)) {
-            OwTab &ot = D.ow[3];
-            CHK(ensure_onewg(ot, 15));
-            if (mode == kSrcU64NegMul && !mul_tab) return fail(CUHE_EINVAL, "second operand missing");
-            if (!tab.twinv) return fail(CUHE_EINVAL, "negacyclic untwist table missing");
-            OwArgs a{dst, src, ot.TW1hi, ot.TW2, src_stride, dst_stride, batch, L, wa, mode == kSrcU64NegMul ? mul_tab : nullptr,
-                     D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, tab.twinv, ot.c128, ot.i4neg};
-            if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            CHK(ws_pair_counters(W));
-            note_dispatch("persistent split inverse halves with rendezvous (negacyclic rows)", L, batch);
-            hipError_t he = ow_launch_stream_inv_15(mode, a, grid64, W.pair_cnt, st);
-            if (he != hipSuccess) return fail(CUHE_EHIP, "persistent split inverse (negacyclic rows): %s", hipGetErrorString(he));
-            if (tm && tm->on) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
-            return CUHE_OK;
-        }
+        // (a persistent split form of the inverse 64K-point rows with the rendezvous was built in round 5 and lost to the pair by 2 %: profiles/r05_split_inverse_ab.txt)
         if (G_.onewg && !half && !(ep && ep->kind) &&
             ((LG == 15 && ((split_inv && G_.onewg_split >= 1) || (mode == kSrcU32Twist && G_.onewg_split == 2))) || (LG == 16 && split_inv && G_.onewg_split == 2)) &&
             (G_.onewg == 2 || 2L * batch >= (long)D.cus * (1 << (16 - LG)))) {
@@ -740,7 +724,7 @@ int cuhe_hip_set_ntt_chunk(int chunk) {
     return CUHE_OK;
 }
 int cuhe_hip_set_onewg_split(int mode) {
-    if (mode < 0 || mode > 3) return fail(CUHE_EINVAL, "split mode %d", mode);
+    if (mode < 0 || mode > 2) return fail(CUHE_EINVAL, "split mode %d", mode);
     G_.onewg_split = mode;
     return CUHE_OK;
 }

@@ -533,89 +533,9 @@ void ntt_onewg_stream(void *__restrict__ dst_, const u32 *__restrict__ src, cons
     else ow_stream_loop<R, SRC, OUT, 0>(dst_, src, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, prime0, np_mod, pair_cnt, &give_up, ta);
 }
 
-// ---- persistent form of the SPLIT inverse of full negacyclic rows of 2 Lh points (round 5): resident workgroups
-// walk over the 2 * batch halves like ow_stream_loop -- no prefetch (a half reads BOTH halves of its u64 row: 512 KB at 64K points,
-// more than the LDS holds) -- and the two workgroups of a row meet before their stores, which write alternate 4-byte words of the same
-// lines (coefficient 2 j + h).  MODE: kSrcU64Neg (rows) or kSrcU64NegMul (products of two rows, multiplied as they are loaded).
-template <int R, int MODE, int H>
-__device__ __forceinline__ void ow_stream_inv_loop(u32 *__restrict__ dst, const u64 *__restrict__ src, const u64 *__restrict__ mul, const u64 *__restrict__ TW1,
-                                                   u64 *buf, const u64 *tw2, long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab,
-                                                   const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod, unsigned *pair_cnt, int *give_up) {
-    static_assert(MODE == kSrcU64Neg || MODE == kSrcU64NegMul, "row sources of the persistent split inverse");
-    static_assert(R == 16 || R == 32, "sub-transforms of 16K / 32K points");
-    using G = OwGeom<R>;
-    constexpr int T = G::T, Lh = G::Lh, L = 2 * Lh;
-    const int t = threadIdx.x;
-    const int nitems = 2 * ((nbatch + 7) & ~7);
-    unsigned *const gave_up_total = pair_cnt ? pair_cnt + kOwGiveUpSlot : nullptr;
-    int round = 0;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int batch = (item >> 4) * 8 + (item & 7);
-        int opaque = 0;                                    // (see ow_stream_loop: keeps the loop-invariant addresses out of the loop-carried state)
-        asm volatile("" : "+v"(opaque));
-        const long ro = (long)min(batch, nbatch - 1) * src_stride;      // a padding item recomputes the last real row and stores nothing
-        const u64 *row = src + ro;
-        const u64 *mrow = MODE == kSrcU64NegMul ? mul + ro : nullptr;
-        const int tt = t + opaque;
-        u64 *lb = buf + opaque;
-        u64 x[32], y[32], z[32];
-#pragma unroll
-        for (int a0 = 0; a0 < 32; a0 += 4) {
-            u64 y0[4], y1[4], w0[4], w1[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int k = (a0 + a) * T + tt;            // (tt: the 64 reversed offsets are recomputed per item instead of living across the loop)
-                y0[a] = row[(L - k) & (L - 1)]; y1[a] = row[Lh - k];
-                if constexpr (MODE == kSrcU64NegMul) { w0[a] = mrow[(L - k) & (L - 1)]; w1[a] = mrow[Lh - k]; }
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if constexpr (MODE == kSrcU64NegMul) { y0[a] = mulp(y0[a], w0[a]); y1[a] = mulp(y1[a], w1[a]); }
-                x[a0 + a] = H ? subp(y0[a], y1[a]) : addp(y0[a], y1[a]);
-            }
-        }
-        if constexpr (H) SplitShift<0>::run(x);
-        owb_stage1_x1<R>(x, y, lb, TW1 + (long)H * Lh + t + opaque, true, t);
-        owb_stage2_x2<R>(y, z, lb, tw2 + opaque, t, true);
-        if (pair_cnt) {                                    // rendezvous with the workgroup of the other parity (block ^ 8), as in ow_stream_loop
-            if (t == 0) {
-                unsigned *c = pair_cnt + (((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
-                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned want = 2u * (unsigned)(round + 1);
-                bool met = false;
-                for (int spin = 0; spin < 256 && !met; ++spin) {
-                    met = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
-                    if (!met) __builtin_amdgcn_s_sleep(4);
-                }
-                if (!met) { *give_up = 1; __hip_atomic_fetch_add(gave_up_total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-            __syncthreads();
-            if (*give_up) pair_cnt = nullptr;
-        }
-        dft_regs<32, false>(z);
-        if (batch < nbatch) {
-            const int pidx = np_mod > 0 ? (prime0 + batch) % np_mod : prime0 + batch;
-            ow_store_half_nc<R>(z, dst, dst_stride, batch, H, tt, xtab, primes[pidx], pinv[pidx]);      // (tt: or the 32 store / table offsets live across the loop)
-        }
-        ++round;
-    }
-}
-template <int LGH, int MODE>
-__global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
-void ntt_onewg_stream_inv(u32 *__restrict__ dst, const u64 *__restrict__ src, const u64 *__restrict__ mul, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
-                          long src_stride, long dst_stride, int nbatch, const u64 *__restrict__ xtab, const u32 *__restrict__ primes, const u64 *__restrict__ pinv,
-                          int prime0, int np_mod, unsigned *pair_cnt) {
-    constexpr int R = (1 << LGH) / 1024;
-    using G = OwGeom<R>;
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    u64 *buf = lds;
-    u64 *tw2 = lds + G::XWB;
-    __shared__ int give_up;
-    tw2[threadIdx.x] = TW2[threadIdx.x];
-    if (threadIdx.x == 0) give_up = 0;
-    if ((blockIdx.x >> 3) & 1) ow_stream_inv_loop<R, MODE, 1>(dst, src, mul, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, primes, pinv, prime0, np_mod, pair_cnt, &give_up);
-    else ow_stream_inv_loop<R, MODE, 0>(dst, src, mul, TW1, buf, tw2, src_stride, dst_stride, nbatch, xtab, primes, pinv, prime0, np_mod, pair_cnt, &give_up);
-}
+// (Round 5 built the persistent form of the SPLIT inverse of 64K-point rows -- resident 32K-point workgroups, rendezvous of a row's two
+// halves before the stores of coefficient 2 j + h -- and removed it: 1.82 ms against 1.78 ms for the two-pass pair per 32 ciphertexts of
+// x^65536+1; profiles/r05_split_inverse_ab.txt.)
 
 
 }  // namespace cuhe

@@ -29,9 +29,6 @@ hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream
 constexpr int kOwPairCounters = 512;     // + 1 slot behind them: workgroups that gave a rendezvous up (never reset by a launch)
 hipError_t ow_launch_stream_14(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
 hipError_t ow_launch_stream_15(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
-// persistent SPLIT inverse of full negacyclic rows of 64K points (kSrcU64Neg / kSrcU64NegMul -> kOutModPNc): a.TW1 = the inverse parity
-// tables (TW1hi), a.tw = the second operand rows (products) or null, a.xtab = the untwist table; grid / pair_cnt as above
-hipError_t ow_launch_stream_inv_15(int mode, const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st);
 bool ow_supported(int mode, int out, bool half);
 // half = true with a full-length source: the SPLIT form (two half-length transforms per row), 32K / 64K-point rows
 bool ow_split_supported(int mode, int out);

@@ -114,36 +114,6 @@ hipError_t OW_CONCAT(ow_launch_stream_, CUHE_OW_LGH)(int mode, int out, const Ow
 }
 #endif
 #if CUHE_OW_LGH == 15
-template <int MODE>
-static hipError_t launch_stream_inv(const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st) {
-    auto kern = ntt_onewg_stream_inv<kLgh, MODE>;
-    static std::mutex mu; static std::atomic<uint64_t> done{0};
-    int cur = 0;
-    hipError_t e = hipGetDevice(&cur);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (cur & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!(done.load(std::memory_order_relaxed) & bit)) {
-            e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::bytes_stream);
-            if (e != hipSuccess) return e;
-            done.fetch_or(bit, std::memory_order_release);
-        }
-    }
-    if (pair_cnt) {
-        e = hipMemsetAsync(pair_cnt, 0, (size_t)(grid / 2) * sizeof(unsigned), st);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes_stream, st, (u32 *)a.dst, (const u64 *)a.src, a.tw, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
-                       a.xtab, a.primes, a.pinv, a.prime0, a.np_mod, pair_cnt);
-    return hipGetLastError();
-}
-hipError_t ow_launch_stream_inv_15(int mode, const OwArgs &a, int grid, unsigned *pair_cnt, hipStream_t st) {
-    if (grid < 16 || (grid & 15) || grid / 2 > kOwPairCounters || !a.xtab) return hipErrorInvalidValue;
-    if (mode == kSrcU64Neg) return launch_stream_inv<kSrcU64Neg>(a, grid, pair_cnt, st);
-    if (mode == kSrcU64NegMul && a.tw) return launch_stream_inv<kSrcU64NegMul>(a, grid, pair_cnt, st);
-    return hipErrorInvalidValue;
-}
 bool ow_supported(int mode, int out, bool half) {
     if (half) return (mode == kSrcU32Ext && (out == kOutU64 || out == kOutU64Mul)) || (mode == kSrcWindow && out == kOutU64);
     if (mode == kSrcU32Twist) return out == kOutU64 || out == kOutU64Mul;

@@ -373,8 +373,7 @@ int cuhe_hip_set_ll_rows(int rows);
  * cuhe_hip_set_onewg_split: full-length INVERSE negacyclic rows of 32K points (the ciphertext domain of x^32768 + 1) run,
  * when the call fills the chip, SPLIT into the two 16K-point transforms of their even and odd outputs, two workgroups per
  * CU (mode 1, default: 13 % faster than one 32K-point workgroup per row); 0: never; 2: also the forward rows of 32K points
- * and the inverse rows of 64K points (no gain measured: parity tests and A/B runs); 3: as 1, and the inverse rows of 64K points
- * as PERSISTENT split halves with the rendezvous of a row's two workgroups (round 5 A/B).  Environment CUHE_ONEWG_SPLIT.
+ * and the inverse rows of 64K points (no gain measured: parity tests and A/B runs).  Environment CUHE_ONEWG_SPLIT.
  * Environment CUHE_ONEWG / CUHE_ONEWG64 override the defaults for A/B runs of whole programs.  Replaces the same
  * reference code as the two-pass kernels (cuhe/Base.cu:309-842, cuhe/Operations.cu:306-398). */
 int cuhe_hip_set_onewg(int mode, int rows64k);
