@@ -211,7 +211,7 @@ enum { X2C = 1, X2N = 2, RELIN = 3, MS = 4, AND = 5, XOR = 6, COPY = 7, NOT = 8 
 struct Ct { sched::Node *n = nullptr; int level = 0, domain = 2; bool prod = false; int dev = 0; };
 long key(int level, int domain, bool prod) { return (long)level | (long)domain << 8 | (long)(prod ? 1 : 0) << 12; }
 std::atomic<long> lone{0};
-void spin(double us) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < us) {} }
+void spin(double us) { static const bool off = getenv("SIM_NOSPIN") != nullptr; if (off) return; const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < us) {} }
 void simBatch(int, sched::Node *const *, sched::Node *const *, sched::Node *const *, int count, void *stream) { mock::launch(stream); spin(25.0 + 0.4 * count); }
 void gate(int kind, Ct &out, std::vector<Ct *> reads, long k) {
 	std::vector<sched::Node *> r; for (Ct *c : reads) if (c->n != out.n) r.push_back(c->n);
