@@ -792,7 +792,7 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, sin
                            "key memory divide by the number of ranks" % (K * lib_ct_len * 8, q.numCrtPrime * q.crtLen * 4),
             "primes_per_rank": sh.count, "numCrtPrime": q.numCrtPrime, "numEvalKey": K, "ring_degree": q.modLen,
             "comm_size": lib_comm_size, "rccl_per_rank": per_rank,
-            "exchange": "RCCL group of broadcasts inside cuhe_hip_mul_relin_sharded, on the compute stream" if in_library
+            "exchange": "RCCL all-gather inside cuhe_hip_mul_relin_sharded, on the compute stream (one in-place ncclAllGather when the blocks are equal, one padded ncclAllGather otherwise; the path every rank took is in rccl_per_rank)" if in_library
                         else "torch.distributed all-gather around the C-ABI stages (in-library communicator unavailable: %s)" % comm_err,
             "collective": "1 all-gather of %d B per rank per multiply" % (sh.count * q.crtLen * 4)}
 

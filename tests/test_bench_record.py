@@ -35,3 +35,39 @@ def test_newest_traffic_record_matches_the_kernel_sources_in_the_tree():
     assert rec["transform_len"] == 65536 and rec["bytes_per_transform"] >= 10 * 65536          # at least the algorithmic bytes
     lanes = sum(rec["valu_lane_instructions_per_point"].values())
     assert 100 < lanes < 250                                                                   # vector lane-instructions per point
+
+
+def test_live_pmc_record_is_read_back_from_a_rocpd_database(tmp_path, monkeypatch):
+    """bench.measure_traffic_live (round 5: the PMC passes run as child processes of bench.py itself) against a stand-in for rocprofv3:
+    a script that writes the rocpd tables the function queries.  Checks the query, the units (KB per dispatch, FETCH_SIZE x 2, SQ_INSTS_VALU per
+    shader engine x 64 lanes) and the fall-back to None when a pass fails."""
+    import sqlite3
+    import subprocess
+    import bench
+    B, L = 8192, 65536
+    per_counter = {"FETCH_SIZE": 800000.0, "WRITE_SIZE": 4850000.0, "SQ_INSTS_VALU": 40188928.0}
+
+    def fake_run(cmd, **kw):
+        counter, outdir = cmd[cmd.index("--pmc") + 1], cmd[cmd.index("-d") + 1]
+        os.makedirs(outdir, exist_ok=True)
+        db = sqlite3.connect(os.path.join(outdir, "p_results.db"))
+        db.executescript("create table rocpd_info_kernel_symbol(id integer, display_name text); create table rocpd_kernel_dispatch(event_id integer, kernel_id integer);"
+                         "create table rocpd_info_pmc(id integer, name text); create table rocpd_pmc_event(event_id integer, pmc_id integer, value real);")
+        db.execute("insert into rocpd_info_kernel_symbol values (1, 'void cuhe::ntt_onewg_stream<15, 0, 0>(void*, unsigned int const*)')")
+        db.execute("insert into rocpd_info_kernel_symbol values (2, 'void other_kernel(int)')")
+        db.execute("insert into rocpd_info_pmc values (7, ?)", (counter,))
+        for ev in range(3):
+            db.execute("insert into rocpd_kernel_dispatch values (?, 1)", (ev,))
+            db.execute("insert into rocpd_pmc_event values (?, 7, ?)", (ev, per_counter[counter]))
+        db.execute("insert into rocpd_kernel_dispatch values (9, 2)"); db.execute("insert into rocpd_pmc_event values (9, 7, 1.0)")
+        db.commit(); db.close()
+        return subprocess.CompletedProcess(cmd, 0, "", "")
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p, _e=os.path.exists: True if p.endswith("rocprofv3") else _e(p))
+    rec = bench.measure_traffic_live(L, B, 0)
+    assert rec and rec["one_launch"] and rec["dispatches_sampled"] == 3 and rec["transforms_per_launch"] == B
+    assert rec["bytes_per_launch"] == int(1024 * (2 * 800000.0 + 4850000.0))
+    assert rec["valu_lane_instructions_per_transform"] == int(40188928.0 * 32 * 64 / B)
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 1, "", "boom"))
+    assert bench.measure_traffic_live(L, B, 0) is None
