@@ -24,10 +24,12 @@
 namespace sample_profiler {
 constexpr int kDepth = 28, kMax = 200000;
 static void *g_pc[kMax][kDepth];
+static int g_tid[kMax];
 static volatile int g_n = 0;
 static void handler(int) {
 	const int i = __sync_fetch_and_add(&g_n, 1);
 	if (i >= kMax) return;
+	g_tid[i] = (int)syscall(SYS_gettid);
 	void *buf[kDepth + 2];
 	const int n = backtrace(buf, kDepth + 2);
 	for (int k = 0; k < kDepth; ++k) g_pc[i][k] = k + 2 < n ? buf[k + 2] : nullptr;      // skip the handler and the signal trampoline
@@ -36,6 +38,7 @@ static std::atomic<bool> g_run{false};
 static std::thread g_sampler;
 inline void start() {
 	void *warm[4]; backtrace(warm, 4);          // loads libgcc's unwinder outside the handler
+	g_n = 0;                                    // (a new profile per start: test_prince_flow --repeat N --profile reports every block on its own)
 	struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_handler = handler; sa.sa_flags = SA_RESTART;
 	sigaction(SIGUSR2, &sa, nullptr);
 	g_run = true;
@@ -89,6 +92,30 @@ inline void report(FILE *f, const char *marker_obj = "libcuHE.so", int top = 30)
 		fprintf(f, "%s\n", title);
 		for (int i = 0; i < (int)v.size() && i < top; ++i) fprintf(f, "  %6d  %5.1f %%  %s\n", v[i].first, 100.0 * v[i].first / std::max(kept, 1), v[i].second.c_str());
 	};
+	// per thread: the innermost frame inside libcuHE.so (the call site in the C++ layer the sample sits under), so that the ONE worker that
+	// issues the batches can be read on its own (tools/resolve_samples.py adds file:line)
+	std::map<int, std::map<std::string, int>> perThread; std::map<int, int> perThreadTotal;
+	for (int i = 0; i < n; ++i) {
+		std::string site;
+		for (int k = 0; k < kDepth && g_pc[i][k] && site.empty(); ++k) {
+			Dl_info di;
+			if (!dladdr(g_pc[i][k], &di) || !di.dli_fname) continue;
+			const char *b = strrchr(di.dli_fname, '/');
+			if (std::string(b ? b + 1 : di.dli_fname) != marker_obj) continue;
+			char buf[256];
+			snprintf(buf, sizeof buf, "%s+0x%lx", marker_obj, (unsigned long)((char *)g_pc[i][k] - (char *)di.dli_fbase));
+			site = buf;
+		}
+		if (site.empty()) continue;
+		++perThread[g_tid[i]][site]; ++perThreadTotal[g_tid[i]];
+	}
+	for (auto &t : perThread) {
+		std::vector<std::pair<int, std::string>> v;
+		for (auto &e : t.second) v.push_back({e.second, e.first});
+		std::sort(v.begin(), v.end(), [](auto &x, auto &y) { return x.first > y.first; });
+		fprintf(f, "thread %d: %d samples; innermost call site in %s:\n", t.first, perThreadTotal[t.first], marker_obj);
+		for (int i = 0; i < (int)v.size() && i < 22; ++i) fprintf(f, "  %6d  %5.1f %%  %s\n", v[i].first, 100.0 * v[i].first / std::max(perThreadTotal[t.first], 1), v[i].second.c_str());
+	}
 	dump("LEAF symbol:", leaf);
 	dump("innermost frame in libcuHE.so / libcuhe_hip.so (offsets: tools/resolve_samples.py):", ours);
 	dump("leaf <- innermost own frame:", pair);

@@ -18,5 +18,6 @@ for line in sys.stdin:
     name = "?"
     if path and os.path.exists(path):
         r = subprocess.run(["addr2line", "-f", "-C", "-e", path, "0x" + off], capture_output=True, text=True)
-        name = r.stdout.split("\n")[0][:110]
+        parts = r.stdout.split("\n")
+        name = parts[0][:90] + ("  " + os.path.basename(parts[1]) if len(parts) > 1 and parts[1] and not parts[1].startswith("??") else "")
     print("%s %s+0x%s  %s" % (cnt, obj, off, name))
