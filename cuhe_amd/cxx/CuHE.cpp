@@ -341,7 +341,8 @@ void CuPolynomial::schedDetach() {
 void CuPolynomial::schedRelease() {
 	if (!node_) return;
 	sched::Node *n = node_; node_ = NULL;
-	sched::submit(device_ >= 0 ? device_ : 0, Nodes(), Nodes(1, n), [n](void *s) { n->obj->stream_ = s; n->obj->reset(); });
+	// (release-only: reset() enqueues nothing, its blocks go back with the positions of their last uses -- Scheduler.h)
+	sched::submit(device_ >= 0 ? device_ : 0, Nodes(), Nodes(1, n), [n](void *s) { n->obj->stream_ = s; n->obj->reset(); }, false, sched::kReleaseOnly);
 	sched::releaseNode(n);
 }
 void CuPolynomial::reset() {

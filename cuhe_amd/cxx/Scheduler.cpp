@@ -52,6 +52,9 @@ struct StreamState {
 	std::atomic<long> seq{0};              // tasks issued on this stream so far (written by its worker only)
 	std::mutex m;                          // guards `event` / `covered`
 	long covered = 0;                      // the event's last record lies behind task #covered
+	// what THIS stream has waited for already (its own worker only): per foreign stream, the `covered` of the event record it waited on last.
+	// Everything enqueued here since is ordered behind that stream's tasks up to that number: no second wait (one barrier packet each) for them
+	std::vector<std::pair<StreamState *, long>> waited;
 };
 struct Task {
 	std::function<void(void *)> fn;
@@ -139,8 +142,14 @@ void pruneReaders(Node *n) {               // recMu held
 	for (size_t i = 0; i < all.size(); ++i) if (!shadowed[i]) n->readers.push_back(all[i]);
 	for (size_t i = 0; i < all.size(); ++i) if (shadowed[i]) unrefTask(all[i]);
 }
-// stream `s` (of device `dev`) waits until task #seq of `from` has finished; returns the number of events recorded (0 or 1)
-int orderAfter(int dev, void *s, StreamState *from, long seq) {
+// the stream of `me` (a worker's own, on device `dev`) waits until task #seq of `from` has finished, unless it has done so already;
+// returns the number of events recorded (0 or 1), *waited: whether a wait was enqueued
+std::atomic<long> waitsSkipped{0}, waitsDone{0};
+int orderAfter(int dev, StreamState *me, StreamState *from, long seq, bool *waited = nullptr) {
+	std::pair<StreamState *, long> *mine = nullptr;
+	for (auto &w : me->waited) if (w.first == from) { mine = &w; break; }
+	if (waited) *waited = false;
+	if (mine && mine->second >= seq) { waitsSkipped.fetch_add(1, std::memory_order_relaxed); return 0; }
 	std::lock_guard<std::mutex> lk(from->m);
 	int recorded = 0;
 	if (from->covered < seq) {
@@ -148,14 +157,24 @@ int orderAfter(int dev, void *s, StreamState *from, long seq) {
 		CSC(cuhe_hip_event_record(from->dev, from->event, from->stream));
 		from->covered = now; recorded = 1;
 	}
-	CSC(cuhe_hip_stream_wait_event(dev, s, from->event));
+	CSC(cuhe_hip_stream_wait_event(dev, me->stream, from->event));
+	if (mine) mine->second = from->covered; else me->waited.push_back({from, from->covered});
+	if (waited) *waited = true;
+	waitsDone.fetch_add(1, std::memory_order_relaxed);
 	return recorded;
 }
 
 // ---- device blocks released and taken inside tasks.  The library's stream-ordered pool (cuhe_hip_malloc_stream) hands a
 // block freed on one stream to another stream only behind everything enqueued on the first; here a released block carries
 // "task #k of stream S" -- its last use -- and the taker is ordered behind exactly that, usually an event record of long ago.
-struct Block { void *ptr; StreamState *ss; long seq; };
+// (a block released by a release-only task carries the positions of that task's dependencies: up to kMaxPos streams)
+constexpr int kMaxPos = 3;
+struct Pos { StreamState *ss; long seq; };
+struct Block { void *ptr; Pos pos[kMaxPos]; int npos; };
+// the release-only task this worker is running: the positions its blocks take (nullptr outside such a task) and, once a block that is
+// NOT the cache's had to be released in the order of the worker's own stream, the fact that the stream has been ordered behind them
+struct ReleaseCtx { int dev; StreamState *me; std::vector<std::pair<StreamState *, long>> *pos; bool ordered; long waits, records; };
+thread_local ReleaseCtx *tlsRelease = nullptr;
 struct BlockCache {                        // per device
 	std::mutex m;
 	std::unordered_map<size_t, std::deque<Block>> bySize;
@@ -240,7 +259,7 @@ DevState &deviceState(int dev);
 // a task whose dependencies have all been issued.  `me` / `next`: the calling worker's index on ITS device and its chain slot
 void makeReady(Task *t, Task **next) {
 	DevState &D = deviceState(t->dev);
-	if (t->kind && batchRunner && maxBatch > 1) {
+	if (t->kind > 0 && batchRunner && maxBatch > 1) {
 		std::lock_guard<std::mutex> lk(D.m);
 		const GroupKey k{t->kind, t->key};
 		Group &G = D.staged[k];
@@ -312,7 +331,7 @@ void workerMain(DevState *Dp, int me) {
 			D.idleSeconds += std::chrono::duration<double>(clk::now() - w0).count();
 		}
 		const auto b0 = clk::now();
-		const bool asBatch = batch[0]->kind && batchRunner && maxBatch > 1;       // (a group of one member still counts as a batch in flight)
+		const bool asBatch = batch[0]->kind > 0 && batchRunner && maxBatch > 1;       // (a group of one member still counts as a batch in flight)
 		if (asBatch) ++D.busyBatch; else ++D.busyRegular;
 		D.used = true;
 		lk.unlock();
@@ -329,10 +348,22 @@ void workerMain(DevState *Dp, int me) {
 				for (auto &e : latest) if (e.first == d->ss) { if (d->seq > e.second) e.second = d->seq; found = true; }
 				if (!found) latest.push_back({d->ss, d->seq});
 			}
-		for (auto &e : latest) { records += orderAfter(D.dev, s, e.first, e.second); ++waits; }
+		const bool releaseOnly = batch.size() == 1 && batch[0]->kind == kReleaseOnly;
+		ReleaseCtx rel{D.dev, ss, &latest, false, 0, 0};
+		if (releaseOnly) {                      // no wait here: the blocks it releases take the positions of its dependencies (own stream included)
+			for (Task *d : batch[0]->deps) {
+				if (d->ss != ss) continue;
+				bool found = false;
+				for (auto &e : latest) if (e.first == ss) { if (d->seq > e.second) e.second = d->seq; found = true; }
+				if (!found) latest.push_back({ss, d->seq});
+			}
+			tlsRelease = &rel;
+		} else
+			for (auto &e : latest) { bool w; records += orderAfter(D.dev, ss, e.first, e.second, &w); if (w) ++waits; }
 		tlsStream = s;
 		const auto f0 = clk::now();
-		if (batch.size() == 1) batch[0]->fn(s);
+		if (releaseOnly) { batch[0]->fn(s); tlsRelease = nullptr; waits += rel.waits; records += rel.records; }
+		else if (batch.size() == 1) batch[0]->fn(s);
 		else {
 			std::vector<Node *> subjects, o1, o2;
 			for (Task *t : batch) { subjects.push_back(t->subject); o1.push_back(t->op1); o2.push_back(t->op2); }
@@ -352,7 +383,7 @@ void workerMain(DevState *Dp, int me) {
 			t->succ.clear();
 		}
 		if (batch.size() > 1) { ++D.batchesRun; D.batchedTasks += (long)batch.size(); } else ++D.loneTasks;
-		if (trace && batch[0]->kind) ++D.sizeHist[batch[0]->kind][(int)batch.size()];
+		if (trace && batch[0]->kind > 0) ++D.sizeHist[batch[0]->kind][(int)batch.size()];
 		D.waits += waits; D.records += records;
 		D.busySeconds += std::chrono::duration<double>(clk::now() - b0).count();
 		D.gateSeconds += std::chrono::duration<double>(f1 - f0).count();
@@ -451,7 +482,7 @@ void *taskAlloc(int dev, size_t bytes) {
 	StreamState *me = tlsSS && tlsSS->dev == dev ? tlsSS : nullptr;
 	if (dev < 0 || dev >= kMaxDevices) return cuhe_hip_malloc(dev, bytes);
 	BlockCache &C = caches[dev];
-	Block b{nullptr, nullptr, 0};
+	Block b{nullptr, {}, 0};
 	{
 		std::lock_guard<std::mutex> lk(C.m);
 		C.checkGeneration();
@@ -459,13 +490,14 @@ void *taskAlloc(int dev, size_t bytes) {
 		if (it != C.bySize.end() && !it->second.empty()) {
 			std::deque<Block> &q = it->second;
 			size_t pick = q.size();
-			for (size_t i = q.size(); i-- > 0 && q.size() - i <= 8;) if (q[i].ss == me) { pick = i; break; }     // one of this stream's own: nothing to wait for
-			if (pick == q.size()) { pick = 0; ++C.foreign; } else ++C.hits;                                    // else the one released longest ago
+			auto own = [&](const Block &x) { for (int k = 0; k < x.npos; ++k) if (x.pos[k].ss != me) return false; return true; };
+			for (size_t i = q.size(); i-- > 0 && q.size() - i <= 8;) if (own(q[i])) { pick = i; break; }     // last used on this stream only: nothing to wait for
+			if (pick == q.size()) { pick = 0; ++C.foreign; } else ++C.hits;                                // else the one released longest ago
 			b = q[pick]; q.erase(q.begin() + pick);
 		} else ++C.misses;
 	}
 	if (b.ptr) {
-		if (b.ss != me && me) orderAfter(dev, me->stream, b.ss, b.seq);
+		if (me) for (int k = 0; k < b.npos; ++k) if (b.pos[k].ss != me) orderAfter(dev, me, b.pos[k].ss, b.pos[k].seq);
 		return b.ptr;
 	}
 	void *p = cuhe_hip_malloc(dev, bytes);
@@ -482,15 +514,37 @@ void forgetBlock(void *p) {                // released outside a task (the clien
 		if (!C.sizeOf.empty()) C.sizeOf.erase(p);
 	}
 }
+// a release-only task has to put its worker's stream behind its dependencies after all (a block that is not the cache's goes back in
+// the order of that stream; more streams than a block has room for)
+static void orderReleaseStream(ReleaseCtx *R) {
+	if (R->ordered) return;
+	for (auto &e : *R->pos) if (e.first != R->me) { bool w; R->records += orderAfter(R->dev, R->me, e.first, e.second, &w); if (w) ++R->waits; }
+	R->ordered = true;
+}
 bool taskFree(int dev, void *p) {
 	StreamState *me = tlsSS && tlsSS->dev == dev ? tlsSS : nullptr;
 	if (dev < 0 || dev >= kMaxDevices) return false;
+	ReleaseCtx *R = tlsRelease;
 	BlockCache &C = caches[dev];
-	std::lock_guard<std::mutex> lk(C.m);
+	std::unique_lock<std::mutex> lk(C.m);
 	C.checkGeneration();
 	auto it = C.sizeOf.find(p);
-	if (it == C.sizeOf.end() || !me) return false;                 // not one of ours (allocated before the object was attached)
-	C.bySize[it->second].push_back(Block{p, me, me->seq.load(std::memory_order_relaxed) + 1});     // last use: the running task
+	if (it == C.sizeOf.end() || !me) {                              // not one of ours (allocated before the object was attached)
+		lk.unlock();
+		if (R) orderReleaseStream(R);
+		return false;
+	}
+	const size_t bytes = it->second;
+	if (R && !R->ordered && R->dev == dev && !R->pos->empty() && (int)R->pos->size() <= kMaxPos) {
+		Block b{p, {}, 0};                                            // last uses: the dependencies of the running task, wherever they ran
+		for (auto &e : *R->pos) b.pos[b.npos++] = Pos{e.first, e.second};
+		C.bySize[bytes].push_back(b);
+		return true;
+	}
+	if (R && !R->ordered) { lk.unlock(); orderReleaseStream(R); lk.lock(); }
+	Block b{p, {}, 1};
+	b.pos[0] = Pos{me, me->seq.load(std::memory_order_relaxed) + 1};  // last use: the running task
+	C.bySize[bytes].push_back(b);
 	return true;
 }
 void stop() {
@@ -511,7 +565,8 @@ void stop() {
 		printf("allocator: %lld hipMalloc, %lld pool hits, %lld stream hits, %lld cross-stream hand-overs\n", ac[0], ac[1], ac[2], ac[3]);
 		long hits = 0, foreign = 0, misses = 0;
 		for (BlockCache &C : caches) { hits += C.hits; foreign += C.foreign; misses += C.misses; }
-		printf("task blocks: %ld from the same stream, %ld from another stream (ordered behind their last use), %ld from the library\n", hits, foreign, misses);
+		printf("task blocks: %ld from the same stream, %ld from another stream (ordered behind their last use), %ld from the library; stream waits enqueued %ld, "
+		       "not needed (already behind that task) %ld\n", hits, foreign, misses, waitsDone.load(), waitsSkipped.load());
 		long batches = 0, batched = 0, lone = 0, waits = 0, records = 0, incomplete = 0;
 		double busy = 0, gate = 0, order = 0, idle = 0;
 		for (DevState *D : devs) if (D) {
@@ -538,6 +593,7 @@ void stop() {
 		D->busySeconds = D->idleSeconds = D->gateSeconds = D->orderSeconds = 0; D->sizeHist.clear(); D->used = false;
 	}
 	for (BlockCache &C : caches) C.hits = C.foreign = C.misses = 0;
+	waitsDone = 0; waitsSkipped = 0;
 	totalTasks.store(0); maxQueued.store(0);
 }
 
@@ -561,7 +617,7 @@ Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *
 	ensureWorkers(dev);
 	Task *t = new Task;
 	t->fn = std::move(fn); t->dev = dev; t->kind = kind; t->key = key; t->subject = subject; t->op1 = op1; t->op2 = op2;
-	const bool batchable = kind && batchRunner && maxBatch > 1;
+	const bool batchable = kind > 0 && batchRunner && maxBatch > 1;
 	{
 		std::lock_guard<std::mutex> lk(recMu);
 		t->id = nextId.fetch_add(1) + 1;

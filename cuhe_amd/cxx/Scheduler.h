@@ -45,6 +45,10 @@ void releaseNode(Node *n);                 // the client object lets go (tasks m
 // staging area until the workers have nothing else to issue, then up to maxBatch of them run as ONE call of the batch runner
 // (gather the subjects' blocks, one array entry point of the C ABI over all their rows, scatter) instead of their closures.
 // op1 / op2: the operands of a batchable binary gate (subject = op1 (x) op2)
+// kind == kReleaseOnly: fn only RELEASES the device blocks of the polynomial it writes (taskFree) and enqueues nothing.  Such a task
+// waits for nothing on its worker's stream: every block it releases carries the positions of the task's dependencies (the block's real
+// last uses), so that the next taker on the stream of those uses -- the batch of the next layer -- gets it without any event.
+constexpr int kReleaseOnly = -1;
 Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep = false,
              int kind = 0, long key = 0, Node *subject = nullptr, Node *op1 = nullptr, Node *op2 = nullptr);
 typedef void (*BatchRunner)(int kind, Node *const *subjects, Node *const *op1, Node *const *op2, int count, void *stream);

@@ -9,6 +9,15 @@
 #pragma once
 #include "CuHE.h"
 #include "cuhe_hip.h"
+#include <cstdlib>
+// CUHE_TRACE_MARK=1: a recognisable kernel (the library's VALU probe, ~1 ms) before and after the timed part of a client, so that a
+// rocprofv3 kernel trace can be cut to that part (tools/rocpd_summary.py --between k_probe_valu)
+static inline void traceMark() {
+	if (!getenv("CUHE_TRACE_MARK")) return;
+	double a, b, c;
+	cuhe_hip_device_sync(0);
+	cuhe_hip_probe_valu(0, 1, 1, &a, &b, &c);
+}
 #include <cstdio>
 #include <cstdlib>
 #include <thread>

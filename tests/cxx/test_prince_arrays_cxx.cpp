@@ -218,6 +218,7 @@ int main(int argc, char **argv) {
 		++layer;
 	};
 	setAsynchronous(async);                         // the gates only enqueue; get() + x2z() and the end of the timing synchronise
+	traceMark();
 	const auto t0 = clk::now();
 	M.linear(whitenIn);
 	for (int i = 1; i <= 5; ++i) { M.sboxLayer(false); check(); M.linear(fwdRound[i]); }
@@ -228,6 +229,7 @@ int main(int argc, char **argv) {
 	M.linear(whitenOut);
 	if (cuhe_hip_stream_sync(0, NULL) != 0) { printf("stream sync failed\n"); return 2; }
 	const double encSeconds = std::chrono::duration<double>(clk::now() - t0).count() - paused;
+	traceMark();
 	bool constant; const u64x got = M.decryptState(constant);
 	const u64x want = plainPrince(pt, key0, key1, NULL);
 	const bool ok = constant && got == want && want == 0x9fb51935fc3df524ULL && M.level() == 24;

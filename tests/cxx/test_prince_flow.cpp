@@ -290,6 +290,7 @@ int main(int argc, char **argv) {
 	}
 	setAsynchronous(async);
 	if (scheduledGates) setScheduled(true, schedWorkers);
+	traceMark();
 	const auto t2 = clk::now();
 	printf("encrypted 192 bits in %.2f s\n", std::chrono::duration<double>(t2 - t1).count());
 
@@ -298,6 +299,7 @@ int main(int argc, char **argv) {
 	const auto t2b = clk::now();
 	synchronize();                                          // (scheduled gates: everything recorded has run)
 	const auto t3 = clk::now();
+	traceMark();
 	if (profile) { sample_profiler::stop(); sample_profiler::report(stdout); }
 	if (isScheduled()) printf("the client thread recorded the circuit in %.3f s\n", std::chrono::duration<double>(t2b - t2).count() - ev.paused);
 	const double encSeconds = std::chrono::duration<double>(t3 - t2).count() - ev.paused;

@@ -8,6 +8,9 @@
 //    copies the clock, a stream wait joins it -- so "the producer's work precedes the consumer's work on the GPU" is checked
 //    through exactly the lazily recorded per-stream events the scheduler relies on, across streams and across devices;
 //  * batches: members share kind, key and device, never exceed the cap, and every gate runs exactly once;
+//  * BLOCKS: gates take device blocks inside tasks (taskAlloc), every gate that touches the polynomial uses its block on its stream,
+//    release-only tasks (sched::kReleaseOnly: they wait for nothing and enqueue nothing) hand the blocks back (taskFree) -- whoever
+//    gets such a block next must be ordered, on the device, behind EVERY use it had, whichever streams those ran on;
 //  * a task runs on a stream of ITS device, workers are per device, drain / wait / waitNode / stop / restart work, nothing leaks
 //    (every Task and Node is deleted: counted through the references the test holds).
 // Built and run by tests/test_scheduler_logic.py (plain g++, also under -fsanitize=thread when the toolchain has it).
@@ -84,6 +87,7 @@ using namespace cuHE;
 namespace {
 struct Gate {
 	int id, dev, kind; long key;
+	int w = -1; std::vector<int> rd; bool allocs = false;      // block model: the node written, the nodes read, "takes a block for w if it has none"
 	std::vector<int> mustFollow;                       // gate ids, from the test's own model of the dependency rule
 	std::atomic<int> runs{0};
 	mock::Clock stamp; int stream = -1;
@@ -93,6 +97,12 @@ std::mutex gm;
 std::atomic<long> failures{0}, batchesSeen{0}, batchedGates{0};
 std::atomic<int> maxBatchSeen{0};
 void fail(const char *what, int a = 0, int b = 0) { ++failures; fprintf(stderr, "FAIL: %s (%d, %d)\n", what, a, b); }
+// block model (program(..., blocks = true)): the block a node holds (touched by the node's gates only, which the scheduler orders on the host),
+// and every use a block has had since it was handed out: (stream id, launch number on that stream)
+bool blocksOn = false;
+std::vector<void *> blk;
+std::map<void *, std::vector<std::pair<int, long>>> uses;
+std::atomic<long> blocksTaken{0}, blocksReused{0}, blocksReleased{0};
 
 void runGate(Gate *g, void *stream) {
 	if (mock::deviceOf(stream) != g->dev) fail("gate ran on a stream of another device", g->id, mock::deviceOf(stream));
@@ -102,7 +112,23 @@ void runGate(Gate *g, void *stream) {
 		Gate *p = gates[d];
 		if (p->runs.load() != 1) { fail("dependency not issued before its consumer", g->id, d); continue; }
 	}
+	void *took = nullptr;
+	if (blocksOn && g->allocs && !blk[g->w]) { took = sched::taskAlloc(g->dev, 4096); if (!took) fail("taskAlloc returned nothing", g->id); }      // (its waits precede the launch)
 	const mock::Clock now = mock::launch(stream);
+	if (blocksOn) {
+		std::lock_guard<std::mutex> lk(gm);
+		const int sid = mock::idOf(stream);
+		if (took) {
+			++blocksTaken;
+			auto &u = uses[took];
+			if (!u.empty()) ++blocksReused;
+			for (auto &e : u) { auto it = now.find(e.first); if ((it == now.end() ? 0 : it->second) < e.second) fail("a block was handed out before one of its uses is ordered behind", g->id, e.first); }
+			u.clear();
+			blk[g->w] = took;
+		}
+		if (blk[g->w]) uses[blk[g->w]].push_back({sid, now.at(sid)});
+		for (int r : g->rd) if (r != g->w && blk[r]) uses[blk[r]].push_back({sid, now.at(sid)});
+	}
 	{
 		std::lock_guard<std::mutex> lk(gm);
 		for (int d : g->mustFollow) {
@@ -115,6 +141,15 @@ void runGate(Gate *g, void *stream) {
 		}
 		g->stamp = now; g->stream = mock::idOf(stream);
 	}
+	if (g->runs.fetch_add(1) != 0) fail("gate ran twice", g->id);
+}
+// a release-only gate: no launch, the node's block goes back
+void runRelease(Gate *g, void *stream) {
+	if (mock::deviceOf(stream) != g->dev) fail("release ran on a stream of another device", g->id);
+	for (int d : g->mustFollow) if (gates[d]->runs.load() != 1) fail("dependency not issued before the release", g->id, d);
+	void *p;
+	{ std::lock_guard<std::mutex> lk(gm); p = blk[g->w]; blk[g->w] = nullptr; }
+	if (p) { ++blocksReleased; if (!sched::taskFree(g->dev, p)) fail("taskFree refused a block taskAlloc handed out", g->id); }
 	if (g->runs.fetch_add(1) != 0) fail("gate ran twice", g->id);
 }
 // node -> gate of the recorded batchable task, to find the members inside the batch runner
@@ -140,8 +175,9 @@ void batchRunner(int kind, sched::Node *const *subjects, sched::Node *const *, s
 }
 
 // one random program: `nodes` polynomials spread over `ndev` devices, `ngates` gates
-void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int policyNo, int cap) {
+void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int policyNo, int cap, bool blocks = false) {
 	mock::numGpus = ndev;
+	blocksOn = blocks; blk.assign(nodesN, nullptr); uses.clear();
 	setenv("CUHE_SCHED_POLICY", std::to_string(policyNo).c_str(), 1);
 	sched::setBatchRunner(batches ? batchRunner : nullptr, cap);
 	sched::start(3);
@@ -167,6 +203,9 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 		if (rng() % 7 == 0 && !rd.empty()) rd.push_back(rd[0]);          // an operand listed twice
 		const bool isBatchable = rng() % 3 != 0;
 		g->kind = isBatchable ? 1 + (int)(rng() % 3) : 0;
+		const bool release = blocks && rng() % 5 == 0;                    // the polynomial is reset: a release-only task
+		if (release) { rd.clear(); g->kind = sched::kReleaseOnly; }
+		g->w = w; g->rd = rd; g->allocs = blocks && rng() % 2 == 0;
 		g->key = (long)(rng() % 2);
 		// the dependency rule, restated: after the last writer of everything touched, and after every reader since of what is written
 		std::set<int> mf;
@@ -179,18 +218,19 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 		gates[t] = g;
 		std::vector<sched::Node *> reads, writes(1, nodes[w]);
 		for (int r : rd) reads.push_back(nodes[r]);
-		if (g->kind) { std::lock_guard<std::mutex> lk(gm); pendingBySubject[nodes[w]].push_back(g); }
+		if (g->kind > 0) { std::lock_guard<std::mutex> lk(gm); pendingBySubject[nodes[w]].push_back(g); }
 		const bool keep = rng() % 50 == 0;
 		sched::Task *task = sched::submit(g->dev, reads, writes, [g](void *s) {
+			if (g->kind == sched::kReleaseOnly) { runRelease(g, s); return; }
 			if (g->kind) {                                   // ran alone although batchable: take it off its subject's list
 				std::lock_guard<std::mutex> lk(gm);
 				for (auto &kv : pendingBySubject) { auto &v = kv.second; for (size_t i = 0; i < v.size(); ++i) if (v[i] == g) { v.erase(v.begin() + i); goto done; } }
 				done:;
 			}
 			runGate(g, s);
-		}, keep, g->kind, g->key, g->kind ? nodes[w] : nullptr, nullptr, nullptr);
+		}, keep, g->kind, g->key, g->kind > 0 ? nodes[w] : nullptr, nullptr, nullptr);
 		if (keep) kept.push_back(task);
-		if (rng() % 40 == 0) nodeDev[w] = (int)(rng() % ndev);          // the node "moved"
+		if (!blocks && rng() % 40 == 0) nodeDev[w] = (int)(rng() % ndev);          // the node "moved" (not in the block model: a block stays with its device's cache)
 		if (rng() % 97 == 0) sched::waitNode(nodes[w]);
 	}
 	for (sched::Task *k : kept) sched::wait(k);
@@ -198,8 +238,10 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 	for (Gate *g : gates) if (g->runs.load() != 1) fail("gate did not run exactly once", g->id, g->runs.load());
 	if (sched::stats().tasks != ngates) fail("task count", (int)sched::stats().tasks, ngates);
 	for (sched::Node *n : nodes) sched::releaseNode(n);
+	for (void *&p : blk) if (p) { sched::forgetBlock(p); free(p); p = nullptr; }      // blocks the nodes still hold
 	sched::stop();
 	if (sched::on() || sched::threads() != 0) fail("stop() left workers behind");
+	blocksOn = false;
 }
 }  // namespace
 
@@ -313,7 +355,14 @@ int main(int argc, char **argv) {
 					if (batches && batchesSeen.load() == b0) fail("no batch was formed", ndev, pol);
 					if (!batches && batchesSeen.load() != b0) fail("the batch runner ran although it was switched off");
 					++programs;
+					if (ndev <= 2) {          // the same program with device blocks taken, used and released inside the tasks
+						program(ndev, 40 + 10 * ndev, 3000, 7000u * round + 100u * ndev + 10u * pol + batches, batches != 0, pol, batches ? 64 : 1, true);
+						++programs;
+					}
 				}
+	if (blocksTaken.load() < 1000 || blocksReused.load() * 4 < blocksTaken.load() || blocksReleased.load() * 2 < blocksTaken.load())
+		fail("the block model did not exercise reuse", (int)blocksTaken.load(), (int)blocksReused.load());
+	printf("blocks: %ld taken inside tasks, %ld of them had been used before, %ld released by release-only tasks\n", blocksTaken.load(), blocksReused.load(), blocksReleased.load());
 	if (maxBatchSeen.load() > 128) fail("batch above the cap", maxBatchSeen.load());
 	printf("%ld programs, %ld batches of %ld gates (largest %d), %ld event records, %ld stream waits, %ld mock streams\n", programs, batchesSeen.load(), batchedGates.load(),
 	       maxBatchSeen.load(), mock::eventRecords.load(), mock::streamWaits.load(), (long)mock::streams.size());

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd (sqlite) result: per-kernel call count / total / average
 duration (the `--kernel-trace --stats` table) and, if present, per-dispatch PMC averages.
-usage: rocpd_summary.py results.db [more.db ...]"""
+usage: rocpd_summary.py results.db [more.db ...]
+       rocpd_summary.py --between MARKER results.db     per-kernel table of every stretch of dispatches enclosed by two runs of the
+                                                        kernel MARKER (the clients' CUHE_TRACE_MARK=1: k_probe_valu around the timed part)"""
 import sqlite3
 import sys
 
@@ -39,5 +41,43 @@ def main(paths):
                 print("%-110s %-14s n=%-5d avg=%14.1f sum=%16.1f" % (short(r[0]), r[1], r[2], r[3], r[4]))
 
 
+def between(marker, path, top=40):
+    db = sqlite3.connect(path)
+    rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s"
+                      " on d.kernel_id = s.id order by d.start").fetchall()
+    windows, cur, seen_marker = [], None, False
+    for name, st, en in rows:
+        if marker in name:
+            if cur:
+                windows.append(cur)
+            cur, seen_marker = None, True
+        elif seen_marker:
+            cur = cur or []
+            cur.append((name, st, en))
+    print("== %s: %d stretches enclosed by '%s'" % (path, len(windows), marker))     # (what follows the last marker is not enclosed)
+    for wi, w in enumerate(windows):
+        span = max(e for _, _, e in w) - min(s for _, s, _ in w)
+        # time with at least one kernel running (union of the intervals) and the sum of the durations (> union where streams overlap)
+        busy, last = 0, 0
+        for _, st, en in sorted(w, key=lambda x: x[1]):
+            if en > last:
+                busy += en - max(st, last)
+                last = en
+        agg = {}
+        for name, st, en in w:
+            a = agg.setdefault(short(name), [0, 0])
+            a[0] += 1
+            a[1] += en - st
+        tot = sum(a[1] for a in agg.values())
+        print("-- stretch %d: %d dispatches, first start to last end %.3f ms, some kernel running %.3f ms, sum of durations %.3f ms"
+              % (wi, len(w), span / 1e6, busy / 1e6, tot / 1e6))
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+            print("%-110s %6d %12d %10.0f %6.2f" % (name, a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if len(sys.argv) > 3 and sys.argv[1] == "--between":
+        for p in sys.argv[3:]:
+            between(sys.argv[2], p)
+    else:
+        main(sys.argv[1:])
