@@ -261,6 +261,11 @@ int init_device(int dev) {
     // ---- transforms + scratch (initNtt: cuhe/Operations.cu:173-184)
     CHK(ensure_ntt(dev, L, pnum));
     if (G_.nc) CHK(ensure_twist(dev, n));
+    // the tables of the one-workgroup forms of every sub-transform size this parameter set can reach (rows of nttLen points, their halves,
+    // the half-length transforms of the folded reductions and of the key-switch windows): here, like the reference's initNtt, not inside the
+    // first gate that needs them -- a homomorphic PRINCE block lost 6 ms to three such first uses (profiles/r05_prince_gaps.txt)
+    for (int lgh = 12; lgh <= 15 && (1 << lgh) <= L; ++lgh) CHK(ensure_onewg(D.ow[lgh - 12], lgh));
+    if (G_.nc && n == 65536) CHK(ensure_onewg_twist(D.ow[3], 15));
     if (q.ncOnly()) {                    // no cyclic representation, hence no Barrett tables (the ring has x^n + 1 only)
         HIPCHK(hipDeviceSynchronize());
         D.ready = true;

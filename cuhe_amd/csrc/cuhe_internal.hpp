@@ -251,6 +251,8 @@ int launch_icrt_mfma(u32 *dst, const u32 *src, const DevCtx &D, const IcrtLevel 
 // ---- transforms (cuhe_transforms.hip)
 int ensure_ntt(int dev, int len, int batch_hint);
 int ensure_twist(int dev, int len);
+int ensure_onewg(OwTab &tab, int lgh);            // tables of the one-workgroup transforms of 2^lgh points (the current device); made at init
+int ensure_onewg_twist(OwTab &tab, int lgh);
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
             int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr, int np_mod = 0,
             const Epilogue *ep = nullptr);

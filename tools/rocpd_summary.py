@@ -73,6 +73,33 @@ def between(marker, path, top=40):
               % (wi, len(w), span / 1e6, busy / 1e6, tot / 1e6))
         for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
             print("%-110s %6d %12d %10.0f %6.2f" % (name, a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot))
+        # where the device sat idle: gaps between the end of everything running and the next start, by size and by the kernel that follows
+        gaps, last, prev = [], None, None
+        for name, st, en in sorted(w, key=lambda x: x[1]):
+            if last is not None and st > last:
+                gaps.append((st - last, short(prev)[:48], short(name)[:48]))
+            if last is None or en > last:
+                last, prev = en, name
+        if gaps:
+            edges = [2e3, 5e3, 10e3, 20e3, 50e3, 100e3, 1e9]
+            hist = [[0, 0] for _ in edges]
+            for g in gaps:
+                for i, e in enumerate(edges):
+                    if g[0] <= e:
+                        hist[i][0] += 1
+                        hist[i][1] += g[0]
+                        break
+            print("   idle gaps: %d, %.3f ms in total; by size (us): %s" % (len(gaps), sum(g[0] for g in gaps) / 1e6, "  ".join(
+                "<=%g: %d (%.2f ms)" % (e / 1e3, h[0], h[1] / 1e6) for e, h in zip(edges, hist) if h[0])))
+            by_next = {}
+            for g in gaps:
+                a = by_next.setdefault(g[2], [0, 0])
+                a[0] += 1
+                a[1] += g[0]
+            for name, a in sorted(by_next.items(), key=lambda kv: -kv[1][1])[:12]:
+                print("   idle before %-50s %5d gaps %9.3f ms  (%.1f us each)" % (name, a[0], a[1] / 1e6, a[1] / a[0] / 1e3))
+            for g in sorted(gaps, reverse=True)[:8]:
+                print("   gap %8.1f us  after %-48s before %s" % (g[0] / 1e3, g[1], g[2]))
 
 
 if __name__ == "__main__":

@@ -39,9 +39,21 @@ na = torch.randint(0, 1 << 62, (B * npn, L), dtype=torch.int64, device=dev, gene
 nb = torch.randint(0, 1 << 62, (B * npn, L), dtype=torch.int64, device=dev, generator=gen)
 out = torch.empty((B * npn, q.crtLen), dtype=torch.int32, device=dev)
 import time
+
+
+def mark():            # CUHE_TRACE_MARK=1: the library's probe kernel around the timed calls (tools/rocpd_summary.py --between k_probe_valu)
+    if os.environ.get("CUHE_TRACE_MARK"):
+        x = [C.c_double() for _ in range(3)]
+        torch.cuda.synchronize()
+        ck(lib.cuhe_hip_probe_valu(0, 1, 1, C.byref(x[0]), C.byref(x[1]), C.byref(x[2])))
+
+
 for i in range(calls + 2):
     if i == 2:
+        mark()
         torch.cuda.synchronize(); t0 = time.perf_counter()
     ck(lib.cuhe_hip_mul_relin_batch(out.data_ptr(), na.data_ptr(), nb.data_ptr(), 0, B, 0, None))
 torch.cuda.synchronize()
-print("batch %d ring %s: %.4f ms per ciphertext" % (B, ring, (time.perf_counter() - t0) / calls / B * 1e3))
+dt = time.perf_counter() - t0
+mark()
+print("batch %d ring %s: %.4f ms per ciphertext" % (B, ring, dt / calls / B * 1e3))
