@@ -125,6 +125,9 @@ SIGNATURES = {
     "cuhe_hip_copy_list": (i32, [vp, vp, i32, sz, i32, vp]),
     "cuhe_hip_intt_batch": (i32, [vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_gather_blocks": (i32, [vp, vp, i32, sz, i32, vp]),
+    "cuhe_hip_ct_ntt_list": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "cuhe_hip_ct_intt_list": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "cuhe_hip_set_row_lists": (i32, [i32]),
     "cuhe_hip_scatter_blocks": (i32, [vp, vp, i32, sz, i32, vp]),
     "cuhe_hip_ntt_mul_pairs": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "cuhe_hip_crt_combine": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),

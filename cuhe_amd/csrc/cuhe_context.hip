@@ -145,7 +145,7 @@ int ws_slab(Workspace &w, int li, int which, size_t bytes, u64 **out) {        /
 void free_workspace(Workspace *w) {
     for (auto &per_len : w->slab) for (auto &sl : per_len) if (sl) hipFree(sl);
     void *ptrs[] = {w->b_ntt, w->b_mq, w->b_crt, w->hold, w->b_alias, w->relin, w->win, w->bt_ntt, w->bt_crt, w->mr_ntt, w->mr_crt,
-                    w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out, w->pair_cnt, w->rc_acc};
+                    w->sh_a, w->sh_b, w->sh_rows, w->sh_raw, w->sh_out, w->pair_cnt, w->rc_acc, w->ls_crt, w->ls_ntt};
     for (void *p : ptrs) if (p) hipFree(p);
     if (w->ev) hipEventDestroy(w->ev);
     if (w->ev_lane) hipEventDestroy(w->ev_lane);

@@ -81,6 +81,8 @@ struct Workspace {
     // lanes of the batched relinearisation (relin_batch_core): a helper lane owns a stream; lane 0 marks "inputs ready"
     hipStream_t lane_stream = nullptr; hipEvent_t ev_lane = nullptr, ev_in = nullptr;
     u64 *rc_acc = nullptr;               // the sums of the single-ciphertext relinearisation chain (cuhe_hip_relin_crt)
+    // gathered rows of the list transforms (cuhe_hip_ct_ntt_list / cuhe_hip_ct_intt_list) when a call does not take a one-workgroup kernel
+    u32 *ls_crt = nullptr; u64 *ls_ntt = nullptr; size_t n_ls_crt = 0, n_ls_ntt = 0;
 };
 struct IcrtLevel {
     u32 *M = nullptr, *mi = nullptr, *bi = nullptr; double *rp = nullptr; int W = 0, np = 0;
@@ -255,12 +257,15 @@ int ensure_onewg(OwTab &tab, int lgh);            // tables of the one-workgroup
 int ensure_onewg_twist(OwTab &tab, int lgh);
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
             int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm = nullptr, const u64 *mul_tab = nullptr, int np_mod = 0,
-            const Epilogue *ep = nullptr);
+            const Epilogue *ep = nullptr, const RowRebase *rb = nullptr);
+// (internal) returned by the transforms when rows in separate blocks (RowRebase) were asked for and the call would not take a one-workgroup
+// kernel: nothing has been enqueued, the caller gathers the rows and calls again without
+constexpr int kNoListForm = -1000;
 int barrett_impl(u32 *dst, const u32 *src, int prime0, int np, int dev, hipStream_t st, int np_mod);
 inline int ct_len() { return G_.nc ? G_.prm.modLen : G_.prm.nttLen; }
 int need_cyclic();
-int ct_forward(u64 *X, const u32 *x, int rows, int dev, hipStream_t st, const u64 *mul_tab = nullptr, int np_mod = 0);
+int ct_forward(u64 *X, const u32 *x, int rows, int dev, hipStream_t st, const u64 *mul_tab = nullptr, int np_mod = 0, const RowRebase *rb = nullptr);
 bool fused_xn1();
-int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st, const u64 *Y = nullptr);
+int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st, const u64 *Y = nullptr, const RowRebase *rb = nullptr);
 
 }  // namespace cuhe_impl

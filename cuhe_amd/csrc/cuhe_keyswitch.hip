@@ -766,6 +766,96 @@ int cuhe_hip_intt_batch(uint32_t *dst, const uint64_t *src, int lvl, int batch, 
     const int np = lvl < 0 ? 1 : q.numCrtPrimeAt(lvl);
     return ct_inverse(dst, (const u64 *)src, batch * np, 0, np, false, dev, S(st_));
 }
+// ---- transforms of ciphertexts that live in SEPARATE blocks (the members of a batch of scheduled gates, cuhe_amd/cxx/CuHE.cpp runBatch): the
+// one-workgroup kernels address row r of block c = r / np through RowRebase (ntt_kernels.cuh), kRowBlocksMax blocks per launch -- no gather before,
+// no scatter after.  A call that would not take such a kernel (few rows: the two-pass pair; rows of 64K points: the persistent forms) gathers
+// into / scatters from a scratch array of the calling thread's workspace instead: same results, the traffic of round 4.
+static int fill_rebase(RowRebase &R, int per, const void *const *src, long src_block_bytes, void *const *dst, long dst_block_bytes, int c0, int n) {
+    R.per = per;
+    for (int i = 0; i < kRowBlocksMax; ++i) { R.src_adj[i] = 0; R.dst_adj[i] = 0; }
+    for (int i = 0; i < n; ++i) {
+        if (src) {
+            if (!src[c0 + i] || ((uintptr_t)src[c0 + i] & 15)) return fail(CUHE_EINVAL, "source block %d is null or not 16-byte aligned", c0 + i);
+            R.src_adj[i] = (long)((const char *)src[c0 + i] - (const char *)src[c0]) - (long)i * src_block_bytes;
+        }
+        if (dst) {
+            if (!dst[c0 + i] || ((uintptr_t)dst[c0 + i] & 15)) return fail(CUHE_EINVAL, "destination block %d is null or not 16-byte aligned", c0 + i);
+            R.dst_adj[i] = (long)((char *)dst[c0 + i] - (char *)dst[c0]) - (long)i * dst_block_bytes;
+        }
+    }
+    return CUHE_OK;
+}
+static int g_row_lists = getenv("CUHE_ROW_LISTS") ? atoi(getenv("CUHE_ROW_LISTS")) : 1;      // 0: always gather / scatter (A/B runs, tests)
+int cuhe_hip_set_row_lists(int on) {
+    if (on != 0 && on != 1) return fail(CUHE_EINVAL, "on %d", on);
+    g_row_lists = on;
+    return CUHE_OK;
+}
+// c2n of `count` ciphertexts of level lvl: dst[i] u64[np][ct_len] = transform of src[i] u32[np][crtLen]; returns in *direct (may be null) how many
+// ciphertexts went through the kernels' own block addressing
+int cuhe_hip_ct_ntt_list(uint64_t *const *dst, const uint32_t *const *src, int count, int lvl, int dev, void *st_, int *direct) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (count < 1 || !dst || !src) return fail(CUHE_EINVAL, "count %d", count);
+    hipStream_t st = S(st_);
+    const int np = q.numCrtPrimeAt(lvl), L = ct_len();
+    const long cB = (long)np * q.crtLen * sizeof(u32), nB = (long)np * L * sizeof(u64);
+    int done_direct = 0;
+    for (int c0 = 0; c0 < count; c0 += kRowBlocksMax) {
+        const int n = std::min(kRowBlocksMax, count - c0);
+        RowRebase R;
+        CHK(fill_rebase(R, np, (const void *const *)src, cB, (void *const *)dst, nB, c0, n));
+        const int r = g_row_lists ? ct_forward((u64 *)dst[c0], src[c0], n * np, dev, st, nullptr, 0, &R) : kNoListForm;
+        if (r == kNoListForm) {                 // everything that is left as ONE array call (more rows per launch than chunk by chunk)
+            const int m = count - c0;
+            Workspace *W = nullptr;
+            CHK(workspace(dev, st, &W));
+            CHK(ws_grow(&W->ls_crt, &W->n_ls_crt, (size_t)m * np * q.crtLen));
+            CHK(ws_grow(&W->ls_ntt, &W->n_ls_ntt, (size_t)m * np * L));
+            CHK(move_blocks(true, W->ls_crt, (void *const *)(src + c0), m, (size_t)cB, dev, st_));
+            CHK(ct_forward(W->ls_ntt, W->ls_crt, m * np, dev, st));
+            CHK(move_blocks(false, W->ls_ntt, (void *const *)(dst + c0), m, (size_t)nB, dev, st_));
+            break;
+        }
+        CHK(r);
+        done_direct += n;
+    }
+    if (direct) *direct = done_direct;
+    return CUHE_OK;
+}
+// n2c of `count` ciphertexts of level lvl into ONE array: dst u32[count][np][crtLen] = inverse transform (products: + reduction modulo the
+// polynomial modulus) of the blocks src[i] u64[np][ct_len]
+int cuhe_hip_ct_intt_list(uint32_t *dst, const uint64_t *const *src, int count, int lvl, int is_prod, int dev, void *st_, int *direct) {
+    CHK(need_init(dev));
+    const Params &q = G_.prm;
+    if (lvl < 0 || lvl >= q.depth) return fail(CUHE_EINVAL, "level %d", lvl);
+    if (count < 1 || !dst || !src) return fail(CUHE_EINVAL, "count %d", count);
+    hipStream_t st = S(st_);
+    const int np = q.numCrtPrimeAt(lvl), L = ct_len();
+    const long nB = (long)np * L * sizeof(u64);
+    int done_direct = 0;
+    for (int c0 = 0; c0 < count; c0 += kRowBlocksMax) {
+        const int n = std::min(kRowBlocksMax, count - c0);
+        u32 *out = dst + (size_t)c0 * np * q.crtLen;
+        RowRebase R;
+        CHK(fill_rebase(R, np, (const void *const *)src, nB, nullptr, 0, c0, n));
+        const int r = g_row_lists ? ct_inverse(out, (const u64 *)src[c0], n * np, 0, np, is_prod != 0, dev, st, nullptr, &R) : kNoListForm;
+        if (r == kNoListForm) {
+            const int m = count - c0;
+            Workspace *W = nullptr;
+            CHK(workspace(dev, st, &W));
+            CHK(ws_grow(&W->ls_ntt, &W->n_ls_ntt, (size_t)m * np * L));
+            CHK(move_blocks(true, W->ls_ntt, (void *const *)(src + c0), m, (size_t)nB, dev, st_));
+            CHK(ct_inverse(out, W->ls_ntt, m * np, 0, np, is_prod != 0, dev, st));
+            break;
+        }
+        CHK(r);
+        done_direct += n;
+    }
+    if (direct) *direct = done_direct;
+    return CUHE_OK;
+}
 int cuhe_hip_gather_blocks(void *dst, const void *const *srcs, int count, size_t bytes, int dev, void *st) {
     return move_blocks(true, dst, (void *const *)srcs, count, bytes, dev, st);
 }

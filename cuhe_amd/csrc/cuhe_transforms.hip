@@ -206,7 +206,7 @@ static int ws_pair_counters(Workspace &W) {
 template <int LG>
 int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
                int prime0, WindowArgs wa, DevCtx &D, Workspace &W, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod,
-               const Epilogue *ep) {
+               const Epilogue *ep, const RowRebase *rb) {
     constexpr int L = 1 << LG;
     NttTab &tab = D.ntt[LG - 13];
     const int chunk = tab.chunk;
@@ -233,11 +233,11 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
         // profiles/r03_perf_ntt_table.txt.  From 10 halves per workgroup on, so that time per transform never rises with the batch.)
         const long stream_min = G_.onewg == 2 ? 2L * gridp : 20L * gridp;
         const bool stream_ok = half && mode == kSrcU32Ext && gridp >= 16 && gridp / 2 <= kOwPairCounters && wgs >= stream_min &&
-                               ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0;
+                               ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0 && !rb;      // (rows in separate blocks: ntt_onewg only)
         const bool rows64_onewg = G_.onewg64 == 1 || (G_.onewg64 >= 2 && stream_ok);
         // negacyclic forward transform of full 64K-point rows (the ciphertext domain of x^65536 + 1): the persistent form, two
         // 32K-point halves per row meeting before their interleaved stores, from two halves per workgroup on (or forced)
-        if (LG == 16 && mode == kSrcU32Twist && !mul_tab && G_.onewg && G_.onewg64 >= 2 && grid64 >= 16 &&
+        if (LG == 16 && mode == kSrcU32Twist && !mul_tab && !rb && G_.onewg && G_.onewg64 >= 2 && grid64 >= 16 &&
             (G_.onewg == 2 || 2L * batch >= 2L * grid64) && ((uintptr_t)src & 15) == 0 && (src_stride & 3) == 0) {
             OwTab &ot = D.ow[3];
             CHK(ensure_onewg_twist(ot, 15));
@@ -270,6 +270,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 if (out == kOutModPNc && !xt) return fail(CUHE_EINVAL, "negacyclic untwist table missing");
                 OwArgs a{dst, src, mode == kSrcU32Twist ? ot.TW1g : ot.TW1hi, ot.TW2, src_stride, dst_stride, batch, L, wa, mode == kSrcU64NegMul ? mul_tab : nullptr,
                          D.p, D.pinv, prime0, np_mod, nullptr, 0, FoldGeom{0, 0, 0, 0, 0}, xt, ot.c128, ot.i4neg};
+                a.rb = rb;
                 if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 note_dispatch("split row: one workgroup per half-length sub-transform", L, batch);
                 CHK(onewg_launch(LG - 1, mode, out, true, a, st));
@@ -295,6 +296,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
                 const bool inv = out_is_inverse(out);
                 OwArgs a{dst, src, half ? ot.TW1h : inv ? ot.TW1i : ot.TW1f, ot.TW2, mode == kSrcWindow ? 0 : src_stride, dst_stride, batch, nst, wa, tw,
                          D.p, D.pinv, prime0, np_mod, e.aux, e.aux_stride, e.fg, xt};
+                a.rb = rb;
                 if (tm && tm->on) for (int i = 0; i < 2; ++i) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, st); tm->ev.push_back(ev); }
                 // resident workgroups walk over their share of the halves, the next half's samples arriving by LDS-DMA beside stage 3
                 // of the current one, the two halves of a row meeting before their interleaved stores
@@ -311,6 +313,7 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
             }
         }
     }
+    if (rb) return kNoListForm;          // rows in separate blocks exist in the one-workgroup kernels only: the caller gathers them
     if constexpr (LG == 13) {
         return fail(CUHE_EINVAL, "8192-point transforms exist in the one-workgroup form only (source %d, %s)", mode, ep && ep->kind ? "folded-reduction store" : "plain store");
     } else {
@@ -378,17 +381,17 @@ int run_ntt_lg(int mode, void *dst, const void *src, int batch, long src_stride,
 }
 
 int run_ntt(int len, int mode, void *dst, const void *src, int batch, long src_stride, long dst_stride, int nstore,
-            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod, const Epilogue *ep) {
+            int prime0, WindowArgs wa, int dev, hipStream_t st, EvTimer *tm, const u64 *mul_tab, int np_mod, const Epilogue *ep, const RowRebase *rb) {
     if (batch <= 0) return CUHE_OK;
     CHK(ensure_ntt(dev, len, batch));
     DevCtx &D = G_.dev[dev];
     Workspace *W = nullptr;
     CHK(workspace(dev, st, &W));
     switch (len) {
-        case 8192:  return run_ntt_lg<13>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
-        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
-        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
-        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep);
+        case 8192:  return run_ntt_lg<13>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep, rb);
+        case 16384: return run_ntt_lg<14>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep, rb);
+        case 32768: return run_ntt_lg<15>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep, rb);
+        default:    return run_ntt_lg<16>(mode, dst, src, batch, src_stride, dst_stride, nstore, prime0, wa, D, *W, st, tm, mul_tab, np_mod, ep, rb);
     }
 }
 
@@ -475,10 +478,10 @@ int need_cyclic() {
     return CUHE_OK;
 }
 // CRT rows u32[rows][crtLen] -> ct rows u64[rows][ct_len]; mul_tab: rows the outputs are multiplied by on the way out
-int ct_forward(u64 *X, const u32 *x, int rows, int dev, hipStream_t st, const u64 *mul_tab, int np_mod) {
+int ct_forward(u64 *X, const u32 *x, int rows, int dev, hipStream_t st, const u64 *mul_tab, int np_mod, const RowRebase *rb) {
     const Params &q = G_.prm;
-    if (G_.nc) return run_ntt(q.modLen, kSrcU32Twist, X, x, rows, q.crtLen, q.modLen, q.modLen, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, mul_tab, np_mod);
-    return run_ntt(q.nttLen, kSrcU32Ext, X, x, rows, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, mul_tab, np_mod);
+    if (G_.nc) return run_ntt(q.modLen, kSrcU32Twist, X, x, rows, q.crtLen, q.modLen, q.modLen, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, mul_tab, np_mod, nullptr, rb);
+    return run_ntt(q.nttLen, kSrcU32Ext, X, x, rows, q.crtLen, q.nttLen, q.nttLen, 0, WindowArgs{0, 0, 0}, dev, st, nullptr, mul_tab, np_mod, nullptr, rb);
 }
 // Phi_m = x^n + 1 with n = L/2 on the cyclic representation: INTT, mod p_i and the reduction in one pass-2 epilogue
 bool fused_xn1() {
@@ -487,18 +490,21 @@ bool fused_xn1() {
 // ct rows -> CRT rows u32[rows][crtLen]; row r is reduced modulo prime prime0 + r (row r mod np_mod when np_mod > 0, prime0
 // = 0 then); is_prod: the rows are products of two reduced polynomials (cyclic representation: reduce modulo Phi_m)
 // Y != null: the rows are the pointwise products X * Y, multiplied as pass 1 loads them (kSrcU64NegMul)
-int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st, const u64 *Y) {
+// rb != null (Y == null): the rows X are read from separate blocks (RowRebase::src_adj; dst_adj all zero: dst is one array); kNoListForm when the
+// call would not take a one-workgroup kernel -- nothing has been enqueued then
+int ct_inverse(u32 *dst, const u64 *X, int rows, int prime0, int np_mod, bool is_prod, int dev, hipStream_t st, const u64 *Y, const RowRebase *rb) {
     const Params &q = G_.prm;
     const int n = q.modLen, L = q.nttLen, cl = q.crtLen;
     const WindowArgs wa{0, 0, 0};
     const int mode = Y ? kSrcU64NegMul : kSrcU64Neg;
-    if (G_.nc) return run_ntt(n, mode, dst, X, rows, n, cl, kNcInverse, prime0, wa, dev, st, nullptr, Y, np_mod);
-    if (!is_prod) return run_ntt(L, mode, dst, X, rows, L, cl, cl, prime0, wa, dev, st, nullptr, Y, np_mod);
-    if (fused_xn1()) return run_ntt(L, mode, dst, X, rows, L, cl, kFoldXn1, prime0, wa, dev, st, nullptr, Y, np_mod);
+    if (rb && Y) return fail(CUHE_EINVAL, "rows in separate blocks: no second operand");
+    if (G_.nc) return run_ntt(n, mode, dst, X, rows, n, cl, kNcInverse, prime0, wa, dev, st, nullptr, Y, np_mod, nullptr, rb);
+    if (!is_prod) return run_ntt(L, mode, dst, X, rows, L, cl, cl, prime0, wa, dev, st, nullptr, Y, np_mod, nullptr, rb);
+    if (fused_xn1()) return run_ntt(L, mode, dst, X, rows, L, cl, kFoldXn1, prime0, wa, dev, st, nullptr, Y, np_mod, nullptr, rb);
     Workspace *Wp = nullptr;
     CHK(workspace(dev, st, &Wp));
     CHK(ws_barrett(*Wp, rows));
-    CHK(run_ntt(L, mode, Wp->hold, X, rows, L, L, L, prime0, wa, dev, st, nullptr, Y, np_mod));
+    { const int r = run_ntt(L, mode, Wp->hold, X, rows, L, L, L, prime0, wa, dev, st, nullptr, Y, np_mod, nullptr, rb); if (r != CUHE_OK) return r; }
     return barrett_impl(dst, Wp->hold, prime0, rows, dev, st, np_mod);
 }
 

@@ -43,6 +43,11 @@ __device__ __forceinline__ void xcd_map(int tiles, int &batch, int &tile) {
 }
 
 struct WindowArgs { int words, w, wid0; };
+// rows that live in SEPARATE blocks, `per` consecutive rows in each (the ciphertexts of a batch of gates: cuhe_hip_ct_ntt_list /
+// cuhe_hip_ct_intt_list): the kernel keeps addressing row r as base + r * stride, and block c = r / per comes with the byte offset that
+// makes that land in its own block -- adj[c] = (block_c - base) - c * per * stride bytes.  per = 0: one array (every other caller)
+constexpr int kRowBlocksMax = 128;           // (2 KB of kernel arguments; a layer of PRINCE S-boxes offers groups of up to 128 ciphertexts)
+struct RowRebase { int per; long src_adj[kRowBlocksMax]; long dst_adj[kRowBlocksMax]; };
 
 // sample `idx` of transform `batch` as pass 1 sees it, for every source kind (see the enum above)
 template <int LG, int MODE>

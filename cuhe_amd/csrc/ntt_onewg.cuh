@@ -313,7 +313,7 @@ __global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
 void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
                long src_stride, long dst_stride, int nbatch, int nstore, WindowArgs wa, const u64 *__restrict__ tw,
                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
-               const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab, StreamTwistArgs ta) {
+               const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab, StreamTwistArgs ta, RowRebase rb) {
     constexpr int R = (1 << LGH) / 1024;
     using G = OwGeom<R>;
     constexpr int T = G::T, Lh = G::Lh;
@@ -335,6 +335,11 @@ void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64
         batch = (r >> 1) * 8 + (g & 7);
     } else batch = blockIdx.x;
     if (batch >= nbatch) return;
+    if (rb.per > 0) {                                     // rows in separate blocks: the block of this row (uniform in the workgroup)
+        const int c = batch / rb.per;
+        src_ = (const char *)src_ + rb.src_adj[c];
+        dst_ = (char *)dst_ + rb.dst_adj[c];
+    }
     const int t = threadIdx.x;
     tw2[t] = TW2[t];
 

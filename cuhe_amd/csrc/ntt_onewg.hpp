@@ -16,6 +16,7 @@ struct OwArgs {
     const u32 *primes; const u64 *pinv; int prime0, np_mod;
     const u32 *aux; long aux_stride; FoldGeom fg; const u64 *xtab;
     u64 c128 = 0; int i4neg = 0;          // split negacyclic forward rows: psi^T and the sign of psi^Lh = +-2^48 (ntt_onewg.cuh)
+    const RowRebase *rb = nullptr;        // rows in separate blocks (ntt_kernels.cuh); ow_launch_* only, not the persistent forms
 };
 // hipErrorInvalidValue: this (sub-transform size, source, epilogue, half) combination is not instantiated
 hipError_t ow_launch_12(int mode, int out, bool half, const OwArgs &a, hipStream_t st);        // 4K-point halves of the zero-padded 8K-point transform only

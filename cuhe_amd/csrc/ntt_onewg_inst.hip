@@ -15,6 +15,7 @@ namespace cuhe {
 namespace {
 
 constexpr int kLgh = CUHE_OW_LGH;
+const RowRebase kNoRebase{};                          // per = 0: rows of one array
 using Geo = OwGeom<(1 << kLgh) / 1024>;
 
 template <int MODE, int OUT, bool HALF>
@@ -37,7 +38,8 @@ hipError_t launch(const OwArgs &a, hipStream_t st) {
     const int nb8 = (a.nbatch + 7) & ~7;
     const int grid = HALF ? 2 * nb8 : a.nbatch;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
-                       a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab, StreamTwistArgs{a.c128, a.i4neg});
+                       a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab, StreamTwistArgs{a.c128, a.i4neg},
+                       a.rb ? *a.rb : kNoRebase);
     return hipGetLastError();
 }
 

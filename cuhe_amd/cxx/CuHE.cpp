@@ -1013,7 +1013,13 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 	const size_t cRows = (size_t)np * param.crtLen, nRows = (size_t)np * cuhe_hip_ct_len();
 	const size_t cBytes = cRows * sizeof(uint32), nBytes = nRows * sizeof(uint64);
 	const size_t cScratch = (size_t)cls * param.numCrtPrime * param.crtLen * sizeof(uint32), nScratch = (size_t)cls * param.numCrtPrime * cuhe_hip_ct_len() * sizeof(uint64);
+	static const bool listForms = !(getenv("CUHE_SCHED_LISTS") && atoi(getenv("CUHE_SCHED_LISTS")) == 0);     // (A/B: 0 = gather / array call / scatter everywhere)
 	if (kind == kBatchX2N) {                                     // c2n of every ciphertext: one transform call over n * np rows
+		if (listForms) {                                          // ... that reads every ciphertext's CRT block and writes its new NTT block: no gather, no scatter
+			const void *ps[kMaxGateBatch];
+			for (int i = 0; i < n; ++i) { ps[i] = c[i]->cRep_; c[i]->nRepAlloc(st); ptr[i] = c[i]->nRep_; }
+			CSC(cuhe_hip_ct_ntt_list((uint64_t *const *)ptr, (const uint32_t *const *)ps, n, lvl, dev, st, NULL));
+		} else {
 		uint32 *cin = (uint32 *)tlsBatchScratch.get(dev, 0, cScratch, st);
 		uint64 *nout = (uint64 *)tlsBatchScratch.get(dev, 1, nScratch, st);
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
@@ -1021,6 +1027,7 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		CSC(cuhe_hip_ntt_rows(U64P(nout), cin, n * np, dev, st));
 		for (int i = 0; i < n; ++i) { c[i]->nRepAlloc(st); ptr[i] = c[i]->nRep_; }
 		CSC(cuhe_hip_scatter_blocks(ptr, nout, n, nBytes, dev, st));
+		}
 		for (int i = 0; i < n; ++i) {
 			c[i]->dropKeep();
 			if (keepCrtRows()) { c[i]->cKeep_ = c[i]->cRep_; c[i]->cRep_ = NULL; } else c[i]->cRepFree();      // (as c2n does)
@@ -1028,7 +1035,6 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 		}
 		return;
 	}
-	static const bool listForms = !(getenv("CUHE_SCHED_LISTS") && atoi(getenv("CUHE_SCHED_LISTS")) == 0);     // (A/B: 0 = gather / array call / scatter everywhere)
 	if (kind == kBatchModSwitch && !fromNtt && listForms) {      // CRT-domain ciphertexts switch inside their own blocks: no gather, no scatter, no scratch
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;
 		CSC(cuhe_hip_crt_mod_switch_list(ptr, ptr, lvl, n, dev, st));
@@ -1040,11 +1046,14 @@ void SchedAccess::runBatch(int kind, sched::Node *const *subjects, sched::Node *
 	// (kernels that produce CRT rows write the modLen coefficients of the ring: on a ring shorter than the row the rest has to read as zero)
 	if (shortRing() && fromNtt) CSC(cuhe_hip_memset_async(dev, rows, 0, n * cBytes, st));
 	if (fromNtt) {                                               // n2c: inverse transform (+ reduction modulo the polynomial modulus for products)
-		uint64 *nin = (uint64 *)tlsBatchScratch.get(dev, 1, nScratch, st);
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->nRep_;
-		CSC(cuhe_hip_gather_blocks(nin, ptr, n, nBytes, dev, st));
-		if (prod) CSC(cuhe_hip_intt_mod_batch(rows, U64P(nin), lvl, n, dev, st));
-		else CSC(cuhe_hip_intt_batch(rows, U64P(nin), lvl, n, dev, st));
+		if (listForms) CSC(cuhe_hip_ct_intt_list(rows, (const uint64_t *const *)ptr, n, lvl, prod ? 1 : 0, dev, st, NULL));     // (reads the ciphertexts' own NTT blocks)
+		else {
+			uint64 *nin = (uint64 *)tlsBatchScratch.get(dev, 1, nScratch, st);
+			CSC(cuhe_hip_gather_blocks(nin, ptr, n, nBytes, dev, st));
+			if (prod) CSC(cuhe_hip_intt_mod_batch(rows, U64P(nin), lvl, n, dev, st));
+			else CSC(cuhe_hip_intt_batch(rows, U64P(nin), lvl, n, dev, st));
+		}
 		for (int i = 0; i < n; ++i) { c[i]->cRepAlloc(st); c[i]->nRepFree(); c[i]->domain_ = 2; c[i]->isProd_ = false; c[i]->prodTerms_ = 0; }
 	} else {
 		for (int i = 0; i < n; ++i) ptr[i] = c[i]->cRep_;

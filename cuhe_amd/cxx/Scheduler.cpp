@@ -145,11 +145,12 @@ void pruneReaders(Node *n) {               // recMu held
 // the stream of `me` (a worker's own, on device `dev`) waits until task #seq of `from` has finished, unless it has done so already;
 // returns the number of events recorded (0 or 1), *waited: whether a wait was enqueued
 std::atomic<long> waitsSkipped{0}, waitsDone{0};
+int waitDedup = 1, releaseOnlyOn = 1;      // CUHE_SCHED_WAIT_DEDUP / CUHE_SCHED_RELEASE_ONLY = 0: the behaviour before (A/B runs)
 int orderAfter(int dev, StreamState *me, StreamState *from, long seq, bool *waited = nullptr) {
 	std::pair<StreamState *, long> *mine = nullptr;
 	for (auto &w : me->waited) if (w.first == from) { mine = &w; break; }
 	if (waited) *waited = false;
-	if (mine && mine->second >= seq) { waitsSkipped.fetch_add(1, std::memory_order_relaxed); return 0; }
+	if (waitDedup && mine && mine->second >= seq) { waitsSkipped.fetch_add(1, std::memory_order_relaxed); return 0; }
 	std::lock_guard<std::mutex> lk(from->m);
 	int recorded = 0;
 	if (from->covered < seq) {
@@ -348,7 +349,7 @@ void workerMain(DevState *Dp, int me) {
 				for (auto &e : latest) if (e.first == d->ss) { if (d->seq > e.second) e.second = d->seq; found = true; }
 				if (!found) latest.push_back({d->ss, d->seq});
 			}
-		const bool releaseOnly = batch.size() == 1 && batch[0]->kind == kReleaseOnly;
+		const bool releaseOnly = releaseOnlyOn && batch.size() == 1 && batch[0]->kind == kReleaseOnly;
 		ReleaseCtx rel{D.dev, ss, &latest, false, 0, 0};
 		if (releaseOnly) {                      // no wait here: the blocks it releases take the positions of its dependencies (own stream included)
 			for (Task *d : batch[0]->deps) {
@@ -459,6 +460,8 @@ void start(int n) {
 	if (getenv("CUHE_SCHED_POLICY")) policy = atoi(getenv("CUHE_SCHED_POLICY"));
 	if (getenv("CUHE_SCHED_QUIET_US")) quietNs = 1000L * atol(getenv("CUHE_SCHED_QUIET_US"));
 	if (getenv("CUHE_SCHED_BATCH_WORKERS")) batchWorkers = atoi(getenv("CUHE_SCHED_BATCH_WORKERS"));
+	if (getenv("CUHE_SCHED_WAIT_DEDUP")) waitDedup = atoi(getenv("CUHE_SCHED_WAIT_DEDUP"));
+	if (getenv("CUHE_SCHED_RELEASE_ONLY")) releaseOnlyOn = atoi(getenv("CUHE_SCHED_RELEASE_ONLY"));
 	trace = getenv("CUHE_SCHED_TRACE") ? atoi(getenv("CUHE_SCHED_TRACE")) : 0;
 	const int nd = std::max(1, std::min(cuhe_hip_num_gpus(), kMaxDevices));
 	for (int d = 0; d < nd; ++d) ensureWorkers(d);

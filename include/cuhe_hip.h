@@ -259,6 +259,16 @@ int cuhe_hip_crt_mod_switch_batch(uint32_t *dst, const uint32_t *src, int lvl, i
    array; the pointer list is HOST memory and travels as a kernel argument.  What lets the C++ layer's gate scheduler run the
    ready gates of one kind on separately owned ciphertexts as one call of the array entry points above and below. */
 int cuhe_hip_gather_blocks(void *dst, const void *const *srcs, int count, size_t bytes, int dev, void *stream);
+/* The two transforms that touch the ct-sized rows of such separately owned ciphertexts, WITHOUT the gather / scatter: the one-workgroup
+   kernels find row r of ciphertext r / np in that ciphertext's own block (the block offsets travel as a kernel argument, 128 blocks per
+   launch).  ct_ntt_list: c2n of every ciphertext, dst[i] u64[np][ct_len] <- src[i] u32[np][crtLen] (CuCtxt::x2n, cuhe/CuHE.cu:392-411, once
+   per ciphertext there); ct_intt_list: n2c into ONE array dst u32[count][np][crtLen] <- src[i] u64[np][ct_len], is_prod: + the reduction
+   modulo the polynomial modulus (CuHE.cu:412-431).  A call whose row count or length takes another kernel form gathers / scatters through
+   scratch of its own instead (same results); *direct (may be NULL): how many ciphertexts went through the kernels' block addressing.
+   cuhe_hip_set_row_lists(0): always the gather / scatter form (A/B runs; CUHE_ROW_LISTS=0). */
+int cuhe_hip_ct_ntt_list(uint64_t *const *dst, const uint32_t *const *src, int count, int lvl, int dev, void *stream, int *direct);
+int cuhe_hip_ct_intt_list(uint32_t *dst, const uint64_t *const *src, int count, int lvl, int is_prod, int dev, void *stream, int *direct);
+int cuhe_hip_set_row_lists(int on);
 int cuhe_hip_scatter_blocks(void *const *dsts, const void *src, int count, size_t bytes, int dev, void *stream);
 /* elementwise gates over LISTS of separately owned ciphertexts of one level, one launch per 64: ct rows z = x * y (mul != 0) or
    x + y modulo P (cAnd / cXor in the NTT domain), CRT rows z = (a + b) mod p (cXor in the CRT domain); lists in host memory */

@@ -241,6 +241,11 @@ int main() {
 		uint32 *ac = (uint32 *)deviceMalloc(crtBytes), *bc = (uint32 *)deviceMalloc(crtBytes), *rc = (uint32 *)deviceMalloc(crtBytes);
 		uint32 *dbl = (uint32 *)deviceMalloc((size_t)np * param.nttLen * sizeof(uint32));
 		uint64 *an = (uint64 *)deviceMalloc(nttBytes), *bn = (uint64 *)deviceMalloc(nttBytes), *pn = (uint64 *)deviceMalloc(nttBytes);
+		// crt() writes the modLen coefficients of the ring and ntt() reads whole rows of crtLen: the rest of a CRT row has to BE zero, which is why the
+		// reference creates its representations with cudaMalloc + cudaMemset (cuhe/CuHE.cu, *RepCreate) -- and a block that comes back from the pool holds
+		// whatever its last owner left there (with scheduled gates that made this section fail in three runs out of four until the rows were cleared)
+		CSC(cuhe_hip_memset_async(0, ac, 0, crtBytes, 0)); CSC(cuhe_hip_memset_async(0, bc, 0, crtBytes, 0)); CSC(cuhe_hip_memset_async(0, rc, 0, crtBytes, 0));
+		CSC(cuhe_hip_memset_async(0, dbl, 0, (size_t)np * param.nttLen * sizeof(uint32), 0));
 		crt(ac, ca.rRep(), logq, 0); crt(bc, cb.rRep(), logq, 0);
 		ntt(an, ac, logq, 0); ntt(bn, bc, logq, 0);
 		nttMul(pn, an, bn, logq, 0);

@@ -165,11 +165,12 @@ struct Machine {
 
 int main(int argc, char **argv) {
 	bool checkRounds = true, async = false, virt = false, json = false;
-	int ndev = 1;
+	int ndev = 1, repeat = 1;
 	for (int i = 1; i < argc; ++i) {
 		const std::string a = argv[i];
 		if (a == "--no-round-checks") checkRounds = false; else if (a == "--async") async = true; else if (a == "--virtual") virt = true;
 		else if (a == "--json") json = true; else if (a == "--devices" && i + 1 < argc) ndev = atoi(argv[++i]);
+		else if (a == "--repeat" && i + 1 < argc) repeat = atoi(argv[++i]);      // the block N times in one process: from the second on the arrays' device memory is not first-time hipMalloc any more
 	}
 	if (ndev < 1 || ndev > 16) { printf("--devices 1..16\n"); return 2; }
 	const u64x F = ~0ULL, pt = 0, key0 = F, key1 = 0;             // the reference's run (Prince.cu:69-74)
@@ -178,6 +179,7 @@ int main(int argc, char **argv) {
 	Dhs dhs;
 	dhs.setup(25, 2, 16, 25, 25, 21845);
 	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey);
+	for (int pass = 0; pass < (repeat > 1 ? repeat : 1); ++pass) {
 	Machine M(dhs, ndev);
 	std::vector<u64x> expect;
 	plainPrince(pt, key0, key1, &expect);
@@ -237,8 +239,10 @@ int main(int argc, char **argv) {
 	if (!ok) ++failures;
 	printf("Prince Encryption: %.3f s on %d %sGPU%s, CuCtxtArray gates, %s (round checks excluded)\n", encSeconds, ndev, virt ? "virtual " : "", ndev > 1 ? "s" : "",
 	       async ? "asynchronous" : "synchronous");
-	if (json) printf("{\"prince_seconds\": %.4f, \"devices\": %d, \"virtual\": %s, \"kat\": \"%016llx\", \"kat_ok\": %s, \"round_states_checked\": %d, \"failures\": %d}\n",
-	                 encSeconds, ndev, virt ? "true" : "false", got, ok ? "true" : "false", checkRounds ? layer : 0, failures);
+	if (json) printf("{\"prince_seconds\": %.4f, \"block\": %d, \"devices\": %d, \"virtual\": %s, \"kat\": \"%016llx\", \"kat_ok\": %s, \"round_states_checked\": %d, \"failures\": %d}\n",
+	                 encSeconds, pass, ndev, virt ? "true" : "false", got, ok ? "true" : "false", checkRounds ? layer : 0, failures);
+	if (isAsynchronous()) { setAsynchronous(false); }
+	}
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;
 }

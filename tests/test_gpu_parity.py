@@ -1287,6 +1287,88 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
             o.close()
 
 
+@pytest.mark.parametrize("name", ["toy1155", "dhs_simple", "prince_small", "pow2_32768"])
+def test_transforms_of_separately_owned_blocks(gu, name):
+    """cuhe_hip_ct_ntt_list / cuhe_hip_ct_intt_list (round 5: what the gate scheduler's batches call instead of gather + array transform +
+    scatter): the one-workgroup kernels address the rows of every ciphertext inside that ciphertext's own block.  140 ciphertexts (up to
+    128 blocks per launch) whose blocks lie in a shuffled order inside one pool (offsets of both signs) against the per-ciphertext transforms
+    (cuhe_hip_ct_ntt) and the array forms on gathered rows (cuhe_hip_intt_batch / cuhe_hip_intt_mod_batch), bit for bit; products too; a call
+    of 3 ciphertexts (takes the two-pass pair on the long rings: the entry points gather through their own scratch) and the forced
+    gather form (cuhe_hip_set_row_lists(0)) give the same rows."""
+    import ctypes as C
+    lib, ck = gu.lib, gu.ck
+    g = gu.GpuCtx(*PSETS[name])
+    try:
+        q = g.prm
+        rng = np.random.default_rng(91)
+        plist = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        for lvl, n in ((0, 70), (1, 3)):
+            npr, logq, ctlen = g.np_(lvl), g.logq(lvl), g.ctlen
+            crt = [np.zeros((npr, q.crtLen), dtype=np.uint32) for _ in range(2 * n)]
+            for a in crt:
+                for t in range(npr):
+                    a[t, :q.modLen] = rng.integers(0, g.primes[t], q.modLen, dtype=np.uint32)
+            # blocks in shuffled slots of one pool, a gap of one block between neighbours
+            cpool, npool = gu.empty_u32(4 * n, npr, q.crtLen), gu.empty_u64(4 * n, npr, ctlen)
+            slots = rng.permutation(2 * n)
+            dcrt = [cpool[2 * int(sl)] for sl in slots]
+            dntt = [npool[2 * int(sl)] for sl in slots]
+            for t, a in zip(dcrt, crt):
+                t.copy_(gu.to_dev(a))
+            direct = C.c_int(-1)
+            ck(lib.cuhe_hip_ct_ntt_list(plist(dntt), plist(dcrt), 2 * n, lvl, 0, None, C.byref(direct)))
+            assert direct.value in (0, min(2 * n, 128), 2 * n), direct.value
+            if name == "prince_small" and n == 70:
+                assert direct.value == 128, direct.value              # 128 blocks x 3 rows of 32K points fill the chip (the form the scheduler's batches rely
+                                                                      # on); the 12 ciphertexts left over are too few: gathered
+            if name == "prince_small" and n == 3:
+                assert direct.value == 0                              # the two-pass pair: through the entry point's own scratch
+            want = gu.empty_u64(npr, ctlen)
+            for i in sorted(set([0, 1, n // 2, n - 1, n, 2 * n - 1])):
+                ck(lib.cuhe_hip_ct_ntt(want.data_ptr(), dcrt[i].data_ptr(), logq, 0, None))
+                assert np.array_equal(gu.host_u64(dntt[i]), gu.host_u64(want)), (lvl, i)
+            # ---- n2c of non-products: the round trip, and the array form on gathered rows
+            back = gu.empty_u32(2 * n, npr, q.crtLen); back.zero_()
+            ck(lib.cuhe_hip_ct_intt_list(back.data_ptr(), plist(dntt), 2 * n, lvl, 0, 0, None, C.byref(direct)))
+            got = gu.host_u32(back)
+            for i in range(2 * n):
+                assert np.array_equal(got[i][:, :q.modLen], crt[i][:, :q.modLen]), (lvl, i)
+            narr = gu.empty_u64(2 * n, npr, ctlen)
+            ck(lib.cuhe_hip_gather_blocks(narr.data_ptr(), plist(dntt), 2 * n, npr * ctlen * 8, 0, None))
+            ref = gu.empty_u32(2 * n, npr, q.crtLen); ref.zero_()
+            ck(lib.cuhe_hip_intt_batch(ref.data_ptr(), narr.data_ptr(), lvl, 2 * n, 0, None))
+            assert np.array_equal(got, gu.host_u32(ref))
+            # ---- products: z_i = a_i * b_i in their own blocks, n2c with the reduction modulo the polynomial modulus
+            zpool = gu.empty_u64(2 * n, npr, ctlen)
+            z = [zpool[2 * int(k)] for k in rng.permutation(n)]
+            ck(lib.cuhe_hip_ct_binop_list(1, plist(z), plist(dntt[:n]), plist(dntt[n:]), n, logq, 0, None))
+            pr = gu.empty_u32(n, npr, q.crtLen); pr.zero_()
+            ck(lib.cuhe_hip_ct_intt_list(pr.data_ptr(), plist(z), n, lvl, 1, 0, None, C.byref(direct)))
+            zarr = gu.empty_u64(n, npr, ctlen)
+            ck(lib.cuhe_hip_gather_blocks(zarr.data_ptr(), plist(z), n, npr * ctlen * 8, 0, None))
+            pref = gu.empty_u32(n, npr, q.crtLen); pref.zero_()
+            ck(lib.cuhe_hip_intt_mod_batch(pref.data_ptr(), zarr.data_ptr(), lvl, n, 0, None))
+            assert np.array_equal(gu.host_u32(pr), gu.host_u32(pref)), lvl
+            # ---- the forced gather form
+            ck(lib.cuhe_hip_set_row_lists(0))
+            try:
+                pr2 = gu.empty_u32(n, npr, q.crtLen); pr2.zero_()
+                ck(lib.cuhe_hip_ct_intt_list(pr2.data_ptr(), plist(z), n, lvl, 1, 0, None, C.byref(direct)))
+                assert direct.value == 0 and np.array_equal(gu.host_u32(pr2), gu.host_u32(pref))
+                again = [gu.empty_u64(npr, ctlen) for _ in range(2 * n)]
+                ck(lib.cuhe_hip_ct_ntt_list(plist(again), plist(dcrt), 2 * n, lvl, 0, None, C.byref(direct)))
+                assert direct.value == 0
+                for i in (0, n, 2 * n - 1):
+                    assert np.array_equal(gu.host_u64(again[i]), gu.host_u64(dntt[i])), (lvl, i)
+            finally:
+                ck(lib.cuhe_hip_set_row_lists(1))
+            bad = (C.c_void_p * 2)(dntt[0].data_ptr(), None)
+            assert lib.cuhe_hip_ct_intt_list(back.data_ptr(), bad, 2, lvl, 0, 0, None, None) != 0
+        assert lib.cuhe_hip_ct_ntt_list(plist(dntt), plist(dcrt), 2, q.depth, 0, None, None) != 0          # no such level
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("name", ["toy1155", "pow2_32768"])
 def test_list_block_and_event_entry_points(gu, name):
     """The round-4 additions to the C ABI that the C++ layer's gate scheduler is built on, each against the entry point it
