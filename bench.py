@@ -600,7 +600,8 @@ def bench_prince(world, single_dev):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "cuhe_amd", "cxx"), "-s", exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
         # three blocks in one process: `value` is the FIRST (what the reference times: one block after set-up, examples/Prince/Prince.cu:83-87);
         # the later ones no longer pay the first-time hipMalloc of the arrays (profiles/r05_prince_gaps_arrays.txt)
-        cmd = [exe, "--no-round-checks", "--async", "--json", "--repeat", "3", "--devices", str(world)] + (["--virtual"] if single_dev and world > 1 else [])
+        # (one GPU only: the repeated form of the multi-device client has not run on hardware)
+        cmd = [exe, "--no-round-checks", "--async", "--json"] + (["--repeat", "3"] if world == 1 else []) + ["--devices", str(world)] + (["--virtual"] if single_dev and world > 1 else [])
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
