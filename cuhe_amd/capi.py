@@ -48,6 +48,7 @@ SIGNATURES = {
     "cuhe_hip_set_virtual_devices": (i32, [i32]),
     "cuhe_hip_set_device_base": (i32, [i32]),
     "cuhe_hip_init": (i32, [vp, i32]),
+    "cuhe_hip_same_ring": (i32, [vp, i32]),
     "cuhe_hip_shutdown": (i32, []),
     "cuhe_hip_get_coeff_modulus": (i32, [i32, vp, sz, C.POINTER(sz)]),
     "cuhe_hip_get_crt_primes": (i32, [vp, i32]),

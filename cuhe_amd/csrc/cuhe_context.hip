@@ -379,9 +379,26 @@ int cuhe_hip_set_device_base(int dev) {
     return CUHE_OK;
 }
 
+static bool same_inputs(const Params &a, const Params &b) {
+    return a.depth == b.depth && a.modMsg == b.modMsg && a.logRelin == b.logRelin && a.logCoeffMin == b.logCoeffMin &&
+           a.logCoeffCut == b.logCoeffCut && a.mSize == b.mSize;
+}
+int cuhe_hip_same_ring(const int32_t *modulus, int ncoeffs) {
+    if (!G_.inited || !G_.params_set || !same_inputs(G_.prm, G_.prm_init) || G_.nc_mode != G_.nc_mode_init) return 0;
+    if (!modulus) return G_.modulus == host::cyclotomic(G_.prm.mSize) ? 1 : 0;
+    return (size_t)ncoeffs == G_.modulus.size() && std::equal(modulus, modulus + ncoeffs, G_.modulus.begin()) ? 1 : 0;
+}
+
 int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
     if (!G_.params_set) return fail(CUHE_EINVAL, "setParameters must precede initCuHE");
-    if (G_.inited) return fail(CUHE_EINVAL, "already initialised");
+    if (G_.inited) {
+        // A second scheme object built in the same process (examples/DHS/simple_DHS.cu:176,186: CuDHS(string) runs setParameters
+        // + initCuHE again while the first object is alive and is used afterwards): the reference re-creates its tables beside the
+        // old ones and every live object stays valid.  On the SAME ring that is a no-op here -- tables, resident evaluation keys
+        // and every block clients hold are kept; another ring needs cuhe_hip_shutdown first (it frees all of them).
+        if (cuhe_hip_same_ring(modulus, ncoeffs) == 1) return CUHE_OK;
+        return fail(CUHE_EINVAL, "already initialised on another ring (cuhe_hip_shutdown first)");
+    }
     const Params &q = G_.prm;
     if (modulus) {
         if (ncoeffs != q.modLen + 1 || modulus[q.modLen] != 1)
@@ -426,7 +443,7 @@ int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
     for (int i = 0; i < q.depth; ++i)
         for (int j = 0; j < q.numCrtPrime - i; ++j) G_.coeffModulus[i].mul_small(G_.primes[j]);
     G_.dev.resize(G_.ndev);
-    G_.inited = true;
+    G_.inited = true; G_.prm_init = G_.prm; G_.nc_mode_init = G_.nc_mode;
     for (int dev = 0; dev < G_.ndev; ++dev) {
         int r = init_device(dev);
         if (r != CUHE_OK) { G_.inited = false; return r; }

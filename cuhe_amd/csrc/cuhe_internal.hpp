@@ -138,6 +138,7 @@ struct DevCtx {
 
 struct Global {
     Params prm;
+    Params prm_init; int nc_mode_init = -1;   // what the live context was initialised with (cuhe_hip_same_ring)
     bool params_set = false, inited = false, relin_ready = false;
     int ndev = 1, dev_base = 0;
     bool virtual_devices = false;  // tests: logical devices 0..ndev-1 all live on physical device dev_base

@@ -171,7 +171,9 @@ static void installModulus(const ZZX &modulus) {
 		long v; conv(v, c);
 		mod[i] = (int32_t)v;
 	}
-	if (cuhe_hip_is_initialised()) CSC(cuhe_hip_shutdown());
+	// a second initCuHE on the ring the library already runs on (a second scheme object from a key string, examples/DHS/DHS.cu:57-118)
+	// keeps tables, evaluation keys and the blocks live objects hold; another ring starts from scratch
+	if (cuhe_hip_is_initialised() && !cuhe_hip_same_ring(mod.data(), (int)mod.size())) CSC(cuhe_hip_shutdown());
 	CSC(cuhe_hip_init(mod.data(), (int)mod.size()));
 	loadCoeffModuli();
 }

@@ -78,6 +78,11 @@ int cuhe_hip_set_virtual_devices(int on);
  * modulus: monic integer polynomial, modLen+1 coefficients low-to-high
  * (NULL => the cyclotomic polynomial Phi_m).  Synchronous. */
 int cuhe_hip_init(const int32_t *modulus, int ncoeffs);
+/* 1 if the library is initialised and the CURRENT parameters (cuhe_hip_set_parameters) + this modulus describe the ring it was
+ * initialised on, else 0.  cuhe_hip_init on the same ring is then a no-op that keeps tables, resident evaluation keys and every
+ * block handed out: a second scheme object built from a key string (examples/DHS/DHS.cu:57-118: setParameters + initCuHE again,
+ * examples/DHS/simple_DHS.cu:176-190) leaves the first one usable, as in the reference. */
+int cuhe_hip_same_ring(const int32_t *modulus, int ncoeffs);
 int cuhe_hip_is_initialised(void);       /* 1 between a successful cuhe_hip_init and cuhe_hip_shutdown */
 int cuhe_hip_shutdown(void);
 /* coefficient modulus q_lvl as little-endian bytes (initCuHE's ZZ* output, Operations.cu:157-160) */

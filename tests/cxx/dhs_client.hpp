@@ -18,8 +18,11 @@ static inline void traceMark() {
 	cuhe_hip_device_sync(0);
 	cuhe_hip_probe_valu(0, 1, 1, &a, &b, &c);
 }
+#include "Utils.h"
 #include <cstdio>
 #include <cstdlib>
+#include <sstream>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -201,6 +204,58 @@ struct Dhs {
 			}
 			initRelinearization(ek.data());
 		}
+	}
+	// ---- key strings (examples/DHS/DHS.cu:120-189: getPublicKey / getPrivateKey through cuhe/Utils.h's PicklableMap) and the scheme
+	// object built back from one (DHS.cu:57-118: setParameters + initCuHE AGAIN in the same process; no key generation).  A public
+	// string gives an object that encrypts and evaluates, a private one also decrypts.
+	std::vector<cuHE_Utils::Picklable *> publicPicklables() {
+		using cuHE_Utils::Picklable;
+		std::vector<Picklable *> ps;
+		const long ints[6] = {param.depth, param.modMsg, param.logRelin, param.logCoeffMin, param.logCoeffCut, param.mSize};
+		const char *names[6] = {"d", "p", "w", "min", "cut", "m"};
+		for (int i = 0; i < 6; ++i) { ZZ v = to_ZZ(ints[i]); ps.push_back(new Picklable(names[i], &v, 1)); }
+		ps.push_back(new Picklable("coeffMod", q.data(), depth));
+		ps.push_back(new Picklable("polyMod", phiZ));
+		for (int i = 0; i < depth; ++i) ps.push_back(new Picklable("pk" + std::to_string(i), pk[i]));
+		for (size_t i = 0; i < ek.size(); ++i) ps.push_back(new Picklable("ek" + std::to_string(i), ek[i]));
+		return ps;
+	}
+	std::string getPublicKey() { cuHE_Utils::PicklableMap pm(publicPicklables()); return pm.toString(); }
+	std::string getPrivateKey() {
+		std::vector<cuHE_Utils::Picklable *> ps = publicPicklables();
+		for (int i = 0; i < depth; ++i) ps.push_back(new cuHE_Utils::Picklable("sk" + std::to_string(i), sk[i]));
+		cuHE_Utils::PicklableMap pm(ps);
+		return pm.toString();
+	}
+	bool hasPrivate() const { return !sk.empty(); }
+	// reloadKeys: run initRelinearization on the string's evaluation keys too (the reference's constructor does not: its second
+	// and third objects live on the keys the first one loaded)
+	void setupFromKey(const std::string &key, bool reloadKeys) {
+		cuHE_Utils::PicklableMap pm(key);
+		auto num = [&](const char *k) { return atoi(pm.get(k)->getValues().c_str()); };
+		setParameters(num("d"), num("p"), num("w"), num("min"), num("cut"), num("m"));
+		n = param.modLen; depth = param.depth; np = param.numCrtPrime;
+		q.assign(depth, ZZ());
+		{ cuHE_Utils::Picklable *cm = pm.get("coeffMod"); for (int i = 0; i < depth && i < cm->getCoeffsLen(); ++i) q[i] = cm->getCoeffs()[i]; }
+		phiZ = pm.get("polyMod")->getPoly();
+		phi.assign(n + 1, 0);
+		for (int i = 0; i <= n; ++i) { long v; conv(v, coeff(phiZ, i)); phi[i] = v; }
+		pk.assign(depth, ZZX());
+		for (int i = 0; i < depth; ++i) pk[i] = pm.get("pk" + std::to_string(i))->getPoly();
+		sk.clear();
+		try { pm.get("sk0"); sk.assign(depth, ZZX()); } catch (char const *) {}
+		for (size_t i = 0; i < sk.size(); ++i) sk[i] = pm.get("sk" + std::to_string((int)i))->getPoly();
+		ek.clear();
+		if (param.logRelin > 0) {
+			ek.assign(param.numEvalKey, ZZX());
+			for (int i = 0; i < param.numEvalKey; ++i) ek[i] = pm.get("ek" + std::to_string(i))->getPoly();
+		}
+		std::vector<ZZ> fromLibrary(depth);
+		initCuHE(fromLibrary.data(), phiZ);
+		for (int i = 0; i < depth; ++i) if (!(fromLibrary[i] == q[i])) { printf("key string: coefficient modulus of level %d differs from the library's\n", i); exit(2); }
+		primes.resize(np);
+		if (cuhe_hip_get_crt_primes(primes.data(), np) != 0) { printf("cannot read the CRT primes\n"); exit(2); }
+		if (reloadKeys && !ek.empty()) initRelinearization(ek.data());
 	}
 	ZZX encrypt(const ZZX &msg, int lvl) { return maskedSample(lvl, msg); }
 	ZZX encryptBit(int bit, int lvl) { ZZX m; if (bit) SetCoeff(m, 0, 1); return encrypt(m, lvl); }

@@ -75,6 +75,36 @@ int main(int argc, char **argv) {
 			report("and2", w.level() == 2 && dhs.decrypt(w.zRep(), 2) == mulMod2(x01, x2, dhs.phi));
 		}
 	}
+	{	// checkKeys (examples/DHS/simple_DHS.cu:165-205): key strings out, a SECOND scheme object from the private string and a THIRD from
+		// the public one in this process -- each runs setParameters + initCuHE again (DHS.cu:57-118), the second initRelinearization as
+		// well -- cross encrypt / decrypt, then the FIRST object evaluates a multiplicative level again: its evaluation keys, tables and
+		// the device blocks of a ciphertext that was alive across the re-initialisations must be intact.
+		CuCtxt alive; alive.setLevel(0, 0, y1); alive.x2n();            // device-resident across everything below
+		long long before[4] = {0, 0, 0, 0}, after[4] = {0, 0, 0, 0};
+		synchronize();
+		const unsigned long long gen0 = cuhe_hip_generation();
+		cuhe_hip_alloc_counters(before);
+		const std::string priv = dhs.getPrivateKey(), pub = dhs.getPublicKey();
+		ZZX x3 = randomBits(n);
+		ZZX c1 = dhs.encrypt(x3, 0);
+		Dhs *dhs2 = new Dhs; dhs2->setupFromKey(priv, true);
+		bool ok = dhs2->hasPrivate() && dhs2->decrypt(c1, 0) == x3;
+		Dhs *dhs3 = new Dhs; dhs3->setupFromKey(pub, false);
+		ok = ok && !dhs3->hasPrivate();
+		ZZX c3 = dhs3->encrypt(x3, 0);
+		ok = ok && dhs.decrypt(c3, 0) == x3;
+		ok = ok && pub.size() < priv.size() && dhs2->getPublicKey() == pub && dhs3->getPublicKey() == pub && dhs2->getPrivateKey() == priv;
+		report("keys", ok);
+		delete dhs2; delete dhs3;
+		synchronize();
+		cuhe_hip_alloc_counters(after);
+		const bool sameContext = cuhe_hip_generation() == gen0;
+		// the first object again: AND of a ciphertext made by the third object with the one that stayed on the device
+		CuCtxt a, z; a.setLevel(0, 0, c3); a.x2n();
+		cAnd(z, a, alive); z.relin(); z.modSwitch(); z.x2z();
+		report("and after re-initialisation", sameContext && dhs.decrypt(z.zRep(), 1) == mulMod2(x3, x1, dhs.phi));
+		printf("allocator across checkKeys: hipMalloc calls %lld -> %lld, context generation %s\n", before[0], after[0], sameContext ? "unchanged (tables and keys kept)" : "CHANGED");
+	}
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);
 	return failures ? 1 : 0;
 }

@@ -29,8 +29,9 @@ def test_cxx_api_program(sched):
 
 
 @pytest.mark.parametrize("sched", [False, True], ids=["synchronous", "scheduled"])
-@pytest.mark.parametrize("params", [(3, 2, 8, 40, 20, 1155), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
-                         ids=["toy1155", "dhs_simple", "pow2_32768-negacyclic"])
+@pytest.mark.parametrize("params", [(3, 2, 8, 40, 20, 1155), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768),
+                                    (3, 2, 16, 50, 25, 32767), (3, 2, 16, 50, 25, 32749)],
+                         ids=["toy1155", "dhs_simple", "pow2_32768-negacyclic", "phi32767-generic-64K", "prime32749-fold-64K"])
 def test_dhs_scheme_flow(params, sched):
     """keygen / encrypt / XOR / NOT / AND + relin + modSwitch (two levels) / decrypt through CuHE.h -- the checks of
     examples/DHS/simple_DHS.cu:49-170, with the reference example's own parameter set as the second case"""

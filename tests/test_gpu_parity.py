@@ -116,7 +116,13 @@ PSETS = {
     "pow2_16384": (3, 2, 16, 50, 25, 16384),     # x^n + 1
     "prince_small": (3, 2, 16, 25, 25, 21845),   # Prince ring (n=16384, L=32768), 3 levels
     "pow2_32768": (3, 2, 16, 48, 24, 32768),     # x^16384 + 1 with 24-bit primes: the NEGACYCLIC ciphertext domain applies
+    # general Phi_m behind 64K-point transforms: what the reference's ntt_*_64k kernels exist for (cuhe/Operations.cu:322-329,
+    # 460-501, cuhe/Base.cu:659-842,927-1001).  Depth 3 / 4 primes: the oracle's Barrett chain at L = 65536 takes ~2 s per call.
+    "phi32767": (3, 2, 16, 50, 25, 32767),       # m = 7 * 31 * 151, phi = 27000: generic (folded / five-transform) Barrett, L = 65536
+    "prime32749": (3, 2, 16, 50, 25, 32749),     # prime m, n = 32748: the prime-m fold at L = 65536
+    "prime16381": (3, 2, 16, 50, 25, 16381),     # prime m, n = 16380: the prime-m fold at L = 32768
 }
+GENERAL_64K = ["phi32767", "prime32749", "prime16381"]
 
 
 @pytest.fixture(scope="module", params=list(PSETS))
@@ -321,10 +327,12 @@ def test_mul_pipeline_vs_golden(gu, golden, name, fixture):
         g.close()
 
 
-def test_relin_vs_oracle(gu):
-    """window NTTs + key-switch inner product + mul+relin chain (cuhe/CuHE.cu:570-581)."""
+@pytest.mark.parametrize("name", ["prince_small"] + GENERAL_64K)
+def test_relin_vs_oracle(gu, name):
+    """window NTTs + key-switch inner product + mul+relin chain (cuhe/CuHE.cu:570-581): the Prince ring (w = 16) and general Phi_m
+    behind 64K-point transforms (composite m; prime m at 64K and 32K points)."""
     import oracle_lib as O
-    args = (3, 2, 16, 25, 25, 21845)             # Prince ring, w = 16
+    args = PSETS[name]
     g, o = gu.GpuCtx(*args), O.Ctx(*args)
     try:
         q = o.prm
@@ -345,7 +353,7 @@ def test_relin_vs_oracle(gu):
         g.close(); o.close()
 
 
-@pytest.mark.parametrize("name", ["toy1155", "pow2_16384", "pow2_32768"])
+@pytest.mark.parametrize("name", ["toy1155", "pow2_16384", "pow2_32768"] + GENERAL_64K)
 def test_fused_relin_chain_equals_the_two_calls(gu, name):
     """cuhe_hip_relin_crt (raw -> reduced CRT rows in one call, what CuCtxt::relin uses since round 5) against cuhe_hip_relinearization ;
     cuhe_hip_ct_intt on cyclic and negacyclic rings, every level, repeated (scratch reuse), on a caller's own stream too."""
@@ -426,7 +434,7 @@ def test_config3_full_size_properties(gu, nc):
         g.close()
 
 
-@pytest.mark.parametrize("name", ["toy1155", "prince_small", "pow2_32768"])
+@pytest.mark.parametrize("name", ["toy1155", "prince_small", "pow2_32768", "phi32767", "prime32749"])
 def test_prime_range_entry_points(gu, name):
     """CRT-prime-sharded entry points (cuhe_hip_*_range / *_rows): two shards computed one after the other on one
     GPU and reassembled must equal the unsharded oracle result (the collective itself is covered by
@@ -763,9 +771,10 @@ def test_config4_relin_structured_keys_vs_python(gu):
 
 
 @pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 25, 25, 21845),
-                                  (5, 2, 1, 61, 20, 8191), (6, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
+                                  (5, 2, 1, 61, 20, 8191), (6, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768),
+                                  (3, 2, 16, 50, 25, 32767), (3, 2, 16, 50, 25, 32749)],
                          ids=["toy1155-generic", "pow2_16384-fused", "prince_ring-generic", "dhs_simple-141keys-lds144K",
-                              "w1-161keys-register-kernel", "pow2_32768-negacyclic"])
+                              "w1-161keys-register-kernel", "pow2_32768-negacyclic", "phi32767-generic-64K", "prime32749-fold-64K"])
 def test_mul_relin_batch_equals_single(gu, args):
     """cuhe_hip_mul_relin_batch (B independent cAnd + relin chains in one call: batch*np rows per stage, key values
     shared by four ciphertexts in the inner product) is bit-identical to B single-ciphertext sequences, which the other
@@ -856,8 +865,10 @@ def test_matrix_core_inner_product_equals_valu_kernel(gu, args):
         g.close(); o.close()
 
 
-@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768)],
-                         ids=["toy1155-generic", "pow2_16384-fused", "dhs_simple-prime_m", "pow2_32768-negacyclic"])
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (5, 2, 1, 61, 20, 8191), (3, 2, 16, 48, 24, 32768),
+                                  (3, 2, 16, 50, 25, 32767), (3, 2, 16, 50, 25, 32749), (3, 2, 16, 50, 25, 16381)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "dhs_simple-prime_m", "pow2_32768-negacyclic",
+                              "phi32767-generic-64K", "prime32749-fold-64K", "prime16381-fold-32K"])
 def test_mul_raw_batch_equals_single(gu, args):
     """cuhe_hip_mul_raw_batch (B full multiplications raw -> raw per call) against the oracle's mulZZX-at-the-raw-level
     for every ciphertext of the batch, on the three reduction kinds, at two levels, with odd batch sizes."""
@@ -880,8 +891,9 @@ def test_mul_raw_batch_equals_single(gu, args):
         g.close(); o.close()
 
 
-@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 48, 24, 32768)],
-                         ids=["toy1155-generic", "pow2_16384-fused", "pow2_32768-negacyclic"])
+@pytest.mark.parametrize("args", [(3, 2, 8, 40, 20, 1155), (3, 2, 16, 50, 25, 16384), (3, 2, 16, 48, 24, 32768),
+                                  (3, 2, 16, 50, 25, 32767), (3, 2, 16, 50, 25, 32749)],
+                         ids=["toy1155-generic", "pow2_16384-fused", "pow2_32768-negacyclic", "phi32767-generic-64K", "prime32749-fold-64K"])
 def test_array_gates_equal_single_gates(gu, args):
     """gates on arrays of ciphertexts (cuhe_hip_ntt_mul_pairs, intt_mod_batch, crt_mod_switch_batch, crt_combine) against the
     per-ciphertext entry points they stand for (ntt_mul, intt_mod, crt_mod_switch, crt_add / crt_add_int), which the
@@ -1156,7 +1168,9 @@ def test_sharded_multiply_through_the_c_abi(gu):
 
 @pytest.mark.parametrize("name,args", [("toy1155", (3, 2, 8, 40, 20, 1155)), ("prince_small", (3, 2, 16, 25, 25, 21845)),
                                        ("pow2_16384", (3, 2, 16, 50, 25, 16384)), ("pow2_32768", (3, 2, 16, 48, 24, 32768)),
-                                       ("c3_65536", (9, 2, 16, 576, 24, 65536)), ("n65536", (3, 2, 16, 46, 23, 131072))])
+                                       ("c3_65536", (9, 2, 16, 576, 24, 65536)), ("n65536", (3, 2, 16, 46, 23, 131072)),
+                                       ("phi32767", (3, 2, 16, 50, 25, 32767)), ("prime32749", (3, 2, 16, 50, 25, 32749)),
+                                       ("prime16381", (3, 2, 16, 50, 25, 16381))])
 def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
     """Every form of the transform kernels (two passes with 16 values per thread: throughput; 4 values per thread, radix-4
     through LDS: low latency, taken below cuhe_hip_set_ll_rows rows; ONE workgroup per 8K / 16K / 32K-point sub-transform,
@@ -1287,7 +1301,7 @@ def test_low_latency_kernels_equal_throughput_kernels(gu, name, args):
             o.close()
 
 
-@pytest.mark.parametrize("name", ["toy1155", "dhs_simple", "prince_small", "pow2_32768"])
+@pytest.mark.parametrize("name", ["toy1155", "dhs_simple", "prince_small", "pow2_32768", "phi32767", "prime32749"])
 def test_transforms_of_separately_owned_blocks(gu, name):
     """cuhe_hip_ct_ntt_list / cuhe_hip_ct_intt_list (round 5: what the gate scheduler's batches call instead of gather + array transform +
     scatter): the one-workgroup kernels address the rows of every ciphertext inside that ciphertext's own block.  140 ciphertexts (up to
@@ -1369,7 +1383,7 @@ def test_transforms_of_separately_owned_blocks(gu, name):
         g.close()
 
 
-@pytest.mark.parametrize("name", ["toy1155", "pow2_32768"])
+@pytest.mark.parametrize("name", ["toy1155", "pow2_32768", "phi32767"])
 def test_list_block_and_event_entry_points(gu, name):
     """The round-4 additions to the C ABI that the C++ layer's gate scheduler is built on, each against the entry point it
     generalises: gather / scatter / copy of separately owned blocks through pointer lists, cAnd / cXor over lists
