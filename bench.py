@@ -658,6 +658,28 @@ def bench_prince_gate_by_gate():
         return {"error": repr(ex)[:300]}
 
 
+def sharded_comm_guard(per_rank, world, in_library):
+    """SURVEY 8(e) / cuhe/CuHE.cu:217-256: a `mul_relin_sharded` value quoted as "exchange inside the library over RCCL" is only printed
+    when EVERY rank's communicator really spans the job: ncclCommCount == world, ncclCommUserRank == the rank, and the library's own
+    view agrees (cuhe_hip_comm_info, gathered from all ranks).  Returns None when the record may be printed, else the reason.  (When the
+    in-library communicator is not in use -- the torch.distributed exchange around the same stages -- there is nothing to check.)"""
+    import re
+    if not in_library:
+        return None
+    if len(per_rank) != world or any(not isinstance(x, str) for x in per_rank):
+        return "communicator reports of %d rank(s) for a job of %d" % (sum(isinstance(x, str) for x in per_rank), world)
+    for r, text in enumerate(per_rank):
+        m = re.search(r"ncclCommCount (-?\d+), ncclCommUserRank (-?\d+) \(library: (-?\d+) ranks, rank (-?\d+)\)", text)
+        if not m or "communicator initialised" not in text:
+            return "rank %d: no initialised communicator in its report (%s)" % (r, text[:120])
+        cnt, urank, lranks, lrank = (int(v) for v in m.groups())
+        if cnt != world or lranks != world:
+            return "rank %d: ncclCommCount %d / library %d ranks in a job of %d" % (r, cnt, lranks, world)
+        if urank != r or lrank != r:
+            return "rank %d reports ncclCommUserRank %d / library rank %d" % (r, urank, lrank)
+    return None
+
+
 def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, single_dev=False):
     """primes of ONE ciphertext sharded over the ranks, one all-gather (CRT rows before ICRT) per
     multiply+relinearise; value = multiplies per second of the whole job (max time over ranks).  The whole chain, RCCL
@@ -790,6 +812,9 @@ def bench_mulrelin_sharded(lib, ck, torch, np, dist, dev, rank, world, args, sin
     lib_comm_size = lib.cuhe_hip_comm_size() if in_library else None
     lib.cuhe_hip_comm_destroy()
     lib.cuhe_hip_shutdown(); lib.cuhe_hip_reset_parameters()
+    refused = sharded_comm_guard(per_rank, world, in_library)
+    if refused:                                         # no number under a claim that did not hold
+        return {"value": None, "error": "not reported: " + refused, "rccl_per_rank": per_rank, "comm_size": lib_comm_size}
     return {"value": round(1.0 / dt, 2), "unit": "mul+relin/s (one ciphertext, primes sharded)", "ms": round(dt * 1e3, 3),
             "key_bytes_per_rank": key_bytes, "key_primes_per_rank": kc.value,
             "replicated_ms": round(t_rep * 1e3, 3), "serial_fraction": round(t_rep / dt, 3),

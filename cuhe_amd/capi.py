@@ -60,6 +60,7 @@ SIGNATURES = {
     "cuhe_hip_free": (i32, [i32, vp]),
     "cuhe_hip_set_alloc_cache": (i32, [sz]),
     "cuhe_hip_alloc_counters": (i32, [vp]),
+    "cuhe_hip_set_alloc_fail_after": (i32, [C.c_long]),
     "cuhe_hip_generation": (u64, []),
     "cuhe_hip_malloc_stream": (vp, [i32, sz, vp]),
     "cuhe_hip_free_stream": (i32, [i32, vp, vp]),
@@ -173,6 +174,7 @@ SIGNATURES = {
     "cuhe_hip_set_ntt_chunk": (i32, [i32]),
     "cuhe_hip_set_ntt_overlap": (i32, [i32]),
     "cuhe_hip_probe_valu": (i32, [i32, i32, i32] + [C.POINTER(C.c_double)] * 3),
+    "cuhe_hip_probe_copy": (i32, [i32, sz, i32, i32, C.POINTER(C.c_double)]),
     "cuhe_hip_time_ntt_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp] + [C.POINTER(C.c_float)] * 3),
     "cuhe_hip_modp_add": (i32, [vp, vp, vp, sz, i32, vp]),
     "cuhe_hip_modp_sub": (i32, [vp, vp, vp, sz, i32, vp]),

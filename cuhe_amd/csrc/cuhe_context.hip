@@ -546,8 +546,14 @@ int cuhe_hip_alloc_counters(long long *out4) {
 }
 // may the allocator touch this stream handle on its own?  (only handles known to be alive)
 static inline bool probeable(const DevCtx &D, hipStream_t st) { return st == nullptr || D.ownStreams.count(st) != 0; }
+static std::atomic<long> g_alloc_fail_after{-1};
+int cuhe_hip_set_alloc_fail_after(long n) { g_alloc_fail_after.store(n < 0 ? -1 : n); return CUHE_OK; }
 void *cuhe_hip_malloc(int dev, size_t bytes) {
     if (set_dev(dev) != CUHE_OK) return nullptr;
+    if (g_alloc_fail_after.load(std::memory_order_relaxed) >= 0 && g_alloc_fail_after.fetch_sub(1) == 0) {   // test hook: an allocation failure on demand
+        fail(CUHE_EHIP, "hipMalloc(%zu) failed (injected by cuhe_hip_set_alloc_fail_after)", bytes);
+        return nullptr;
+    }
     DevCtx &D = G_.dev[dev];
     std::unique_lock<std::mutex> lk(G_.mu);
     auto it = D.freeBlocks.find(bytes);
@@ -766,6 +772,62 @@ int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_in
     *shader_mhz = avg / (ms * 1e3 / reps);                              // ticks of one wave per microsecond of one kernel
     *cycles_per_instr = avg / instr / waves_per_simd;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(out); hipFree(ticks);
+    return CUHE_OK;
+}
+
+// ---- cuhe_hip_probe_copy: the streaming-copy ceiling of this box (include/cuhe_hip.h) -- the "measured peak" the HBM-bound kernels are
+// priced against next to the 8 TB/s of the data sheet.  16-byte accesses, grid-stride, 2048 workgroups (8 per CU).
+}  // extern "C"
+namespace {
+template <int UNROLL, bool NT> __global__ __launch_bounds__(256) void k_probe_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (NT) { const float *p = (const float *)(src + i + u * stride);
+                      v[u] = make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2), __builtin_nontemporal_load(p + 3)); }
+            else v[u] = src[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (NT) { float *p = (float *)(dst + i + u * stride);
+                      __builtin_nontemporal_store(v[u].x, p); __builtin_nontemporal_store(v[u].y, p + 1); __builtin_nontemporal_store(v[u].z, p + 2); __builtin_nontemporal_store(v[u].w, p + 3); }
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+extern "C" {
+int cuhe_hip_probe_copy(int dev, size_t bytes, int variant, int reps, double *gb_per_s) {
+    if (bytes < (1u << 20) || (bytes & 15) || reps < 1 || variant < 0 || variant > 3 || !gb_per_s) return fail(CUHE_EINVAL, "probe_copy(%zu bytes, variant %d, %d reps)", bytes, variant, reps);
+    if (hipSetDevice(G_.dev_base + (G_.virtual_devices ? 0 : dev)) != hipSuccess) return fail(CUHE_EHIP, "hipSetDevice");
+    float4 *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc((void **)&a, bytes));
+    if (hipMalloc((void **)&b, bytes) != hipSuccess) { hipFree(a); return fail(CUHE_EHIP, "probe_copy: hipMalloc"); }
+    HIPCHK(hipMemset(a, 0x5a, bytes));
+    const size_t n = bytes / 16;
+    const int blocks = 2048;
+    auto launch = [&]() {
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((k_probe_copy<1, false>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
+            case 1: hipLaunchKernelGGL((k_probe_copy<4, false>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
+            case 2: hipLaunchKernelGGL((k_probe_copy<4, true>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
+            default: hipLaunchKernelGGL((k_probe_copy<8, false>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
+        }
+    };
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    launch(); launch();
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) launch();
+    HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *gb_per_s = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;          // bytes read + bytes written
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(a); hipFree(b);
     return CUHE_OK;
 }
 

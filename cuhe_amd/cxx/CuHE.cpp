@@ -107,14 +107,24 @@ static inline bool streamOrdered() { return asyncGates || gateDepth > 0 || sched
 // same gates below on the scheduler-side objects (from a worker thread, where scheduled() is false).
 static void runBatchedGates(int kind, sched::Node *const *subjects, sched::Node *const *op1, sched::Node *const *op2, int count, void *stream);
 enum { kMaxGateBatch = 128 };                // ready gates of one kind that run as one call of the array entry points
-void setScheduled(bool on, int threads) {
+static bool schedChosenByClient = false;      // the client called setScheduled itself: the environment's default no longer applies
+static void switchScheduled(bool on, int threads) {
 	if (on) { sched::setBatchRunner(runBatchedGates, kMaxGateBatch); sched::start(threads); } else sched::stop();
 }
+void setScheduled(bool on, int threads) { schedChosenByClient = true; switchScheduled(on, threads); }
 bool isScheduled() { return sched::on(); }
 void synchronize() { if (sched::on() && !sched::inWorker()) sched::drain(); }
+// Scheduled gates are the DEFAULT since round 6 (initCuHE switches them on): an unchanged reference client -- one gate per call from one host
+// thread -- then runs a PRINCE block in 0.06 s instead of 0.55 s.  What such a client can observe stays the reference's: x2z(), the raw-pointer
+// getters, the setters and synchronize() return with the work done (cuhe/CuHE.cu:98,121,139,157), misuse is reported at the call.
+// CUHE_SCHED=0 in the environment (or setScheduled(false)) gives the reference's synchronise-per-gate execution; CUHE_SCHED=n > 1 sets
+// the workers per device.  The evidence behind the default: tests/cxx/test_sched_soak.cpp, tools/sched_soak.sh, profiles/r06_sched_soak.txt.
 static void schedFromEnvironment() {
+	if (schedChosenByClient) return;
 	const char *e = getenv("CUHE_SCHED");
-	if (e && atoi(e) > 0 && !sched::on()) setScheduled(true, atoi(e) > 1 ? atoi(e) : 0);
+	const int v = e ? atoi(e) : 1;
+	if (v > 0 && !sched::on()) switchScheduled(true, v > 1 ? v : 0);
+	if (v <= 0 && sched::on()) switchScheduled(false, 0);
 }
 static bool schedCheck() { static const bool on = getenv("CUHE_SCHED_CHECK") && atoi(getenv("CUHE_SCHED_CHECK")) > 0; return on; }
 struct SchedAccess {

@@ -103,6 +103,7 @@ std::mutex doneMu;                         // waiters for "issued" / "outstandin
 std::condition_variable cvDone;
 std::atomic<long> outstanding{0}, totalTasks{0}, maxQueued{0}, nextId{0};
 std::atomic<bool> active{false}, stopping{false};
+extern std::atomic<long> issuedTotal;      // tasks issued so far (the watchdog's sign of life)
 int workersPerDev = 3, stealing = 1, policy = 1, trace = 0;
 int batchWorkers = 1;                      // how many of a device's workers take staged groups (0 = all; CUHE_SCHED_BATCH_WORKERS).  ONE: the batches of a device
                                            // follow each other on one stream with one set of batch scratch, the other workers run the regular tasks --
@@ -399,6 +400,7 @@ void workerMain(DevState *Dp, int me) {
 		}
 		for (Task *x : succAll) if (x->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) makeReady(x, &next);
 		outstanding.fetch_sub((long)batch.size(), std::memory_order_acq_rel);
+		issuedTotal.fetch_add((long)batch.size(), std::memory_order_relaxed);
 		{ std::lock_guard<std::mutex> dl(doneMu); }
 		cvDone.notify_all();
 		for (Task *t : batch) unrefTask(t);
@@ -435,6 +437,54 @@ void ensureWorkers(int dev) {
 	D.cv.wait(lk, [&D, n] { return D.started == n; });      // their streams exist
 }
 
+// ---- watchdog: a wait that sees no task issued for CUHE_SCHED_WATCHDOG_S seconds (default 60; 0 = never) reports the
+// queues of every device to stderr -- once per period -- instead of hanging silently; the wait itself goes on.
+std::atomic<long> issuedTotal{0};
+long watchdogSeconds() { static const long s = getenv("CUHE_SCHED_WATCHDOG_S") ? atol(getenv("CUHE_SCHED_WATCHDOG_S")) : 60; return s; }
+void dumpState(const char *where, Task *stuck) {
+	fprintf(stderr, "scheduler watchdog: %s has seen no task issued for %ld s; %ld task(s) outstanding, %ld recorded, %ld issued, policy %d, %d worker(s) per device, %d take groups\n",
+	        where, watchdogSeconds(), outstanding.load(), totalTasks.load(), issuedTotal.load(), policy, workersPerDev, batchWorkers);
+	if (stuck) {
+		fprintf(stderr, "  waiting for task #%ld (kind %d key %ld device %d): issued %d, %d dependencies not issued, depends on:", stuck->id, stuck->kind, stuck->key, stuck->dev,
+		        (int)stuck->issued.load(), stuck->pending.load());
+		for (Task *d : stuck->deps) fprintf(stderr, " #%ld(kind %d, %s)", d->id, d->kind, d->issued.load() ? "issued" : "NOT issued");
+		fprintf(stderr, "\n");
+	}
+	for (int d = 0; d < kMaxDevices; ++d) {
+		DevState *D = devs[d];
+		if (!D) continue;
+		std::unique_lock<std::mutex> lk(D->m, std::try_to_lock);
+		if (!lk.owns_lock()) { fprintf(stderr, "  device %d: its lock is HELD (a worker is inside the queues)\n", d); continue; }
+		if (D->workers.empty() && !D->used) continue;
+		size_t local = 0; for (auto &q : D->local) local += q.size();
+		fprintf(stderr, "  device %d: %zu worker(s), ready %zu, local %zu, staged %ld in %zu group(s), busy regular %d / batch %d, group takers idle %d\n", d, D->workers.size(),
+		        D->ready.size(), local, D->stagedCount, D->staged.size(), D->busyRegular, D->busyBatch, D->batchIdle);
+		for (auto &g : D->staged) {
+			auto gp = D->groupPending.find(g.first);
+			fprintf(stderr, "    group kind %d key %ld: %zu staged (oldest #%ld), %ld still on their way%s\n", g.first.kind, g.first.key, g.second.q.size(),
+			        g.second.q.empty() ? -1L : g.second.q.front()->id, gp == D->groupPending.end() ? 0L : gp->second, g.second.fromClient ? ", fed by the client" : "");
+		}
+		for (auto &gp : D->groupPending) if (!D->staged.count(gp.first)) fprintf(stderr, "    group kind %d key %ld: nothing staged, %ld on their way\n", gp.first.kind, gp.first.key, gp.second);
+	}
+	fflush(stderr);
+}
+// cvDone.wait with the watchdog; doneMu held through lk
+template <typename Pred> void waitDone(std::unique_lock<std::mutex> &lk, const char *where, Task *stuck, Pred pred) {
+	const long limit = watchdogSeconds();
+	if (limit <= 0) { cvDone.wait(lk, pred); return; }
+	long seen = issuedTotal.load(std::memory_order_relaxed);
+	auto since = clk::now();
+	while (!pred()) {
+		cvDone.wait_for(lk, std::chrono::seconds(1));
+		const long now = issuedTotal.load(std::memory_order_relaxed);
+		if (now != seen) { seen = now; since = clk::now(); continue; }
+		if (std::chrono::duration_cast<std::chrono::seconds>(clk::now() - since).count() >= limit && !pred()) {
+			lk.unlock(); dumpState(where, stuck); lk.lock();
+			since = clk::now();
+		}
+	}
+}
+
 struct AtExit { ~AtExit() {                 // idle workers must not outlive the process's static state
 	if (tlsWorker) { for (DevState *D : devs) if (D) for (auto &w : D->workers) w.detach(); return; }      // exit(-1) from a failed call inside a task: nothing to wait for
 	stopping.store(true);
@@ -454,10 +504,6 @@ void start(int n) {
 	if (active.load()) return;
 	if (n <= 0) { const char *e = getenv("CUHE_SCHED_THREADS"); n = e ? atoi(e) : 0; }
 	if (n <= 0) n = 3;                          // per device.  PRINCE gate by gate on one device: profiles/r05_sched_prince.txt
-	// at least two: with ONE worker per device (CUHE_SCHED_THREADS=1) tests/cxx/test_cuhe_api stalled on the GPU box in round 5 (four runs of four, 120 s
-	// limit each; the CPU harness runs its programs with one worker without a stall and the cause was not found before the GPU time ran out).  Two and
-	// more are what every measurement and test of this layer used.
-	if (n < 2) n = 2;
 	workersPerDev = n;
 	stopping.store(false);
 	if (getenv("CUHE_SCHED_LOCAL")) stealing = atoi(getenv("CUHE_SCHED_LOCAL"));
@@ -474,7 +520,7 @@ void start(int n) {
 void drain() {
 	{
 		std::unique_lock<std::mutex> lk(doneMu);
-		cvDone.wait(lk, [] { return outstanding.load(std::memory_order_acquire) == 0; });
+		waitDone(lk, "drain()", nullptr, [] { return outstanding.load(std::memory_order_acquire) == 0; });
 	}
 	for (int d = 0; d < kMaxDevices; ++d) {
 		DevState *D = devs[d];
@@ -490,7 +536,9 @@ void *taskAlloc(int dev, size_t bytes) {
 	if (dev < 0 || dev >= kMaxDevices) return cuhe_hip_malloc(dev, bytes);
 	BlockCache &C = caches[dev];
 	Block b{nullptr, {}, 0};
-	{
+	//  a thread that has no stream on `dev` -- work on another device inside a task (after moveTo / copyTo), a thread that is not a
+	// worker -- cannot be ordered behind a cached block's last use: it takes a fresh block from the library, never one of the cache's
+	if (me) {
 		std::lock_guard<std::mutex> lk(C.m);
 		C.checkGeneration();
 		auto it = C.bySize.find(bytes);
@@ -504,7 +552,7 @@ void *taskAlloc(int dev, size_t bytes) {
 		} else ++C.misses;
 	}
 	if (b.ptr) {
-		if (me) for (int k = 0; k < b.npos; ++k) if (b.pos[k].ss != me) orderAfter(dev, me, b.pos[k].ss, b.pos[k].seq);
+		for (int k = 0; k < b.npos; ++k) if (b.pos[k].ss != me) orderAfter(dev, me, b.pos[k].ss, b.pos[k].seq);
 		return b.ptr;
 	}
 	void *p = cuhe_hip_malloc(dev, bytes);
@@ -536,8 +584,9 @@ bool taskFree(int dev, void *p) {
 	std::unique_lock<std::mutex> lk(C.m);
 	C.checkGeneration();
 	auto it = C.sizeOf.find(p);
-	if (it == C.sizeOf.end() || !me) {                              // not one of ours (allocated before the object was attached)
-		lk.unlock();
+	if (it == C.sizeOf.end() || !me) {                              // not one of ours (allocated before the object was attached), or no stream here to
+		if (it != C.sizeOf.end()) C.sizeOf.erase(it);                 // date its last use with: the library takes it back, and must not find a stale size
+		lk.unlock();                                                  // here when it hands the pointer out again
 		if (R) orderReleaseStream(R);
 		return false;
 	}
@@ -674,7 +723,7 @@ Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *
 void wait(Task *t) {
 	{
 		std::unique_lock<std::mutex> lk(doneMu);
-		cvDone.wait(lk, [t] { return t->issued.load(std::memory_order_acquire); });
+		waitDone(lk, "wait()", t, [t] { return t->issued.load(std::memory_order_acquire); });
 	}
 	StreamState *ss = t->ss;
 	thread_local std::vector<void *> mine;      // per client thread and device

@@ -105,6 +105,10 @@ int cuhe_hip_set_alloc_cache(size_t bytes);
 /* diagnostics: out4 = { hipMalloc calls, allocations served from the settled pool, from the caller stream's parked blocks,
    blocks handed over from another stream's parked set behind an event } since the library was loaded */
 int cuhe_hip_alloc_counters(long long *out4);
+/* test hook (failure injection): the (n+1)-th allocation from now on -- cuhe_hip_malloc or cuhe_hip_malloc_stream reaching it -- fails the
+   way an exhausted device does (returns NULL, cuhe_hip_last_error names it); n < 0 switches the hook off.  The reference's reaction to
+   a failed cudaMalloc is CSC: message + exit(-1) (cuhe/Debug.h:35-66), which is what the C++ layer does with the NULL. */
+int cuhe_hip_set_alloc_fail_after(long n);
 /* counts the cuhe_hip_shutdown calls so far: every device block the library handed out before a shutdown is gone with it */
 unsigned long long cuhe_hip_generation(void);
 /* stream-ordered variants: a block freed with free_stream is reused only by malloc_stream calls for the same stream
@@ -405,6 +409,11 @@ int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch
  * ticks of a wave per microsecond of kernel time) and the issue cost (*cycles_per_instr: shader cycles per wave-instruction and
  * SIMD).  No counterpart in the reference; a diagnostic, never on the product path. */
 int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_instr_per_s, double *shader_mhz, double *cycles_per_instr);
+/* The streaming-copy ceiling of the box (bench.py roofline.measured_copy_GBs): a grid-stride copy of `bytes` bytes with 16-byte accesses,
+ * 2048 workgroups, `reps` timed launches between hipEvents; *gb_per_s = (bytes read + bytes written) / time.  variant: 0 one float4 per
+ * iteration, 1 four loads then four stores, 2 the same with non-temporal accesses, 3 eight loads then eight stores.  A diagnostic like
+ * cuhe_hip_probe_valu; the HBM-bound kernels of the path (key stream, ICRT, pointwise) are priced against its best figure. */
+int cuhe_hip_probe_copy(int dev, size_t bytes, int variant, int reps, double *gb_per_s);
 
 /* ---- field arithmetic test hooks (tests/test_ModP.cu:50-135): elementwise over n u64 */
 int cuhe_hip_modp_add(uint64_t *z, const uint64_t *x, const uint64_t *y, size_t n, int dev, void *stream);

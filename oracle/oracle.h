@@ -39,6 +39,8 @@ int orc_set_threads(int n);
 uint64_t orc_add_modP(uint64_t x, uint64_t y);
 uint64_t orc_sub_modP(uint64_t x, uint64_t y);
 uint64_t orc_mul_modP(uint64_t x, uint64_t y);
+uint64_t orc_add_modP_div(uint64_t x, uint64_t y);   /* (x + y) % P and (x * y) % P by 128-bit division: cross-checks of the fold only */
+uint64_t orc_mul_modP_div(uint64_t x, uint64_t y);
 uint64_t orc_ls_modP(uint64_t x, int l);      /* x * 2^l mod P, any l >= 0 */
 uint64_t orc_pow_modP(uint64_t x, uint64_t e);
 
@@ -49,6 +51,8 @@ void orc_ntt_naive(uint64_t *dst, const uint32_t *src, int len);
 void orc_ntt_ext(uint64_t *dst, const uint32_t *src, int len);
 /* `batch` independent orc_ntt_ext on `threads` OpenMP threads (0 = all); returns threads used */
 int orc_ntt_ext_batch(uint64_t *dst, const uint32_t *src, int len, int batch, int threads);
+/* the same transforms with per-length tables shared by the batch (the throughput form a host library would use; bench.py cpu_baseline) */
+int orc_ntt_ext_fast_batch(uint64_t *dst, const uint32_t *src, int len, int batch, int threads);
 /* full-length forward transform of u64 input (helper) */
 void orc_ntt_full(uint64_t *dst, const uint64_t *src, int len);
 /* x[j] = (len^-1 * sum_i X[i] w^(-ij) mod P) mod p  -- cuhe/Base.cu:438-490 */

@@ -178,6 +178,7 @@ int main(int argc, char **argv) {
 	multiGPUs(ndev);
 	Dhs dhs;
 	dhs.setup(25, 2, 16, 25, 25, 21845);
+	if (!getenv("CUHE_SCHED")) setScheduled(false);         // this client issues whole layers itself; CUHE_SCHED=1 in the environment runs it on scheduled gates all the same (tools/sched_soak.sh)
 	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey);
 	for (int pass = 0; pass < (repeat > 1 ? repeat : 1); ++pass) {
 	Machine M(dhs, ndev);

@@ -27,7 +27,7 @@
 // default stream, one gate per call -- and the library runs the independent gates concurrently (W worker threads, each on
 // its own stream, ordered by events).  Meant for --threads 1.
 //
-// usage: test_prince_flow [--no-round-checks] [--threads T] [--async | --sched [W] | --compare] [--repeat N] [--devices N [--virtual]]
+// usage: test_prince_flow [--no-round-checks] [--threads T] [--async | --sched [W] | --compare | --default] [--repeat N] [--devices N [--virtual]]
 #include "dhs_client.hpp"
 #include "prince_common.hpp"
 #include "sample_profiler.hpp"
@@ -240,12 +240,13 @@ struct Evaluator {
 };
 
 int main(int argc, char **argv) {
-	bool checkRounds = true, async = false, virtualDevices = false, scheduledGates = false, compare = false, profile = false; int threads = 8, devices = 1, schedWorkers = 0, repeat = 1;
+	bool checkRounds = true, async = false, virtualDevices = false, scheduledGates = false, compare = false, profile = false, libraryDefault = false; int threads = 8, devices = 1, schedWorkers = 0, repeat = 1;
 	for (int i = 1; i < argc; ++i) {
 		if (std::string(argv[i]) == "--no-round-checks") checkRounds = false;
 		else if (std::string(argv[i]) == "--threads" && i + 1 < argc) threads = atoi(argv[++i]);
 		else if (std::string(argv[i]) == "--async") async = true;
 		else if (std::string(argv[i]) == "--compare") compare = true;
+		else if (std::string(argv[i]) == "--default") libraryDefault = true;      // no setScheduled call at all: what an UNCHANGED reference client gets (scheduled gates since round 6; CUHE_SCHED=0: synchronous)
 		else if (std::string(argv[i]) == "--repeat" && i + 1 < argc) repeat = atoi(argv[++i]);      // the block N times in one process (the mode stays on: warm scratch from the second on)
 		else if (std::string(argv[i]) == "--profile") profile = true;          // host-side sampling profile of the encryption (tests/cxx/sample_profiler.hpp)
 		else if (std::string(argv[i]) == "--sched") { scheduledGates = true; if (i + 1 < argc && argv[i + 1][0] != '-') schedWorkers = atoi(argv[++i]); }
@@ -271,6 +272,7 @@ int main(int argc, char **argv) {
 	printf("DHS(25,2,16,25,25,21845): n=%d nttLen=%d primes=%d evalKeys=%d   key generation %.2f s\n", dhs.n, param.nttLen, param.numCrtPrime, param.numEvalKey,
 	       std::chrono::duration<double>(t1k - t0).count());
 
+	if (!libraryDefault) setScheduled(false);               // every other mode of this program chooses for itself (initCuHE switches scheduled gates on by default)
 	Pool pool(threads, devices);
 	// --compare: the same block twice in one process (one key generation): first with the reference's synchronous gates,
 	// then with scheduled gates; bench.py reads the two "Prince Encryption" lines
@@ -312,7 +314,7 @@ int main(int argc, char **argv) {
 	if (numAnd != 1920 || numRelin != 1152 || ev.level != 24) { printf("unexpected operation counts\n"); ++failures; }
 	printf("Prince Encryption: %.3f s on %d %sdevice(s) with %d host thread(s), %s gates (round checks excluded)\n", encSeconds, devices, virtualDevices ? "virtual " : "", threads,
 	       isScheduled() ? "scheduled" : async ? "asynchronous" : "synchronous");
-	if (isScheduled() && pass + 1 == passes) { setScheduled(false); }
+	if (isScheduled() && pass + 1 == passes && !libraryDefault) { setScheduled(false); }
 	}
 	stopAllocator();
 	printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);

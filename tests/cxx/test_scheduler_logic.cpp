@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <random>
@@ -37,6 +38,7 @@ std::vector<Stream *> streams;
 int numGpus = 1;
 std::atomic<long> eventRecords{0}, streamWaits{0}, mallocs{0}, frees{0};
 unsigned long long generation = 1;
+void *recycled = nullptr; bool recycle = false;
 void join(Clock &a, const Clock &b) { for (auto &kv : b) if (a[kv.first] < kv.second) a[kv.first] = kv.second; }
 // a task's device work enqueued on `stream`: returns the stamp (the stream's clock including this launch)
 Clock launch(void *stream) {
@@ -73,8 +75,14 @@ int cuhe_hip_stream_wait_event(int dev, void *st, void *ev) {
 }
 int cuhe_hip_event_sync(int, void *) { return 0; }
 int cuhe_hip_device_sync(int) { return 0; }
-void *cuhe_hip_malloc(int, size_t bytes) { ++mock::mallocs; return malloc(bytes ? bytes : 1); }
-int cuhe_hip_free(int, void *p) { ++mock::frees; free(p); return 0; }
+// (mock::recycle: the next cuhe_hip_free keeps the pointer and the next cuhe_hip_malloc hands the SAME address out again whatever the size --
+// what a real allocator may do at any time -- for the stale-size check of crossDeviceBlocks)
+void *cuhe_hip_malloc(int, size_t bytes) {
+	++mock::mallocs;
+	if (mock::recycled) { void *p = mock::recycled; mock::recycled = nullptr; return p; }
+	return malloc(bytes < 65536 ? 65536 : bytes);
+}
+int cuhe_hip_free(int, void *p) { ++mock::frees; if (mock::recycle && !mock::recycled) { mock::recycled = p; mock::recycle = false; return 0; } free(p); return 0; }
 int cuhe_hip_alloc_counters(long long *out4) { for (int i = 0; i < 4; ++i) out4[i] = 0; return 0; }
 }
 
@@ -175,14 +183,14 @@ void batchRunner(int kind, sched::Node *const *subjects, sched::Node *const *, s
 }
 
 // one random program: `nodes` polynomials spread over `ndev` devices, `ngates` gates
-void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int policyNo, int cap, bool blocks = false) {
+void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int policyNo, int cap, bool blocks = false, int workers = 3) {
 	mock::numGpus = ndev;
 	blocksOn = blocks; blk.assign(nodesN, nullptr); uses.clear();
 	setenv("CUHE_SCHED_POLICY", std::to_string(policyNo).c_str(), 1);
 	sched::setBatchRunner(batches ? batchRunner : nullptr, cap);
-	sched::start(3);
+	sched::start(workers);
 	if (!sched::on()) fail("start() did not switch the mode on");
-	if (sched::threads() < 3 * ndev) fail("fewer workers than 3 per device", sched::threads(), ndev);
+	if (sched::threads() != workers * ndev) fail("not the number of workers per device that was asked for", sched::threads(), ndev);
 	std::mt19937 rng(seed);
 	std::vector<sched::Node *> nodes(nodesN);
 	std::vector<int> nodeDev(nodesN), lastWrite(nodesN, -1);
@@ -242,6 +250,39 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 	sched::stop();
 	if (sched::on() || sched::threads() != 0) fail("stop() left workers behind");
 	blocksOn = false;
+}
+//  blocks and threads that have no stream on the block's device.  A task of device 0 that allocates on device 1 (work after a moveTo /
+// copyTo) cannot be ordered behind the last use of a block in device 1's cache: it must get a FRESH block from the library, and handing it
+// back must leave no size entry behind -- the library may issue the same address again with another size, and the block must then be cached
+// under ITS size.
+void crossDeviceBlocks() {
+	mock::numGpus = 2;
+	sched::setBatchRunner(nullptr, 1);
+	sched::start(2);
+	sched::Node *n0 = sched::newNode(nullptr), *n1 = sched::newNode(nullptr);
+	void *cached = nullptr, *foreign = nullptr, *again = nullptr, *small = nullptr;
+	auto on = [&](int dev, sched::Node *n, std::function<void()> f) { sched::wait(sched::submit(dev, {}, std::vector<sched::Node *>(1, n), [f](void *s) { mock::launch(s); f(); }, true)); };
+	on(1, n1, [&] { cached = sched::taskAlloc(1, 4096); if (!sched::taskFree(1, cached)) fail("a worker of device 1 could not hand its own block back"); });
+	const long m0 = mock::mallocs.load();
+	on(0, n0, [&] {
+		foreign = sched::taskAlloc(1, 4096);                      // a worker of device 0: no stream on device 1
+		if (foreign == cached) fail("a thread without a stream on the device got a cached block (nothing orders it behind the block's last use)");
+		if (mock::mallocs.load() != m0 + 1) fail("the cross-device allocation did not come from the library");
+		if (sched::taskFree(1, foreign)) fail("taskFree kept a block although the caller has no stream on that device");
+		mock::recycle = true; cuhe_hip_free(1, foreign);          // what devFree does when taskFree says no; the mock re-issues this address next
+	});
+	on(1, n1, [&] {
+		if (sched::taskAlloc(1, 4096) != cached) fail("the cached block of device 1 is gone");
+		again = sched::taskAlloc(1, 8192);                        // the library hands the old address out with another size
+		if (again != foreign) fail("mock did not recycle the address");
+		if (!sched::taskFree(1, again)) fail("taskFree refused a block taskAlloc handed out");
+		small = sched::taskAlloc(1, 4096);
+		if (small == again) fail("a block was cached under the size a stale entry remembered: an 8192-byte block came back for 4096");
+		if (sched::taskAlloc(1, 8192) != again) fail("the re-issued block is not cached under its own size");
+	});
+	sched::drain();
+	sched::releaseNode(n0); sched::releaseNode(n1);
+	sched::stop();
 }
 }  // namespace
 
@@ -358,8 +399,14 @@ int main(int argc, char **argv) {
 					if (ndev <= 2) {          // the same program with device blocks taken, used and released inside the tasks
 						program(ndev, 40 + 10 * ndev, 3000, 7000u * round + 100u * ndev + 10u * pol + batches, batches != 0, pol, batches ? 64 : 1, true);
 						++programs;
+						// ... and with ONE and TWO workers per device (CUHE_SCHED_THREADS=1: the single worker runs the regular tasks AND takes the groups)
+						for (int workers : {1, 2}) {
+							program(ndev, 40 + 10 * ndev, 1500, 9000u * round + 100u * ndev + 10u * pol + batches + 1000u * workers, batches != 0, pol, batches ? 32 : 1, workers == 1, workers);
+							++programs;
+						}
 					}
 				}
+	crossDeviceBlocks();
 	if (blocksTaken.load() < 1000 || blocksReused.load() * 4 < blocksTaken.load() || blocksReleased.load() * 2 < blocksTaken.load())
 		fail("the block model did not exercise reuse", (int)blocksTaken.load(), (int)blocksReused.load());
 	printf("blocks: %ld taken inside tasks, %ld of them had been used before, %ld released by release-only tasks\n", blocksTaken.load(), blocksReused.load(), blocksReleased.load());

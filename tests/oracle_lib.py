@@ -52,6 +52,9 @@ def lib():
         for f in ("orc_ntt_naive", "orc_ntt_ext", "orc_ntt_full"):
             getattr(L, f).restype = None; getattr(L, f).argtypes = [vp, vp, i32]
         L.orc_ntt_ext_batch.restype = i32; L.orc_ntt_ext_batch.argtypes = [vp, vp, i32, i32, i32]
+        L.orc_ntt_ext_fast_batch.restype = i32; L.orc_ntt_ext_fast_batch.argtypes = [vp, vp, i32, i32, i32]
+        for f in ("orc_add_modP_div", "orc_mul_modP_div"):
+            getattr(L, f).restype = u64; getattr(L, f).argtypes = [u64, u64]
         L.orc_intt_modp.restype = None; L.orc_intt_modp.argtypes = [vp, vp, i32, u32]
         L.orc_set_param.restype = i32
         L.orc_set_param.argtypes = [C.POINTER(Params)] + [i32] * 6
@@ -124,6 +127,17 @@ def ntt_ext_batch(x, length, threads=0):
     batch = x.shape[0]
     out = np.empty((batch, length), dtype=np.uint64)
     used = lib().orc_ntt_ext_batch(_p(out), _p(x), length, batch, threads)
+    return out, used
+
+
+def ntt_ext_fast_batch(x, length, threads=0):
+    """the same transforms through the table-sharing throughput form (bench.py cpu_baseline): (u64[batch][length], threads used)"""
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    batch = x.shape[0]
+    out = np.empty((batch, length), dtype=np.uint64)
+    used = lib().orc_ntt_ext_fast_batch(_p(out), _p(x), length, batch, threads)
+    if used < 0:
+        raise RuntimeError("orc_ntt_ext_fast_batch: no table slot for length %d" % length)
     return out, used
 
 

@@ -71,3 +71,28 @@ def test_live_pmc_record_is_read_back_from_a_rocpd_database(tmp_path, monkeypatc
     assert rec["valu_lane_instructions_per_transform"] == int(40188928.0 * 32 * 64 / B)
     monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: subprocess.CompletedProcess(cmd, 1, "", "boom"))
     assert bench.measure_traffic_live(L, B, 0) is None
+
+
+def test_sharded_value_is_refused_unless_every_rank_reports_a_communicator_of_the_whole_job():
+    """bench.py --gpus N prints `mul_relin_sharded.value` under the claim "one RCCL all-gather inside the library" only when every rank's
+    ncclCommCount (and the library's own view) equals N (cuhe/CuHE.cu:217-256 is the multi-GPU path it stands for)."""
+    import bench
+
+    def info(rank, cnt, lib_ranks=None, urank=None, state="initialised"):
+        return ("rank %d: comm_init ok; rccl 22606; communicator %s; ncclCommCount %d, ncclCommUserRank %d (library: %d ranks, rank %d); exchanges so far 0 "
+                "(ncclAllGather in place 0, padded 0, broadcast group 0), last: none") % (rank, state, cnt, rank if urank is None else urank,
+                                                                                         cnt if lib_ranks is None else lib_ranks, rank)
+    for world in (2, 4, 8):
+        good = [info(r, world) for r in range(world)]
+        assert bench.sharded_comm_guard(good, world, True) is None
+        assert bench.sharded_comm_guard(good, world, False) is None                     # torch.distributed exchange: nothing claimed
+        one_rank_comms = [info(r, 1) for r in range(world)]                              # every rank alone in its own communicator
+        assert "ncclCommCount 1" in bench.sharded_comm_guard(one_rank_comms, world, True)
+        short = good[:-1] + [info(world - 1, world - 1)]
+        assert "rank %d" % (world - 1) in bench.sharded_comm_guard(short, world, True)
+        assert bench.sharded_comm_guard(good[:-1] + [None], world, True) is not None     # a rank's report is missing
+        assert bench.sharded_comm_guard(good[:-1], world, True) is not None
+        assert bench.sharded_comm_guard([info(0, world)] + [info(r, world, urank=0) for r in range(1, world)], world, True) is not None
+        assert bench.sharded_comm_guard([info(r, world, state="not initialised") for r in range(world)], world, True) is not None
+        assert bench.sharded_comm_guard([info(r, world, lib_ranks=1) for r in range(world)], world, True) is not None
+    assert bench.sharded_comm_guard(["RCCL unavailable: librccl.so not found"] * 2, 2, True) is not None

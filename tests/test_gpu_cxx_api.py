@@ -21,7 +21,7 @@ def test_cxx_api_program(sched):
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_cuhe_api")
-    env = dict(os.environ, CUHE_SCHED="1", CUHE_SCHED_CHECK="1") if sched else dict(os.environ)
+    env = dict(os.environ, CUHE_SCHED="1", CUHE_SCHED_CHECK="1") if sched else dict(os.environ, CUHE_SCHED="0")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -43,19 +43,22 @@ def test_dhs_scheme_flow(params, sched):
     cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_dhs_flow")
-    env = dict(os.environ, CUHE_SCHED="1", CUHE_SCHED_CHECK="1") if sched else dict(os.environ)
+    env = dict(os.environ, CUHE_SCHED="1", CUHE_SCHED_CHECK="1") if sched else dict(os.environ, CUHE_SCHED="0")
     r = subprocess.run([exe] + [str(v) for v in params], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
+    # checkKeys (examples/DHS/simple_DHS.cu:165-205): second / third scheme objects from key strings in the same process, then the first again
+    assert "keys\tright" in r.stdout and "and after re-initialisation\tright" in r.stdout and "generation unchanged" in r.stdout
 
 
 @pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"],
                                    ["--threads", "6", "--async", "--devices", "3", "--virtual"],
                                    ["--threads", "1", "--sched"], ["--threads", "1", "--sched", "3", "--devices", "3", "--virtual"],
-                                   ["--threads", "1", "--sched", "5", "--no-batching"]],
+                                   ["--threads", "1", "--sched", "5", "--no-batching"], ["--threads", "1", "--default"], ["--threads", "1", "--sched", "1"]],
                          ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices",
-                              "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices", "scheduled-1-thread-no-batching"])
+                              "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices", "scheduled-1-thread-no-batching",
+                              "library-default-1-thread", "scheduled-1-thread-1-worker"])
 def test_prince_known_answer(flags):
     """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
     reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
@@ -76,6 +79,7 @@ def test_prince_known_answer(flags):
     subprocess.check_call(["make", "-C", cxx, "-s", "test"])
     exe = os.path.join(ROOT, "cuhe_amd", "lib", "test_prince_flow")
     env = dict(os.environ, CUHE_SCHED_CHECK="1")
+    env.pop("CUHE_SCHED", None)
     if "--no-batching" in flags:                    # every recorded gate runs its own closure (CUHE_SCHED_BATCH=0): the path the batches replace
         env["CUHE_SCHED_BATCH"] = "0"
         flags = [f for f in flags if f != "--no-batching"]
@@ -85,8 +89,10 @@ def test_prince_known_answer(flags):
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
     assert r.stdout.count("right") == (1 if "--no-round-checks" in flags else 13)
-    if "--sched" in flags:
+    if "--sched" in flags or "--default" in flags:    # --default: no setScheduled call and no environment variable -- what an unchanged reference client gets
         assert "scheduled gates" in r.stdout
+    else:
+        assert "scheduled gates" not in r.stdout
 
 
 def test_prince_known_answer_on_arrays():
@@ -147,3 +153,53 @@ def test_prince_known_answer_on_cxx_array_classes(flags):
     assert "ALL PASSED" in r.stdout and "wrong" not in r.stdout
     assert "homomorphic PRINCE: 9fb51935fc3df524" in r.stdout
     assert r.stdout.count("right") == (1 if "--no-round-checks" in flags else 13)
+
+
+def _soak_exe():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    import __graft_entry__ as ge
+    ge.build()
+    cxx = os.path.join(ROOT, "cuhe_amd", "cxx")
+    subprocess.check_call(["make", "-C", cxx, "-s", "test"])
+    return os.path.join(ROOT, "cuhe_amd", "lib", "test_sched_soak")
+
+
+@pytest.mark.parametrize("mode", ["default", "CUHE_SCHED=0", "CUHE_SCHED_THREADS=1"])
+def test_scheduler_soak_conditions(mode):
+    """tests/cxx/test_sched_soak.cpp: operands destroyed while their gates are queued, setScheduled(false) with work queued and a restart,
+    a raw pointer read right after a gate was recorded (the reference's observable synchronous semantics, cuhe/CuHE.cu:98,121,139,157),
+    two client threads, a second initCuHE on the same ring with gates queued -- on the library's default (scheduled gates since round 6:
+    no environment variable, no setScheduled call), on synchronous gates, and with ONE worker per device."""
+    exe = _soak_exe()
+    env = dict(os.environ, CUHE_SCHED_CHECK="1")
+    env.pop("CUHE_SCHED", None)
+    if "=" in mode:
+        k, v = mode.split("=")
+        env[k] = v
+    r = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout and "wrong" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ("gates are synchronous" if mode == "CUHE_SCHED=0" else "gates are scheduled") in r.stdout
+    assert "watchdog" not in r.stderr
+
+
+@pytest.mark.parametrize("sched", ["default", "CUHE_SCHED=0"])
+@pytest.mark.parametrize("n", [0, 3, 40, 150])
+def test_allocation_failure_ends_the_program_like_the_reference(n, sched):
+    """failure injection (cuhe_hip_set_alloc_fail_after): the (n+1)-th device allocation fails -- inside a recorded gate, inside a batch
+    of the scheduler, or on the client thread.  The reference's convention for a failed cudaMalloc is CSC: a message and exit(-1)
+    (cuhe/Debug.h:35-66); the program must end that way within seconds, on scheduled and on synchronous gates: no hang, no crash."""
+    import time
+    exe = _soak_exe()
+    env = dict(os.environ)
+    env.pop("CUHE_SCHED", None)
+    if sched != "default":
+        env["CUHE_SCHED"] = "0"
+    t0 = time.time()
+    r = subprocess.run([exe, "allocfail", str(n)], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 255, (r.returncode, r.stdout[-1000:], r.stderr[-1000:])          # exit(-1)
+    assert "cuheSafeCall() failed" in r.stderr and "injected" in r.stderr
+    assert time.time() - t0 < 120

@@ -434,6 +434,49 @@ def test_config3_full_size_properties(gu, nc):
         g.close()
 
 
+@pytest.mark.parametrize("nc", [True, False], ids=["negacyclic", "cyclic"])
+def test_config3_full_size_vs_oracle(gu, nc):
+    """BASELINE config 3 AT FULL SIZE against the oracle, every coefficient (this comparison used to live only inside
+    bench.py): N = 2^15 (x^32768 + 1), 32 CRT primes, the full multiply raw -> raw = CRT -> NTT -> pointwise -> INTT -> ICRT
+    (cuhe/CuHE.cu:259-268 mulZZX; examples/DHS/DHS.cu:219-221 is the host arithmetic it stands for), in the negacyclic ciphertext
+    domain and in the reference's cyclic one (through the ciphertext-domain entry points AND through ntt / nttMul / inttMod), on
+    reduced random operands, on unreduced ones (every word 32 random bits, what bench.py times), and for three operand pairs per call
+    (cuhe_hip_mul_raw_batch).  The oracle runs with OpenMP over the primes (0.3 s per multiply on the GPU box's cores)."""
+    import oracle_lib as O
+    args = (9, 2, 16, 576, 24, 65536)
+    g, o = gu.GpuCtx(*args, negacyclic=nc), O.Ctx(*args)
+    used = O.set_threads(0)
+    try:
+        q = g.prm
+        assert q.nttLen == 65536 and q.numCrtPrime == 32 and q.modLen == 32768 and g.nc == nc and used >= 1
+        W, M = g.words(0), g.coeff_modulus(0)
+        a, _ = O.random_raw(q.rawLen, q.modLen, W, M, 0xC3A0)
+        b, _ = O.random_raw(q.rawLen, q.modLen, W, M, 0xC3B0)
+        want = o.mul_raw(a, b, 0)
+        assert np.array_equal(g.mul_raw(a, b, 0), want)
+        if not nc:
+            assert np.array_equal(g.mul_raw(a, b, 0, cyclic_api=True), want)
+        rng = np.random.default_rng(0xC3)
+        pairs = [(rng.integers(0, 1 << 32, (q.rawLen, W), dtype=np.uint64).astype(np.uint32),
+                  rng.integers(0, 1 << 32, (q.rawLen, W), dtype=np.uint64).astype(np.uint32)) for _ in range(3)]
+        wants = [o.mul_raw(x, y, 0) for x, y in pairs]
+        assert np.array_equal(g.mul_raw(*pairs[0], 0), wants[0])
+        da = gu.to_dev(np.concatenate([x for x, _ in pairs])); db = gu.to_dev(np.concatenate([y for _, y in pairs]))
+        out = gu.empty_u32(3 * q.rawLen, W)
+        gu.ck(gu.lib.cuhe_hip_mul_raw_batch(out.data_ptr(), da.data_ptr(), db.data_ptr(), 0, 3, 0, None))
+        got = gu.host_u32(out)
+        for i in range(3):
+            assert np.array_equal(got[i * q.rawLen:(i + 1) * q.rawLen], wants[i]), i
+        # one level down: 31 primes, one coefficient word less
+        W1, M1 = g.words(1), g.coeff_modulus(1)
+        a1, _ = O.random_raw(q.rawLen, q.modLen, W1, M1, 0xC3A1)
+        b1, _ = O.random_raw(q.rawLen, q.modLen, W1, M1, 0xC3B1)
+        assert np.array_equal(g.mul_raw(a1, b1, 1), o.mul_raw(a1, b1, 1))
+    finally:
+        O.set_threads(1)
+        g.close(); o.close()
+
+
 @pytest.mark.parametrize("name", ["toy1155", "prince_small", "pow2_32768", "phi32767", "prime32749"])
 def test_prime_range_entry_points(gu, name):
     """CRT-prime-sharded entry points (cuhe_hip_*_range / *_rows): two shards computed one after the other on one

@@ -181,3 +181,39 @@ def test_barrett_restatement_equals_exact_remainder(args):
     hold = c.intt_hold(c.ntt_mul(c.ntt(a), c.ntt(a)))
     assert np.array_equal(c.barrett(hold), c.poly_reduce_exact(hold))
     c.close()
+
+
+def test_fold_reduction_equals_division_and_python_ints():
+    """Round 6: the oracle reduces 128-bit values with the fold 2^64 = 2^32 - 1, 2^96 = -1 (mod P) the reference's field arithmetic uses
+    (cuhe/ModP.h:249-289) instead of `u128 % P`.  Checked against the division forms kept for this purpose and against Python integers on
+    random operands, on every pair of edge values (including unreduced ones: P, P + 1, 2^64 - 1) and on the products that exercise each
+    branch of the fold (borrow of hh, carry of the middle term, result in [P, 2^64))."""
+    import random
+    import oracle_lib as O
+    L = O.lib()
+    P = O.P
+    edge = [0, 1, 2, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, P - 2, P - 1, P, P + 1, (1 << 64) - 2, (1 << 64) - 1, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF,
+            0xFFFFFFFE00000001, 0xFFFFFFFEFFFFFFFF, 1 << 63, (1 << 63) + 1]
+    pairs = [(x, y) for x in edge for y in edge]
+    rnd = random.Random(6)
+    pairs += [(rnd.getrandbits(64), rnd.getrandbits(64)) for _ in range(20000)]
+    pairs += [(rnd.getrandbits(64), rnd.getrandbits(k)) for k in (1, 31, 32, 33) for _ in range(2000)]
+    for x, y in pairs:
+        assert L.orc_mul_modP(x, y) == L.orc_mul_modP_div(x, y) == x * y % P, (x, y)
+        assert L.orc_add_modP(x, y) == L.orc_add_modP_div(x, y) == (x + y) % P, (x, y)
+        assert L.orc_sub_modP(x, y) == (x - y) % P, (x, y)
+
+
+@pytest.mark.parametrize("length", [16384, 32768, 65536])
+def test_throughput_form_of_the_transform_equals_the_oracle_transform(length):
+    """orc_ntt_ext_fast_batch (tables shared by the batch; what bench.py times as cpu_baseline) against orc_ntt_ext on random rows, all-ones,
+    zero and unit rows, one and several threads."""
+    import oracle_lib as O
+    rng = np.random.default_rng(length)
+    x = rng.integers(0, 1 << 32, (5, length // 2), dtype=np.uint64).astype(np.uint32)
+    x[1] = 0xFFFFFFFF; x[2] = 0; x[3] = 0; x[3, 0] = 1
+    want = np.stack([O.ntt_ext(r, length) for r in x])
+    for threads in (1, 4):
+        got, used = O.ntt_ext_fast_batch(x, length, threads)
+        assert used >= 1 and np.array_equal(got, want)
+    assert (got[3] == 1).all() and not got[2].any()

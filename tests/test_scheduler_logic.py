@@ -37,7 +37,7 @@ def test_no_data_race_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     # CUHE_SCHED_QUIET_US=0: no timed waits -- the libtsan of gcc 11 does not intercept pthread_cond_clockwait (condition_variable::wait_for),
     # does not see the mutex released during such a wait and reports "double lock" / races on everything the mutex guards
-    run = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", CUHE_SCHED_QUIET_US="0"))
+    run = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0", CUHE_SCHED_QUIET_US="0", CUHE_SCHED_WATCHDOG_S="0"))   # (the watchdog's waits are timed too)
     assert "ALL PASSED" in run.stdout, (run.stdout[-2000:], run.stderr[-2000:])
     assert "ThreadSanitizer" not in run.stderr, run.stderr[-4000:]
 
