@@ -85,6 +85,7 @@ struct State {
     const char *last_path = "none yet"; long exchanges = 0;
     long path_count[4] = {0, 0, 0, 0};    // exchanges per path (cuhe_hip_comm_info)
     unsigned *stage = nullptr; size_t stage_words = 0; int stage_dev = -1;      // staging buffer of the padded all-gather
+    void *stage_event = nullptr, *stage_stream = nullptr; bool stage_used = false;   // its last use: the event recorded behind the unpack copies, and on which stream
 };
 inline State &state() { static State s; return s; }
 

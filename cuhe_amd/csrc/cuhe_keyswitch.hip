@@ -1031,6 +1031,8 @@ int cuhe_hip_comm_destroy(void) {
     comm::State &C = comm::state();
     if (C.comm) { comm::api().CommDestroy(C.comm); C.comm = nullptr; }
     if (C.stage) { (void)hipFree(C.stage); C.stage = nullptr; C.stage_words = 0; C.stage_dev = -1; }
+    if (C.stage_event) { (void)hipEventDestroy((hipEvent_t)C.stage_event); C.stage_event = nullptr; }
+    C.stage_used = false; C.stage_stream = nullptr;
     C.nranks = 1; C.rank = 0; C.force_exchange = 0; C.exchanges = 0; C.last_path = "none yet";
     for (long &n : C.path_count) n = 0;
     return CUHE_OK;
@@ -1068,7 +1070,8 @@ int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *st) {
     if (lvl < 0 || lvl >= G_.prm.depth) return fail(CUHE_EINVAL, "level %d", lvl);
     comm::State &C = comm::state();
     int force = C.comm ? C.force_exchange : 0;
-    if (const char *e = getenv("CUHE_EXCHANGE")) { if (!strcmp(e, "padded")) force = 2; else if (!strcmp(e, "bcast")) force = 3; }
+    // (the environment override applies to an existing communicator only: without one there is nothing to exchange and the call stays a no-op)
+    if (C.comm) if (const char *e = getenv("CUHE_EXCHANGE")) { if (!strcmp(e, "padded")) force = 2; else if (!strcmp(e, "bcast")) force = 3; }
     const int np = G_.prm.numCrtPrimeAt(lvl), cl = G_.prm.crtLen;
     const int path = comm::exchange_path(np, C.nranks, force);
     if (path == comm::kPathNone) { C.last_path = comm::path_name(path); return CUHE_OK; }
@@ -1087,6 +1090,10 @@ int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *st) {
             HIPCHK(hipMalloc((void **)&C.stage, need * sizeof(u32)));
             C.stage_words = need; C.stage_dev = dev;
         }
+        // ONE staging buffer per communicator: an exchange enqueued on another stream than the previous one is ordered behind the previous
+        // one's last read of the buffer (collectives of one communicator are issued in one order anyway; the copies around them are not)
+        if (!C.stage_event) HIPCHK(hipEventCreateWithFlags((hipEvent_t *)&C.stage_event, hipEventDisableTiming));
+        if (C.stage_used && C.stage_stream != st) HIPCHK(hipStreamWaitEvent(S(st), (hipEvent_t)C.stage_event, 0));
         int f, c; comm::shard_bounds(np, C.nranks, C.rank, &f, &c);
         u32 *mine = C.stage + (size_t)C.rank * slot;
         HIPCHK(hipMemcpyAsync(mine, rows + (size_t)f * cl, (size_t)c * cl * sizeof(u32), hipMemcpyDeviceToDevice, S(st)));
@@ -1097,6 +1104,8 @@ int cuhe_hip_allgather_rows(uint32_t *rows, int lvl, int dev, void *st) {
         if (extra) HIPCHK(hipMemcpy2DAsync(rows, (size_t)(base + 1) * cl * sizeof(u32), C.stage, pitch, (size_t)(base + 1) * cl * sizeof(u32), extra, hipMemcpyDeviceToDevice, S(st)));
         if (base) HIPCHK(hipMemcpy2DAsync(rows + (size_t)extra * (base + 1) * cl, (size_t)base * cl * sizeof(u32), C.stage + (size_t)extra * slot, pitch,
                                          (size_t)base * cl * sizeof(u32), C.nranks - extra, hipMemcpyDeviceToDevice, S(st)));
+        HIPCHK(hipEventRecord((hipEvent_t)C.stage_event, S(st)));
+        C.stage_used = true; C.stage_stream = st;
     } else {
         ncclResult_t r = A.GroupStart();
         if (r != ncclSuccess) return fail(CUHE_EHIP, "all-gather of CRT rows, rank %d of %d: ncclGroupStart: %s", C.rank, C.nranks, A.GetErrorString(r));

@@ -305,6 +305,15 @@ __device__ __forceinline__ void ow_store_half_nc(const u64 (&z)[32], void *dst_,
     }
 }
 
+// RowRebase (2 KB) travels BY VALUE in the kernel-argument segment of every launch, list or not: the GPU reads only `per` (one scalar
+// load) unless the launch is a list, the host copies 2 KB more per dispatch.  ADVICE r05 asked for the A/B: -DCUHE_OW_NO_REBASE_ARG builds
+// the kernels without the argument (list launches refused); launch-bound calls of 32 rows and the headline batch, both builds
+// alternating on one box: profiles/r06_rebase_arg_ab.txt.
+#ifdef CUHE_OW_NO_REBASE_ARG
+#define OW_RB_PARAM
+#else
+#define OW_RB_PARAM , RowRebase rb
+#endif
 // LGH: log2 of the sub-transform; HALF: the transform has 2^(LGH+1) points and this workgroup produces the outputs of one
 // parity -- of the zero-padded forward transform (a source with a zero upper half) or of a SPLIT full-length row (above).
 // TW1: HALF ? u64[2][Lh] (parity h at + h Lh) : u64[Lh].
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(OwGeom<(1 << LGH) / 1024>::T, 4)
 void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64 *__restrict__ TW1, const u64 *__restrict__ TW2,
                long src_stride, long dst_stride, int nbatch, int nstore, WindowArgs wa, const u64 *__restrict__ tw,
                const u32 *__restrict__ primes, const u64 *__restrict__ pinv, int prime0, int np_mod,
-               const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab, StreamTwistArgs ta, RowRebase rb) {
+               const u32 *__restrict__ aux, long aux_stride, FoldGeom fg, const u64 *__restrict__ xtab, StreamTwistArgs ta OW_RB_PARAM) {
     constexpr int R = (1 << LGH) / 1024;
     using G = OwGeom<R>;
     constexpr int T = G::T, Lh = G::Lh;
@@ -335,11 +344,13 @@ void ntt_onewg(void *__restrict__ dst_, const void *__restrict__ src_, const u64
         batch = (r >> 1) * 8 + (g & 7);
     } else batch = blockIdx.x;
     if (batch >= nbatch) return;
+#ifndef CUHE_OW_NO_REBASE_ARG
     if (rb.per > 0) {                                     // rows in separate blocks: the block of this row (uniform in the workgroup)
         const int c = batch / rb.per;
         src_ = (const char *)src_ + rb.src_adj[c];
         dst_ = (char *)dst_ + rb.dst_adj[c];
     }
+#endif
     const int t = threadIdx.x;
     tw2[t] = TW2[t];
 

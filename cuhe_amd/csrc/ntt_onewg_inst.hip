@@ -37,9 +37,15 @@ hipError_t launch(const OwArgs &a, hipStream_t st) {
     }
     const int nb8 = (a.nbatch + 7) & ~7;
     const int grid = HALF ? 2 * nb8 : a.nbatch;
+#ifdef CUHE_OW_NO_REBASE_ARG
+    if (a.rb) return hipErrorInvalidValue;            // (A/B build: no list launches)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
+                       a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab, StreamTwistArgs{a.c128, a.i4neg});
+#else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Geo::T), Geo::bytes, st, a.dst, a.src, a.TW1, a.TW2, a.src_stride, a.dst_stride, a.nbatch,
                        a.nstore, a.wa, a.tw, a.primes, a.pinv, a.prime0, a.np_mod, a.aux, a.aux_stride, a.fg, a.xtab, StreamTwistArgs{a.c128, a.i4neg},
                        a.rb ? *a.rb : kNoRebase);
+#endif
     return hipGetLastError();
 }
 

@@ -42,14 +42,14 @@ void resetParam() {
 int GlobalParameters::_numCrtPrime(int lvl) {
 	if (lvl != -1 && lvl >= depth) {           // cuhe/Parameters.cu:110-113
 		cout << "Error: numCrtPrime(lvl) has lvl: " << lvl << endl;
-		exit(0);
+		detail::die(0);
 	}
 	return cuhe_hip_num_crt_prime(lvl);
 }
 int GlobalParameters::_logCoeff(int lvl) {
 	if (lvl > depth) {                         // cuhe/Parameters.cu:125-128
 		cout << "Error: lvl cannot be more than depth!" << endl;
-		exit(-1);
+		detail::die(-1);
 	}
 	return cuhe_hip_log_coeff(lvl);
 }
@@ -681,8 +681,9 @@ void CuCtxt::relin(cudaStream_t st) {
 		return;
 	}
 	{
-		// x2r ; relinearization ; n2c (cuhe/CuHE.cu:570-581) -- the last two as one call of the library, which runs the key stream
-		// beside the window / inverse transforms (cuhe_hip_relin_crt); the ciphertext ends reduced, in the CRT domain, as before
+		// x2r ; relinearization ; n2c (cuhe/CuHE.cu:570-581) -- the last two as ONE call of the library on this stream (cuhe_hip_relin_crt:
+		// window transforms, key stream, inverse transforms back to back; the form that overlapped the key stream with the transforms
+		// lost its A/B and was removed, profiles/r05_relin_overlap_ab.txt); the ciphertext ends reduced, in the CRT domain, as before
 		GateScope chain;
 		x2r(st);
 		cRepAlloc(st);

@@ -9,10 +9,14 @@
 #define CCE() ((void)0)
 
 namespace cuHE { namespace detail {
+// exit(code) -- from one of the gate scheduler's worker threads: the same exit status WITHOUT running the static destructors under the
+// feet of the client's threads (a failed allocation inside a recorded gate segfaulted at exit in 3 of 6 injected failures, profiles/
+// r06_sched_soak.txt, before this).  Scheduler.cpp.
+void die(int code);
 inline void safeCall(int status, const char *file, int line) {
 	if (status != CUHE_OK) {
 		fprintf(stderr, "cuheSafeCall() failed at %s:%i : %s\n", file, line, cuhe_hip_last_error());
-		exit(-1);
+		die(-1);
 	}
 }
 }} // namespace cuHE::detail

@@ -41,8 +41,20 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <unistd.h>
 
 namespace cuHE {
+namespace sched { bool inWorker(); }
+namespace detail {
+// the reference's reaction to a failed device call is "message ; exit(-1)" (cuhe/Debug.h:35-66) from its one host thread.  From a worker
+// thread of this library exit() would run the process's static destructors while the client's threads (and the other workers) still use
+// what they destroy: the streams are flushed and the process ends with the same status at once.
+void die(int code) {
+	if (!sched::inWorker()) exit(code);
+	fflush(NULL);
+	_exit(code);
+}
+}
 namespace sched {
 
 // one worker's stream (on the worker's device)

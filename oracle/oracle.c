@@ -138,23 +138,24 @@ void orc_ntt_ext(uint64_t *dst, const uint32_t *src, int len) {
  * fold reduction as fft_inplace, with the twiddle and bit-reversal tables made ONCE per length and shared by the whole batch
  * (fft_inplace rebuilds both per transform), reduced operands throughout (one conditional subtraction per add / sub), OpenMP
  * over transforms.  Same outputs as orc_ntt_ext (tests/test_oracle_golden.py). */
-typedef struct { int len; uint64_t *tw; uint32_t *rev; } fast_tab;
-static fast_tab g_fast[4];
-static const fast_tab *fast_table(int len) {
+typedef struct { int len; uint64_t w; uint64_t *tw; uint32_t *rev; } fast_tab;
+static fast_tab g_fast[16];
+static const fast_tab *fast_table_w(int len, uint64_t w) {          /* (made by the calling thread before any parallel region uses it) */
     fast_tab *t = NULL;
-    for (int i = 0; i < 4; i++) if (g_fast[i].len == len) return &g_fast[i];
-    for (int i = 0; i < 4; i++) if (!g_fast[i].len) { t = &g_fast[i]; break; }
+    for (int i = 0; i < 16; i++) if (g_fast[i].len == len && g_fast[i].w == w) return &g_fast[i];
+    for (int i = 0; i < 16; i++) if (!g_fast[i].len) { t = &g_fast[i]; break; }
     if (!t) return NULL;
     const int lg = ilog2(len);
     t->tw = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(len / 2));
     t->rev = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)len);
-    const uint64_t w = root_of_len(len);
+    t->w = w;
     t->tw[0] = 1;
     for (int i = 1; i < len / 2; i++) t->tw[i] = orc_mul_modP(t->tw[i - 1], w);
     for (int i = 0; i < len; i++) { uint32_t j = 0; for (int b = 0; b < lg; b++) if (i >> b & 1) j |= 1u << (lg - 1 - b); t->rev[i] = j; }
     t->len = len;
     return t;
 }
+static const fast_tab *fast_table(int len) { return fast_table_w(len, root_of_len(len)); }
 static inline uint64_t addp(uint64_t x, uint64_t y) { const uint64_t s = x + y; return (s < x || s >= ORC_P) ? s - ORC_P : s; }   /* x, y < P */
 static inline uint64_t subp(uint64_t x, uint64_t y) { return x >= y ? x - y : x + (ORC_P - y); }
 static void ntt_ext_fast(uint64_t *a, const uint32_t *src, int len, const fast_tab *T) {
@@ -926,6 +927,103 @@ int orc_nc_mul_relin_crt_batch(const orc_ctx *c, uint32_t *dst, const uint32_t *
         free(acc); free(key);
     }
     free(cr); free(raw); free(win); free(wn);
+    return 0;
+}
+
+/* ---- bench.py's CPU leg for "ciphertext mul + relin" (round 6): the chain above for ONE pair with the evaluation keys transformed
+ * beforehand (the GPU library keeps them resident in transformed form: the timed region of both sides starts from the same state),
+ * the table-sharing transforms, OpenMP over primes / windows / coefficients.  Same rows as orc_nc_mul_relin_crt_batch with B = 1
+ * (tests/test_oracle_negacyclic.py). */
+struct orc_nc_prepared {
+    const orc_ctx *c; int lvl, n, np, k;
+    uint64_t *keys;                /* u64[np][k][n]: negacyclic transforms of the keys' CRT rows */
+    uint64_t *tw, *itw;            /* psi^j ; n^-1 psi^-j */
+    const fast_tab *F, *I;
+};
+static void nc_fft(uint64_t *a, const fast_tab *T) {
+    const int len = T->len;
+    for (int i = 0; i < len; i++) { const uint32_t j = T->rev[i]; if (j > (uint32_t)i) { const uint64_t t = a[i]; a[i] = a[j]; a[j] = t; } }
+    for (int h = 1; h < len; h <<= 1) {
+        const int step = len / (2 * h);
+        for (int s = 0; s < len; s += 2 * h)
+            for (int k = 0; k < h; k++) {
+                const uint64_t u = a[s + k], v = fold128((u128)a[s + k + h] * T->tw[k * step]);
+                a[s + k] = addp(u, v);
+                a[s + k + h] = subp(u, v);
+            }
+    }
+}
+static void nc_fwd(const orc_nc_prepared *P, uint64_t *dst, const uint32_t *src) {
+    for (int j = 0; j < P->n; j++) dst[j] = fold128((u128)src[j] * P->tw[j]);
+    nc_fft(dst, P->F);
+}
+static void nc_inv_modp(const orc_nc_prepared *P, uint32_t *dst, uint64_t *t, uint32_t p) {     /* t is overwritten */
+    nc_fft(t, P->I);
+    for (int j = 0; j < P->n; j++) {
+        const uint64_t v = fold128((u128)t[j] * P->itw[j]);
+        if (v > ORC_P / 2) { const uint32_t r = (uint32_t)((ORC_P - v) % p); dst[j] = r ? p - r : 0; }
+        else dst[j] = (uint32_t)(v % p);
+    }
+}
+orc_nc_prepared *orc_nc_prepare(const orc_ctx *c, int lvl, const uint32_t *ekc) {
+    const orc_params *q = &c->prm;
+    const int n = q->modLen, cl = q->crtLen, np = orc_num_crt_prime(q, lvl), np0 = q->numCrtPrime, k = orc_num_eval_key(q, lvl), w = q->logRelin;
+    if (n != cl || (n & (n - 1))) return NULL;
+    for (int i = 0; i < np; i++) {
+        const u128 p = c->primes[i];
+        if ((u128)2 * n * (p - 1) * (p - 1) >= ORC_P || (u128)2 * k * n * (((u128)1 << w) - 1) * (p - 1) >= ORC_P) return NULL;
+    }
+    orc_nc_prepared *P = (orc_nc_prepared *)calloc(1, sizeof *P);
+    P->c = c; P->lvl = lvl; P->n = n; P->np = np; P->k = k;
+    const uint64_t psi = nc_psi(n), ipsi = orc_pow_modP(psi, ORC_P - 2), wr = orc_mul_modP(psi, psi);
+    P->F = fast_table_w(n, wr); P->I = fast_table_w(n, orc_pow_modP(wr, ORC_P - 2));
+    if (!P->F || !P->I) { free(P); return NULL; }
+    P->tw = (uint64_t *)malloc(sizeof(uint64_t) * n); P->itw = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint64_t t = 1, it = orc_pow_modP((uint64_t)n, ORC_P - 2);
+    for (int j = 0; j < n; j++) { P->tw[j] = t; P->itw[j] = it; t = orc_mul_modP(t, psi); it = orc_mul_modP(it, ipsi); }
+    P->keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)np * k * n);
+    if (!P->keys) { free(P->tw); free(P->itw); free(P); return NULL; }
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1) collapse(2)
+    for (int i = 0; i < np; i++)
+        for (int j = 0; j < k; j++) nc_fwd(P, P->keys + ((size_t)i * k + j) * n, ekc + ((size_t)j * np0 + i) * cl);
+    return P;
+}
+void orc_nc_prepared_free(orc_nc_prepared *P) { if (P) { free(P->keys); free(P->tw); free(P->itw); free(P); } }
+int orc_nc_mul_relin_prepared(const orc_nc_prepared *P, uint32_t *dst, const uint32_t *a, const uint32_t *b) {
+    const orc_ctx *c = P->c; const orc_params *q = &c->prm;
+    const int n = P->n, np = P->np, k = P->k, W = orc_words_coeff(q, P->lvl), w = q->logRelin;
+    uint32_t *cr = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)np * n);
+    uint32_t *raw = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)q->rawLen * W);
+    uint64_t *wn = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)k * n);
+#pragma omp parallel num_threads(g_threads)
+    {
+        uint64_t *A = (uint64_t *)malloc(sizeof(uint64_t) * n), *B = (uint64_t *)malloc(sizeof(uint64_t) * n);
+        uint32_t *win = (uint32_t *)malloc(sizeof(uint32_t) * n);
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < np; i++) {                                   /* cAnd ; n2c (isProd) */
+            nc_fwd(P, A, a + (size_t)i * n); nc_fwd(P, B, b + (size_t)i * n);
+            for (int x = 0; x < n; x++) A[x] = fold128((u128)A[x] * B[x]);
+            nc_inv_modp(P, cr + (size_t)i * n, A, c->primes[i]);
+        }
+#pragma omp single
+        orc_icrt(c, raw, cr, P->lvl);                                    /* c2r (its own parallel loop over coefficients) */
+#pragma omp for schedule(dynamic, 1)
+        for (int j = 0; j < k; j++) {                                    /* windows and their transforms (Base.cu:345-385) */
+            for (int x = 0; x < n; x++) win[x] = window_of(raw + (size_t)x * W, W, w, j);
+            nc_fwd(P, wn + (size_t)j * n, win);
+        }
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < np; i++) {                                   /* Base.cu:1024-1033 per prime, then n2c (isProd) */
+            memset(A, 0, sizeof(uint64_t) * n);
+            for (int j = 0; j < k; j++) {
+                const uint64_t *x = wn + (size_t)j * n, *y = P->keys + ((size_t)i * k + j) * n;
+                for (int t = 0; t < n; t++) A[t] = addp(A[t], fold128((u128)x[t] * y[t]));
+            }
+            nc_inv_modp(P, dst + (size_t)i * n, A, c->primes[i]);
+        }
+        free(A); free(B); free(win);
+    }
+    free(cr); free(raw); free(wn);
     return 0;
 }
 

@@ -154,6 +154,11 @@ int orc_nc_intt_modp(uint32_t *dst, const uint64_t *src, int n, uint32_t p);
 int orc_nc_relin_modp(uint32_t *dst, const uint32_t *win, const uint32_t *key, int k, int n, uint32_t p);
 /* cAnd + relin of B pairs on x^n + 1 at config-4 sizes: per prime through the negacyclic restatement (CuHE.cu:101,570-581) */
 int orc_nc_mul_relin_crt_batch(const orc_ctx *c, uint32_t *dst, const uint32_t *a, const uint32_t *b, int B, int lvl, const uint32_t *ekc);
+/* the same chain for ONE pair with the keys transformed beforehand and table-sharing transforms: bench.py's CPU leg for mul + relin */
+typedef struct orc_nc_prepared orc_nc_prepared;
+orc_nc_prepared *orc_nc_prepare(const orc_ctx *c, int lvl, const uint32_t *ekc);        /* NULL: not a ring x^n + 1 within the lift bounds */
+void orc_nc_prepared_free(orc_nc_prepared *P);
+int orc_nc_mul_relin_prepared(const orc_nc_prepared *P, uint32_t *dst, const uint32_t *a, const uint32_t *b);
 
 /* ---- optional second CPU baseline (bench.py): the product the reference delegates to NTL (examples/DHS/DHS.cu:219-221) on
  * x^n + 1 by Kronecker substitution and ONE big-integer multiplication through GMP, opened at run time (NTL is not in

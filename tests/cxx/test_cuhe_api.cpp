@@ -314,7 +314,8 @@ int main() {
 		cXor(sum, p1, p2);
 		CHECK(sum.domain() == 3, "cXor of two products answers in the NTT domain");
 		sum.x2z();
-		ZZX want = reduceCoeffs(hostMul(a, a, xn1, q2[0], n2) + hostMul(a, b, xn1, q2[0], n2), q2[0], n2);
+		const ZZX aaHost = hostMul(a, a, xn1, q2[0], n2);        // (the schoolbook product of 16384 coefficients on the fallback big integer takes ~17 s: once)
+		ZZX want = reduceCoeffs(aaHost + hostMul(a, b, xn1, q2[0], n2), q2[0], n2);
 		CHECK(sum.zRep() == want, "a*a + a*b added in the NTT domain (two products: inside the headroom)");
 		{
 			CuCtxt q1, q2c, q3, s12, s123;
@@ -323,7 +324,7 @@ int main() {
 			cXor(s123, s12, q3);                                 // three products: beyond the headroom, the operands are reduced first
 			CHECK(s123.domain() == 3, "cXor beyond the headroom still answers in the NTT domain");
 			s123.x2z();
-			ZZX aa = hostMul(a, a, xn1, q2[0], n2);
+			const ZZX &aa = aaHost;
 			CHECK(s123.zRep() == reduceCoeffs(aa + aa + aa, q2[0], n2), "a*a + a*a + a*a added in the NTT domain (three products: beyond the headroom)");
 		}
 		{
@@ -338,7 +339,7 @@ int main() {
 			CHECK(t.isProd() && t.prodTerms() == 2, "a sum of two products plus a plaintext still counts two products");
 			cXor(u, t, q3);
 			u.x2z();
-			ZZX aa = hostMul(a, a, xn1, q2[0], n2);
+			const ZZX &aa = aaHost;
 			CHECK(u.zRep() == reduceCoeffs(aa + aa + aa + one, q2[0], n2), "(a*a + a*a + 1) + a*a: exact although the plaintext sum sat in between");
 			CuCtxt v, w, q4;
 			cXor(v, q1, q2c);

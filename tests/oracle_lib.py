@@ -375,6 +375,28 @@ class Ctx:
         ek_raw = np.ascontiguousarray(evalkey_raw, dtype=np.uint32)
         return np.stack([self.crt(ek_raw[j], 0) for j in range(ek_raw.shape[0])])
 
+    def nc_prepare(self, lvl, ekc):
+        """keys transformed once (bench.py's CPU leg for mul + relin): a handle for nc_mul_relin_prepared / nc_prepared_free"""
+        L = lib()
+        L.orc_nc_prepare.restype = C.c_void_p; L.orc_nc_prepare.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_nc_prepared_free.restype = None; L.orc_nc_prepared_free.argtypes = [C.c_void_p]
+        L.orc_nc_mul_relin_prepared.restype = C.c_int; L.orc_nc_mul_relin_prepared.argtypes = [C.c_void_p] * 4
+        ekc = np.ascontiguousarray(ekc, dtype=np.uint32)
+        assert ekc.shape[1:] == (self.prm.numCrtPrime, self.prm.crtLen)
+        h = L.orc_nc_prepare(self.h, lvl, _p(ekc))
+        assert h, "not a ring x^n + 1 within the lift bounds"
+        return h
+
+    def nc_mul_relin_prepared(self, h, a, b, lvl):
+        a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
+        assert a.shape == b.shape == (self.np_(lvl), self.prm.crtLen)
+        out = np.empty_like(a)
+        assert lib().orc_nc_mul_relin_prepared(h, _p(out), _p(a), _p(b)) == 0
+        return out
+
+    def nc_prepared_free(self, h):
+        lib().orc_nc_prepared_free(h)
+
     def nc_mul_relin_crt_batch(self, a, b, lvl, ekc):
         """cAnd + relin of B pairs on a ring x^n + 1 (a, b: u32[B][np][crtLen]), per prime through the negacyclic
         restatement: the form of mul_relin_crt that fits BASELINE config 4 (no np x K x nttLen key table)"""

@@ -131,6 +131,16 @@ def test_batched_chain_equals_the_cyclic_chain_of_the_oracle():
             got = o.nc_mul_relin_crt_batch(a, b, lvl, ekc)
             for t in range(3):
                 assert np.array_equal(got[t], o.mul_relin_crt(a[t], b[t], lvl, ek)), (lvl, t)
+            # the prepared form bench.py times as the CPU leg of mul + relin (keys transformed beforehand, shared tables), 1 and 4 threads
+            for threads in (1, 4):
+                O.set_threads(threads)
+                h = o.nc_prepare(lvl, ekc)
+                try:
+                    for t in range(3):
+                        assert np.array_equal(o.nc_mul_relin_prepared(h, a[t], b[t], lvl), got[t]), (lvl, t, threads)
+                finally:
+                    o.nc_prepared_free(h)
+                    O.set_threads(1)
     finally:
         o.close()
     # a ring that is not x^n + 1 is refused
