@@ -306,8 +306,8 @@ def main():
         # 1 GiB read + 1 GiB written per launch, best of its variants; torch's copy_ (what this field held until round 5) beside it
         torch.cuda.synchronize()
         copies = {}
-        for variant, name in ((0, "float4"), (1, "float4_x4"), (2, "float4_x4_nontemporal"), (3, "float4_x8")):
-            g = C.c_double(0)
+        for variant in range(lib.cuhe_hip_probe_copy_shapes()):
+            g, name = C.c_double(0), lib.cuhe_hip_probe_copy_name(variant).decode()
             try:
                 ck(lib.cuhe_hip_probe_copy(0, 1 << 30, variant, 10, C.byref(g)))
                 copies[name] = round(g.value, 1)

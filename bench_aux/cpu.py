@@ -19,8 +19,8 @@ def cpu_ntt_baseline(np, L, sample=0, seconds=4.0):
     once per length, OpenMP over transforms): "the same algorithm on the host cores".  The division form the record carried until round 5
     (oracle transform with u128 % P, tables per transform) is timed beside it on a smaller sample."""
     O = _oracle()
-    cores = os.cpu_count() or 1
-    group = max(cores * 4, 32)                                   # transforms per call (outputs: group x L x 8 bytes)
+    cores = O.host_cores()                                        # affinity mask capped by the cgroup CPU quota, not os.cpu_count()
+    group = max(cores * 8, 32)                                   # transforms per call (outputs: group x L x 8 bytes)
     xh = np.random.default_rng(1).integers(0, 1 << 32, (group, L // 2), dtype=np.uint32)
     got, used = O.ntt_ext_fast_batch(xh, L, 0)                    # warm-up: tables, thread pool, page faults
     assert np.array_equal(got[0], O.ntt_ext(xh[0], L)) and np.array_equal(got[-1], O.ntt_ext(xh[-1], L)), "throughput form differs from the oracle transform"
@@ -31,7 +31,7 @@ def cpu_ntt_baseline(np, L, sample=0, seconds=4.0):
         dt = time.perf_counter() - t0
         if (sample and done >= sample) or (not sample and dt >= seconds):
             break
-    rec = {"value": round(done / dt, 1), "unit": "NTT/s", "cores": used, "kind": "port",
+    rec = {"value": round(done / dt, 1), "unit": "NTT/s", "cores": used, "logical_cpus_visible": os.cpu_count(), "kind": "port",
            "sample": "%d 64K-point forward transforms in %.1f s: oracle radix-2 transform with the Solinas-fold reduction (no division), tables per length, OpenMP over transforms"
                      % (done, dt)}
     small = xh[:max(cores, 8)]

@@ -175,6 +175,8 @@ SIGNATURES = {
     "cuhe_hip_set_ntt_overlap": (i32, [i32]),
     "cuhe_hip_probe_valu": (i32, [i32, i32, i32] + [C.POINTER(C.c_double)] * 3),
     "cuhe_hip_probe_copy": (i32, [i32, sz, i32, i32, C.POINTER(C.c_double)]),
+    "cuhe_hip_probe_copy_shapes": (i32, []),
+    "cuhe_hip_probe_copy_name": (C.c_char_p, [i32]),
     "cuhe_hip_time_ntt_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp] + [C.POINTER(C.c_float)] * 3),
     "cuhe_hip_modp_add": (i32, [vp, vp, vp, sz, i32, vp]),
     "cuhe_hip_modp_sub": (i32, [vp, vp, vp, sz, i32, vp]),

@@ -776,10 +776,11 @@ int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_in
 }
 
 // ---- cuhe_hip_probe_copy: the streaming-copy ceiling of this box (include/cuhe_hip.h) -- the "measured peak" the HBM-bound kernels are
-// priced against next to the 8 TB/s of the data sheet.  16-byte accesses, grid-stride, 2048 workgroups (8 per CU).
+// priced against next to the 8 TB/s of the data sheet.  16-byte accesses; the launch shapes of kCopyShapes (grid-stride with 8 / 16 / 32
+// workgroups per CU, one element per thread, 256 / 512 / 1024 threads, several loads in flight before the stores).
 }  // extern "C"
 namespace {
-template <int UNROLL, bool NT> __global__ __launch_bounds__(256) void k_probe_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
+template <int UNROLL, bool NT> __global__ void k_probe_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
@@ -799,24 +800,57 @@ template <int UNROLL, bool NT> __global__ __launch_bounds__(256) void k_probe_co
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
+// a workgroup copies CONTIGUOUS chunks (UNROLL x blockDim float4 each), chunks handed out round-robin: every wave's loads of one iteration
+// are UNROLL consecutive 1 KB segments instead of UNROLL segments a whole grid apart
+template <int UNROLL> __global__ void k_probe_copy_chunks(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n) {
+    const size_t chunk = (size_t)UNROLL * blockDim.x;
+    for (size_t base = (size_t)blockIdx.x * chunk; base < n; base += (size_t)gridDim.x * chunk) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { const size_t i = base + (size_t)u * blockDim.x + threadIdx.x; if (i < n) v[u] = src[i]; }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { const size_t i = base + (size_t)u * blockDim.x + threadIdx.x; if (i < n) dst[i] = v[u]; }
+    }
+}
+struct CopyShape { int kind, unroll, threads, blocks_per_cu; const char *name; };       // blocks_per_cu 0: one element per thread (no loop)
+const CopyShape kCopyShapes[] = {
+    {0, 1, 256, 8, "float4, 256 thr, 8 wg/CU, grid-stride"},       {0, 4, 256, 8, "4 float4 in flight, 256 thr, 8 wg/CU"},
+    {1, 4, 256, 8, "4 float4 in flight, non-temporal, 256 thr, 8 wg/CU"}, {0, 8, 256, 8, "8 float4 in flight, 256 thr, 8 wg/CU"},
+    {0, 1, 256, 0, "float4, 256 thr, one element per thread"},     {0, 1, 1024, 0, "float4, 1024 thr, one element per thread"},
+    {0, 1, 512, 16, "float4, 512 thr, 16 wg/CU, grid-stride"},     {0, 2, 1024, 2, "2 float4 in flight, 1024 thr, 2 wg/CU"},
+    {0, 4, 1024, 2, "4 float4 in flight, 1024 thr, 2 wg/CU"},      {2, 4, 256, 8, "contiguous chunks of 4 float4 per thread, 256 thr, 8 wg/CU"},
+    {2, 4, 512, 4, "contiguous chunks of 4 float4 per thread, 512 thr, 4 wg/CU"}, {2, 8, 256, 8, "contiguous chunks of 8 float4 per thread, 256 thr, 8 wg/CU"},
+    {2, 2, 1024, 2, "contiguous chunks of 2 float4 per thread, 1024 thr, 2 wg/CU"}, {0, 1, 256, 32, "float4, 256 thr, 32 wg/CU, grid-stride"},
+};
+constexpr int kNumCopyShapes = (int)(sizeof(kCopyShapes) / sizeof(kCopyShapes[0]));
 }  // namespace
 extern "C" {
+int cuhe_hip_probe_copy_shapes(void) { return kNumCopyShapes; }
+const char *cuhe_hip_probe_copy_name(int variant) { return variant >= 0 && variant < kNumCopyShapes ? kCopyShapes[variant].name : ""; }
 int cuhe_hip_probe_copy(int dev, size_t bytes, int variant, int reps, double *gb_per_s) {
-    if (bytes < (1u << 20) || (bytes & 15) || reps < 1 || variant < 0 || variant > 3 || !gb_per_s) return fail(CUHE_EINVAL, "probe_copy(%zu bytes, variant %d, %d reps)", bytes, variant, reps);
-    if (hipSetDevice(G_.dev_base + (G_.virtual_devices ? 0 : dev)) != hipSuccess) return fail(CUHE_EHIP, "hipSetDevice");
+    if (bytes < (1u << 20) || (bytes & 15) || reps < 1 || variant < 0 || variant >= kNumCopyShapes || !gb_per_s) return fail(CUHE_EINVAL, "probe_copy(%zu bytes, variant %d, %d reps)", bytes, variant, reps);
+    const int phys = G_.dev_base + (G_.virtual_devices ? 0 : dev);
+    if (hipSetDevice(phys) != hipSuccess) return fail(CUHE_EHIP, "hipSetDevice");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, phys));
     float4 *a = nullptr, *b = nullptr;
     HIPCHK(hipMalloc((void **)&a, bytes));
     if (hipMalloc((void **)&b, bytes) != hipSuccess) { hipFree(a); return fail(CUHE_EHIP, "probe_copy: hipMalloc"); }
     HIPCHK(hipMemset(a, 0x5a, bytes));
     const size_t n = bytes / 16;
-    const int blocks = 2048;
+    const CopyShape &S = kCopyShapes[variant];
+    const unsigned blocks = S.blocks_per_cu ? (unsigned)(prop.multiProcessorCount * S.blocks_per_cu) : (unsigned)((n + S.threads - 1) / S.threads);
     auto launch = [&]() {
-        switch (variant) {
-            case 0: hipLaunchKernelGGL((k_probe_copy<1, false>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
-            case 1: hipLaunchKernelGGL((k_probe_copy<4, false>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
-            case 2: hipLaunchKernelGGL((k_probe_copy<4, true>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
-            default: hipLaunchKernelGGL((k_probe_copy<8, false>), dim3(blocks), dim3(256), 0, 0, b, a, n); break;
-        }
+        const dim3 g(blocks), t(S.threads);
+        if (S.kind == 2) {
+            if (S.unroll == 2) hipLaunchKernelGGL((k_probe_copy_chunks<2>), g, t, 0, 0, b, a, n);
+            else if (S.unroll == 4) hipLaunchKernelGGL((k_probe_copy_chunks<4>), g, t, 0, 0, b, a, n);
+            else hipLaunchKernelGGL((k_probe_copy_chunks<8>), g, t, 0, 0, b, a, n);
+        } else if (S.kind == 1) hipLaunchKernelGGL((k_probe_copy<4, true>), g, t, 0, 0, b, a, n);
+        else if (S.unroll == 1) hipLaunchKernelGGL((k_probe_copy<1, false>), g, t, 0, 0, b, a, n);
+        else if (S.unroll == 2) hipLaunchKernelGGL((k_probe_copy<2, false>), g, t, 0, 0, b, a, n);
+        else if (S.unroll == 4) hipLaunchKernelGGL((k_probe_copy<4, false>), g, t, 0, 0, b, a, n);
+        else hipLaunchKernelGGL((k_probe_copy<8, false>), g, t, 0, 0, b, a, n);
     };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -828,7 +862,7 @@ int cuhe_hip_probe_copy(int dev, size_t bytes, int variant, int reps, double *gb
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *gb_per_s = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;          // bytes read + bytes written
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(a); hipFree(b);
-    return CUHE_OK;
+    return hipGetLastError() == hipSuccess ? CUHE_OK : fail(CUHE_EHIP, "probe_copy: launch failed");
 }
 
 // waits for everything enqueued on the device; every block freed in stream order becomes an ordinary free block

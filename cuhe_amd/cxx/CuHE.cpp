@@ -313,8 +313,15 @@ static void misuse(const char *msg) { cout << msg << endl; terminate(); }
 CuPolynomial::CuPolynomial() : logq_(-1), domain_(-1), device_(-1), isProd_(false), prodTerms_(0), rRep_(NULL), cRep_(NULL), nRep_(NULL), cKeep_(NULL), stream_(0), node_(NULL), exposed_(false) { clear(zRep_); }
 CuPolynomial::~CuPolynomial() { reset(); }
 // ---- attached / detached (scheduled mode)
+// mulZZX (and whatever else needs its result on the host at once, on objects nobody else can see) runs its gates DIRECTLY on the calling
+// thread in scheduled mode too: recording five tasks for one product and waiting for the last buys nothing and cost 8.5-12.4 ms against
+// 3.2 ms for the BASELINE config 3 product (profiles/r06_mulzzx_staging.txt) -- what every encrypt / decrypt / key generation of a DHS
+// client pays (examples/DHS/DHS.cu:212-252).
+static thread_local int tlsDirectGates = 0;
+struct DirectGates { DirectGates() { ++tlsDirectGates; } ~DirectGates() { --tlsDirectGates; } };
 bool CuPolynomial::scheduled() {
 	if (sched::inWorker()) return false;                        // a recorded gate running on the scheduler-side objects
+	if (tlsDirectGates > 0 && !node_) return false;             // (an object that IS attached keeps its place in the graph)
 	if (!schedulable()) return false;                           // a client's own subclass: no scheduler-side twin can be made of it
 	if (sched::on()) return true;
 	if (node_) schedDetach();                                   // the mode was switched off: back to a plain object
@@ -1103,6 +1110,7 @@ static void runBatchedGates(int kind, sched::Node *const *subjects, sched::Node 
 // The by-value parameters are the reference's signature (cuhe/CuHE.h:184); they are moved, not copied again, into
 // the operands, and the result is swapped out of the product instead of being copied.
 void mulZZX(ZZX &out, ZZX in0, ZZX in1, int lvl, int dev, cudaStream_t st) {
+	DirectGates direct;                                         // local operands, result needed on the host: nothing to schedule
 	CuCtxt a, b;
 	a.setLevel(lvl, dev, std::move(in0));
 	b.setLevel(lvl, dev, std::move(in1));

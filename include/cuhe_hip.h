@@ -409,10 +409,13 @@ int cuhe_hip_time_ntt_fwd(uint64_t *dst, const uint32_t *src, int len, int batch
  * ticks of a wave per microsecond of kernel time) and the issue cost (*cycles_per_instr: shader cycles per wave-instruction and
  * SIMD).  No counterpart in the reference; a diagnostic, never on the product path. */
 int cuhe_hip_probe_valu(int dev, int waves_per_simd, int millis, double *lane_instr_per_s, double *shader_mhz, double *cycles_per_instr);
-/* The streaming-copy ceiling of the box (bench.py roofline.measured_copy_GBs): a grid-stride copy of `bytes` bytes with 16-byte accesses,
- * 2048 workgroups, `reps` timed launches between hipEvents; *gb_per_s = (bytes read + bytes written) / time.  variant: 0 one float4 per
- * iteration, 1 four loads then four stores, 2 the same with non-temporal accesses, 3 eight loads then eight stores.  A diagnostic like
- * cuhe_hip_probe_valu; the HBM-bound kernels of the path (key stream, ICRT, pointwise) are priced against its best figure. */
+/* The streaming-copy ceiling of the box (bench.py roofline.measured_copy_GBs): a copy of `bytes` bytes with 16-byte accesses in launch
+ * shape `variant` (0 ... cuhe_hip_probe_copy_shapes() - 1; cuhe_hip_probe_copy_name says which: grid-stride at several occupancies, one
+ * element per thread, several loads in flight, contiguous chunks per workgroup, non-temporal accesses), `reps` timed launches between
+ * hipEvents; *gb_per_s = (bytes read + bytes written) / time.  A diagnostic like cuhe_hip_probe_valu; the HBM-bound kernels of the path
+ * (key stream, ICRT, pointwise) are priced against the best shape. */
+int cuhe_hip_probe_copy_shapes(void);
+const char *cuhe_hip_probe_copy_name(int variant);
 int cuhe_hip_probe_copy(int dev, size_t bytes, int variant, int reps, double *gb_per_s);
 
 /* ---- field arithmetic test hooks (tests/test_ModP.cu:50-135): elementwise over n u64 */

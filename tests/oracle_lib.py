@@ -126,7 +126,7 @@ def ntt_ext_batch(x, length, threads=0):
     x = np.ascontiguousarray(x, dtype=np.uint32)
     batch = x.shape[0]
     out = np.empty((batch, length), dtype=np.uint64)
-    used = lib().orc_ntt_ext_batch(_p(out), _p(x), length, batch, threads)
+    used = lib().orc_ntt_ext_batch(_p(out), _p(x), length, batch, threads if threads > 0 else host_cores())
     return out, used
 
 
@@ -135,7 +135,7 @@ def ntt_ext_fast_batch(x, length, threads=0):
     x = np.ascontiguousarray(x, dtype=np.uint32)
     batch = x.shape[0]
     out = np.empty((batch, length), dtype=np.uint64)
-    used = lib().orc_ntt_ext_fast_batch(_p(out), _p(x), length, batch, threads)
+    used = lib().orc_ntt_ext_fast_batch(_p(out), _p(x), length, batch, threads if threads > 0 else host_cores())
     if used < 0:
         raise RuntimeError("orc_ntt_ext_fast_batch: no table slot for length %d" % length)
     return out, used
@@ -182,9 +182,28 @@ def gmp_mul_xn1(a_raw, b_raw, q):
     return out
 
 
+def host_cores():
+    """the CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical CPUs
+    under a quota of 16: 128 OpenMP threads there run 2x SLOWER than 16, profiles/r06_cpu_thread_scaling.txt)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def set_threads(n):
-    """OpenMP threads of the Ctx stage loops (0 = all cores); returns the count in effect"""
-    return lib().orc_set_threads(n)
+    """OpenMP threads of the Ctx stage loops (0 = every CPU this process may use, host_cores()); returns the count in effect"""
+    return lib().orc_set_threads(n if n > 0 else host_cores())
 
 
 def set_param(d, p, w, mn, cut, m):

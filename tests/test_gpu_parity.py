@@ -121,8 +121,9 @@ PSETS = {
     "phi32767": (3, 2, 16, 50, 25, 32767),       # m = 7 * 31 * 151, phi = 27000: generic (folded / five-transform) Barrett, L = 65536
     "prime32749": (3, 2, 16, 50, 25, 32749),     # prime m, n = 32748: the prime-m fold at L = 65536
     "prime16381": (3, 2, 16, 50, 25, 16381),     # prime m, n = 16380: the prime-m fold at L = 32768
-}
-GENERAL_64K = ["phi32767", "prime32749", "prime16381"]
+    "phi65535": (3, 2, 16, 50, 25, 65535),       # m = 3 * 5 * 17 * 257, phi = 32768 = the whole row: the quotient (32767 coefficients) does not fit the
+}                                                # folded form, so the DEFAULT reduction is the five-transform chain at L = 65536 (Operations.cu:460-501)
+GENERAL_64K = ["phi32767", "prime32749", "prime16381", "phi65535"]
 
 
 @pytest.fixture(scope="module", params=list(PSETS))

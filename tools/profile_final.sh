@@ -4,9 +4,9 @@
 # HBM counters of the batched multiply + relinearise call.  Text summaries land in gpurun_out/final/;
 # tools/make_traffic_json.py turns the PMC passes into profiles/traffic_rNN.json (bytes and VALU lane-instructions per
 # transform, tagged with the hash of the kernel sources bench.py checks).  Every step runs under its own timeout.
-# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r05]
+# usage (from the repo root on the GPU box): tools/profile_final.sh [skip-tests] [round-tag, default r06]
 export TMPDIR=/tmp
-tag=${2:-r05}
+tag=${2:-r06}
 out=$PWD/gpurun_out/final; mkdir -p $out
 if [ "$1" != "skip-tests" ]; then timeout 1500 python -m pytest tests -m gpu -q --durations=8 --timeout 400 2>&1 | tail -40 > $out/pytest_gpu.txt; cat $out/pytest_gpu.txt; fi
 timeout 600 python bench.py 2>/dev/null | tail -1 > $out/bench_n1.json
