@@ -568,6 +568,23 @@ __device__ __forceinline__ u32 pack_digit(u64 w0, u64 w1, u64 w2, u64 w3, int la
     return (u32)((w0 >> (8 * la)) & 0xff) | (u32)((w1 >> (8 * la)) & 0xff) << 8 | (u32)((w2 >> (8 * la)) & 0xff) << 16 |
            (u32)((w3 >> (8 * la)) & 0xff) << 24;
 }
+// the eight digit words of four window words at once: o[la] = { byte la of w0, w1, w2, w3 } -- a 4 x 4 byte transpose of the low
+// dwords (la < 4) and one of the high dwords, 8 v_perm_b32 each (2 per output word against 3-4 shift / mask / or operations
+// per word for pack_digit as hipcc lowers it).  v_perm_b32 D, S0, S1, sel: byte k of D = byte sel_k of { S1 (0..3), S0 (4..7) }.
+__device__ __forceinline__ void transpose_digits(u32 (&o)[8], u64 w0, u64 w1, u64 w2, u64 w3) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const u32 d0 = (u32)(w0 >> (32 * h)), d1 = (u32)(w1 >> (32 * h)), d2 = (u32)(w2 >> (32 * h)), d3 = (u32)(w3 >> (32 * h));
+        const u32 a01 = __builtin_amdgcn_perm(d1, d0, 0x05010400u);     // d0.b0 d1.b0 d0.b1 d1.b1
+        const u32 b01 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);     // d0.b2 d1.b2 d0.b3 d1.b3
+        const u32 a23 = __builtin_amdgcn_perm(d3, d2, 0x05010400u);
+        const u32 b23 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+        o[4 * h + 0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);    // a01.b0 a01.b1 a23.b0 a23.b1
+        o[4 * h + 1] = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+        o[4 * h + 2] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+        o[4 * h + 3] = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+    }
+}
 static constexpr int kMacMfmaThreads = 256;
 template <int NFULL, int TAIL>
 __global__ __launch_bounds__(kMacMfmaThreads, (2 * NFULL + (TAIL == 64 ? 2 : TAIL == 32 ? 1 : 0)) <= 3 ? 2 : 1)
@@ -619,27 +636,55 @@ void k_relin_mac_mfma(u64 *__restrict__ dst, const u64 *__restrict__ c, const un
             u64 w[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) { const int j = s * 64 + g * 16 + t; w[t] = j < k ? row[j] : 0ull; }
+#ifdef CUHE_MAC_PACK_DIGIT                                              // the round-2 form (A/B: profiles/r06_mac_perm_ab.txt)
 #pragma unroll
             for (int la = 0; la < 8; ++la)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) A.f[la][s][x] = (int)pack_digit(w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3], la);
+#else
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                u32 o[8];
+                transpose_digits(o, w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3]);
+#pragma unroll
+                for (int la = 0; la < 8; ++la) A.f[la][s][x] = (int)o[la];
+            }
+#endif
         }
         if (TAIL == 32) {
             u64 w[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) { const int j = NFULL * 64 + g * 8 + t; w[t] = j < k ? row[j] : 0ull; }
+#ifdef CUHE_MAC_PACK_DIGIT
 #pragma unroll
             for (int la = 0; la < 8; ++la)
                 A.t32[la] = (long)((u64)pack_digit(w[0], w[1], w[2], w[3], la) | (u64)pack_digit(w[4], w[5], w[6], w[7], la) << 32);
+#else
+            u32 lo[8], hi[8];
+            transpose_digits(lo, w[0], w[1], w[2], w[3]);
+            transpose_digits(hi, w[4], w[5], w[6], w[7]);
+#pragma unroll
+            for (int la = 0; la < 8; ++la) A.t32[la] = (long)((u64)lo[la] | (u64)hi[la] << 32);
+#endif
         }
         if (TAIL == 64) {
             u64 w[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) { const int j = NFULL * 64 + g * 16 + t; w[t] = j < k ? row[j] : 0ull; }
+#ifdef CUHE_MAC_PACK_DIGIT
 #pragma unroll
             for (int la = 0; la < 8; ++la)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) A.t64[la][x] = (int)pack_digit(w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3], la);
+#else
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                u32 o[8];
+                transpose_digits(o, w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3]);
+#pragma unroll
+                for (int la = 0; la < 8; ++la) A.t64[la][x] = (int)o[la];
+            }
+#endif
         }
     };
     auto run = [&](int task, const MacFrag<NFULL, TAIL> &B) {
