@@ -292,6 +292,7 @@ int main(int argc, char **argv) {
 	}
 	setAsynchronous(async);
 	if (scheduledGates) setScheduled(true, schedWorkers);
+	synchronize();                                          // (library default: the uploads above were recorded, not run -- they are not part of the block)
 	traceMark();
 	const auto t2 = clk::now();
 	printf("encrypted 192 bits in %.2f s\n", std::chrono::duration<double>(t2 - t1).count());
