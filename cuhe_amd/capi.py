@@ -55,6 +55,7 @@ SIGNATURES = {
     "cuhe_hip_reduce_kind": (i32, []),
     "cuhe_hip_force_generic_reduce": (i32, [i32]),
     "cuhe_hip_start_allocator": (i32, []),
+    "cuhe_hip_reserve_blocks": (i32, [i32, sz, i32]),
     "cuhe_hip_stop_allocator": (i32, []),
     "cuhe_hip_malloc": (vp, [i32, sz]),
     "cuhe_hip_free": (i32, [i32, vp]),

@@ -264,7 +264,12 @@ int init_device(int dev) {
     // the tables of the one-workgroup forms of every sub-transform size this parameter set can reach (rows of nttLen points, their halves,
     // the half-length transforms of the folded reductions and of the key-switch windows): here, like the reference's initNtt, not inside the
     // first gate that needs them -- a homomorphic PRINCE block lost 6 ms to three such first uses (profiles/r05_prince_gaps.txt)
-    for (int lgh = 12; lgh <= 15 && (1 << lgh) <= L; ++lgh) CHK(ensure_onewg(D.ow[lgh - 12], lgh));
+    for (int lgh = 12; lgh <= 15 && (1 << lgh) <= L; ++lgh) {
+        CHK(ensure_onewg(D.ow[lgh - 12], lgh));
+        // ... and the kernels themselves (HIP loads a code object and builds a kernel's function at its first use)
+        const hipError_t we = lgh == 12 ? cuhe::ow_prewarm_12() : lgh == 13 ? cuhe::ow_prewarm_13() : lgh == 14 ? cuhe::ow_prewarm_14() : cuhe::ow_prewarm_15();
+        if (we != hipSuccess) return fail(CUHE_EHIP, "one-workgroup kernels of 2^%d points: %s", lgh, hipGetErrorString(we));
+    }
     if (G_.nc && n == 65536) CHK(ensure_onewg_twist(D.ow[3], 15));
     if (q.ncOnly()) {                    // no cyclic representation, hence no Barrett tables (the ring has x^n + 1 only)
         HIPCHK(hipDeviceSynchronize());
@@ -516,6 +521,24 @@ static void drop_cached(DevCtx &D) {
     D.streamBlocks.clear();
     D.cachedBytes = 0;
 }
+static long long g_alloc_counters[4];      // hipMalloc calls, hits in the settled pool, hits in a stream's parked blocks, idle streams settled
+// `count` blocks of `bytes` bytes into the settled pool of device `dev` (the pooled allocator's own reserve): the reference's allocator
+// takes the device's whole memory when it starts (cuhe/DeviceManager.cu:56-64); here startAllocator takes a bounded reserve of the
+// one block size the classes use while it is on, so that a client's first operations do not pay hipMalloc one block at a time
+int cuhe_hip_reserve_blocks(int dev, size_t bytes, int count) {
+    CHK(need_init(dev));
+    if (bytes == 0 || count < 0) return fail(CUHE_EINVAL, "reserve_blocks(%zu bytes, %d)", bytes, count);
+    CHK(set_dev(dev));
+    DevCtx &D = G_.dev[dev];
+    for (int i = 0; i < count; ++i) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }       // as much as there is: a reserve, not a requirement
+        ++g_alloc_counters[0];
+        std::lock_guard<std::mutex> lk(G_.mu);
+        D.freeBlocks.insert({bytes, p}); D.cachedBytes += bytes;
+    }
+    return CUHE_OK;
+}
 // blocks freed in stream order become ordinary free blocks once that stream has been synchronised
 static void settle_stream_blocks(DevCtx &D, hipStream_t st) {
     std::lock_guard<std::mutex> lk(G_.mu);
@@ -538,7 +561,6 @@ int cuhe_hip_set_alloc_cache(size_t bytes) { G_.cache_cap = bytes; return CUHE_O
 // device, which is more than a whole CRT or NTT stage of a ciphertext takes, and the API allocates and frees a
 // representation on every domain change (cuhe/CuHE.cu:356-408).  Freed blocks are therefore parked and handed out
 // again for the same size: without limit while startAllocator() is in effect, up to cache_cap bytes otherwise.
-static long long g_alloc_counters[4];      // hipMalloc calls, hits in the settled pool, hits in a stream's parked blocks, idle streams settled
 int cuhe_hip_alloc_counters(long long *out4) {
     std::lock_guard<std::mutex> lk(G_.mu);
     for (int i = 0; i < 4; ++i) out4[i] = g_alloc_counters[i];

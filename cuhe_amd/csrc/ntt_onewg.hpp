@@ -30,6 +30,8 @@ hipError_t ow_launch_15(int mode, int out, bool half, const OwArgs &a, hipStream
 constexpr int kOwPairCounters = 512;     // + 1 slot behind them: workgroups that gave a rendezvous up (never reset by a launch)
 hipError_t ow_launch_stream_14(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
 hipError_t ow_launch_stream_15(int mode, int out, const OwArgs &a, int grid, unsigned *pair_cnt, u64 c128, int i4neg, hipStream_t st);
+// every kernel of one size made ready on the current device (code object, functions, LDS attributes): at initialisation
+hipError_t ow_prewarm_12(); hipError_t ow_prewarm_13(); hipError_t ow_prewarm_14(); hipError_t ow_prewarm_15();
 bool ow_supported(int mode, int out, bool half);
 // half = true with a full-length source: the SPLIT form (two half-length transforms per row), 32K / 64K-point rows
 bool ow_split_supported(int mode, int out);

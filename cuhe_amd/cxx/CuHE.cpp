@@ -62,7 +62,20 @@ static thread_local int tlsDevice = 0;
 void setNumDevices(int val) { CSC(cuhe_hip_multi_gpus(val)); }
 int numDevices() { return cuhe_hip_num_gpus(); }
 static bool allocatorOn = false;
-void bootDeviceAllocator(size_t, unsigned long) { CSC(cuhe_hip_start_allocator()); allocatorOn = true; }
+// The reference's allocator takes the device's whole memory when it boots (cuhe/DeviceManager.cu:56-64) and hands out blocks of ONE size.
+// Here the pool grows on demand, and booting it reserves a bounded number of blocks of that size on every device -- CUHE_POOL_RESERVE
+// blocks, default 512, at most 8 GiB per device -- so that the first operations after startAllocator() do not pay hipMalloc block by block
+// (a homomorphic PRINCE block's first run: ~600 blocks, 3-6 ms of idle GPU, profiles/r06_prince_first_block.txt).
+void bootDeviceAllocator(size_t blockBytes, unsigned long) {
+	CSC(cuhe_hip_start_allocator());
+	allocatorOn = true;
+	if (blockBytes == 0 || !cuhe_hip_is_initialised()) return;
+	const char *e = getenv("CUHE_POOL_RESERVE");
+	long want = e ? atol(e) : 512;
+	const long cap = (long)(((size_t)8 << 30) / blockBytes);
+	if (want > cap) want = cap;
+	for (int d = 0; d < numDevices() && want > 0; d++) CSC(cuhe_hip_reserve_blocks(d, blockBytes, (int)want));
+}
 void haltDeviceAllocator() { CSC(cuhe_hip_stop_allocator()); allocatorOn = false; }
 bool deviceAllocatorIsOn() { return allocatorOn; }
 void selectDevice(int dev) { tlsDevice = dev; }

@@ -97,6 +97,10 @@ int cuhe_hip_force_generic_reduce(int on);
 /* ---- allocator: startAllocator / stopAllocator (cuhe/CuHE.h:156,159; DeviceManager.cu:50-138) */
 int cuhe_hip_start_allocator(void);
 int cuhe_hip_stop_allocator(void);
+/* `count` blocks of `bytes` bytes into the free pool of device `dev` ahead of use (fewer if the device runs out: a reserve, not a
+   requirement).  The C++ startAllocator() reserves the one block size its classes use while the pooled allocator is on -- the bounded
+   counterpart of the reference's allocator, which takes the whole device memory at start (cuhe/DeviceManager.cu:56-64). */
+int cuhe_hip_reserve_blocks(int dev, size_t bytes, int count);
 void *cuhe_hip_malloc(int dev, size_t bytes);
 int cuhe_hip_free(int dev, void *ptr);
 /* freed blocks are parked for reuse (hipMalloc/hipFree cost more than a CRT or NTT stage): without limit between
