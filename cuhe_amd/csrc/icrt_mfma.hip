@@ -25,7 +25,10 @@ static int launch_tiles(u32 *dst, const u32 *src, const DevCtx &D, const IcrtLev
         per_cu = std::max(nb, 1);
         occ[slot].store(per_cu, std::memory_order_relaxed);
     }
-    const long resident = (long)std::max(D.cus, 1) * per_cu;
+    // (A/B: CUHE_ICRT_GRID_MULT workgroups per resident slot -- the copy probe streams 25 % faster with far more workgroups than
+    // fit at once than with a resident grid-stride walk, profiles/r06_copy_probe.txt; profiles/r06_icrt_grid_ab.txt says what it does here)
+    static const int mult = getenv("CUHE_ICRT_GRID_MULT") ? std::max(1, atoi(getenv("CUHE_ICRT_GRID_MULT"))) : 1;
+    const long resident = (long)std::max(D.cus, 1) * per_cu * mult;
     const dim3 grid((unsigned)std::min(wgs, resident)), block(kIcrtMfmaThreads);
     IcrtMfmaTab T{I.dig, I.pc, I.nm, I.tiles, I.ksteps};
     hipLaunchKernelGGL(k_icrt_mfma<TILES>, grid, block, lds, st, dst, src, T, np, W, q.modLen, q.crtLen, src_ct_stride, dst_ct_stride, batch, wo);
