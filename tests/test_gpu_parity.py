@@ -155,6 +155,45 @@ def test_ctx_constants(ctxpair):
         assert g.words(lvl) == o.words(lvl) and g.np_(lvl) == o.np_(lvl)
 
 
+def test_second_init_on_the_same_ring_keeps_the_context(gu):
+    """cuhe_hip_init on the ring the library already runs on is a no-op that keeps tables, resident keys and blocks handed out
+    (cuhe_hip_same_ring) -- what a second scheme object built from a key string does to the process (examples/DHS/DHS.cu:57-118,
+    simple_DHS.cu:176-190); another ring is refused until cuhe_hip_shutdown."""
+    import ctypes as C
+    import oracle_lib as O
+    lib, ck = gu.lib, gu.ck
+    args = (3, 2, 8, 40, 20, 1155)
+    g, o = gu.GpuCtx(*args), O.Ctx(*args)
+    try:
+        q = o.prm
+        K, W0, M0 = q.numEvalKey, o.words(0), o.coeff_modulus(0)
+        ek_raw = np.stack([O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE700 + j)[0] for j in range(K)])
+        ek = o.init_relin(ek_raw)
+        g.init_relin(ek_raw)
+        ct, _ = O.random_raw(q.rawLen, q.modLen, W0, M0, 0xE7FF)
+        want = o.relin(ct, 0, ek)
+        blk = lib.cuhe_hip_malloc(0, 4096)
+        gen = lib.cuhe_hip_generation()
+        assert lib.cuhe_hip_same_ring(None, 0) == 1
+        phi = np.ascontiguousarray(O.cyclotomic(q.mSize), dtype=np.int32)
+        assert lib.cuhe_hip_same_ring(phi.ctypes.data_as(C.c_void_p), phi.size) == 1
+        ck(lib.cuhe_hip_set_parameters(*args))                       # the second object's setParameters ...
+        ck(lib.cuhe_hip_init(None, 0))                               # ... and initCuHE
+        ck(lib.cuhe_hip_init(phi.ctypes.data_as(C.c_void_p), phi.size))
+        assert lib.cuhe_hip_generation() == gen and lib.cuhe_hip_is_initialised() == 1
+        assert np.array_equal(g.relin(ct, 0), want)                  # the keys loaded before are still there
+        ck(lib.cuhe_hip_free(0, blk))                                # and so is the block handed out before
+        other = phi.copy(); other[1] += 1                            # another modulus on the same parameters: not the same ring
+        assert lib.cuhe_hip_same_ring(other.ctypes.data_as(C.c_void_p), other.size) == 0
+        assert lib.cuhe_hip_init(other.ctypes.data_as(C.c_void_p), other.size) != 0 and b"another ring" in lib.cuhe_hip_last_error()
+        ck(lib.cuhe_hip_set_parameters(3, 2, 8, 40, 20, 8191))       # other parameters
+        assert lib.cuhe_hip_same_ring(None, 0) == 0 and lib.cuhe_hip_init(None, 0) != 0
+        ck(lib.cuhe_hip_set_parameters(*args))
+        assert lib.cuhe_hip_same_ring(None, 0) == 1 and np.array_equal(g.relin(ct, 0), want)
+    finally:
+        g.close(); o.close()
+
+
 def test_crt_icrt(ctxpair):
     import oracle_lib as O
     name, g, o = ctxpair

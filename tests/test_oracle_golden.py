@@ -217,3 +217,31 @@ def test_throughput_form_of_the_transform_equals_the_oracle_transform(length):
         got, used = O.ntt_ext_fast_batch(x, length, threads)
         assert used >= 1 and np.array_equal(got, want)
     assert (got[3] == 1).all() and not got[2].any()
+
+
+def test_host_cores_respects_the_cgroup_quota(tmp_path, monkeypatch):
+    """the thread count of the CPU baselines is what the process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs under a quota of 16; 128 OpenMP threads run 2x slower there than 16: profiles/r06_cpu_thread_scaling.txt)"""
+    import builtins
+    import os
+    import oracle_lib as O
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                f = tmp_path / "cpu.max"
+                f.write_text(content)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert O.host_cores() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert O.host_cores() == 256
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert O.host_cores() == 1
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert O.host_cores() == 8
