@@ -511,6 +511,19 @@ void CuPolynomial::r2z(cudaStream_t st) {
 	rRepFree();
 	domain_ = 0;
 }
+// Scheduled gates and HOST VALUES.  The scheduler schedules gates; a copy between a ZZX and the device, with its packing or its 16 384 big integers
+// to rebuild and its wait for the PCIe transfer, runs on the CLIENT's thread, at the call -- where the reference runs it, and as parallel as the
+// client is (Prince.cu:188-322: one OpenMP thread per S-box hands four ZZX in, setLevel(lvl, dev, ZZX), and takes four back, x2z ; zRep).  Recorded
+// as tasks (rounds 4-6a) they were serialised on the two or three workers of the device, blocked those workers in stream synchronises while
+// batches of the other client threads waited, and handed memory allocated on a worker to the client to free: the literal client structure with 8
+// threads took 1.2-1.8 s per block against 0.53 s on synchronous gates (profiles/r06_zzx_state_client.txt).  CUHE_CLIENT_STAGING=0: the tasks (A/B).
+static bool clientStaging() { static const bool on = !(getenv("CUHE_CLIENT_STAGING") && atoi(getenv("CUHE_CLIENT_STAGING")) == 0); return on; }
+// (scheduled mode, client thread) a host value goes up now: the polynomial enters the graph in the RAW domain
+void CuPolynomial::hostValueUp(cudaStream_t st) {
+	if (node_) schedDetach();                                  // (attached in the ZZX domain: a recorded copy of a host value)
+	DirectGates here;
+	z2r(st);
+}
 void CuPolynomial::r2c(cudaStream_t st) {
 	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }
 	if (logq_ > param.logCrtPrime) {
@@ -566,8 +579,10 @@ void CuPolynomial::n2c(cudaStream_t st) {
 }
 // In scheduled mode a conversion is recorded as ONE task that writes this polynomial; the mirror takes the domain the
 // conversion ends in (and loses the product mark wherever the chain passes through n2c).
-#define RECORD_SELF(call) do { sched::Node *n_ = schedAttach(); \
-	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }); } while (0)
+// (a conversion that starts from a host value -- CUHE_CLIENT_STAGING=0 only -- uploads it and waits for the copy: sched::kHostBlocking keeps it off the
+// workers that take groups)
+#define RECORD_SELF(call) do { const int kind_ = domain_ == 0 ? sched::kHostBlocking : 0; sched::Node *n_ = schedAttach(); \
+	sched::submit(device_, Nodes(), Nodes(1, n_), [n_](void *s) { n_->obj->stream_ = s; n_->obj->call; }, false, kind_); } while (0)
 // ... as a BATCHABLE gate (Scheduler.h): ready gates of one kind on ciphertexts of one level / domain / device run as one call of
 // the array entry points (batchRunner below).  Ciphertexts only; the key says what the closure would find in the object.
 enum { kBatchX2C = 1, kBatchX2N = 2, kBatchRelin = 3, kBatchModSwitch = 4, kBatchAnd = 5, kBatchXor = 6, kBatchCopy = 7, kBatchNot = 8 };
@@ -577,11 +592,18 @@ static long batchKey(int level, int domain, bool prod) { return (long)level | (l
 void CuPolynomial::x2z(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ < 1) return;
-		sched::Node *n = schedAttach();
-		sched::wait(sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { n->obj->stream_ = s; n->obj->x2z(s); }, true));
-		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
-		domain_ = 0;
-		schedDetach();                                             // a host value lives in the client's object
+		if (!clientStaging()) {
+			sched::Node *n = schedAttach();
+			sched::wait(sched::submit(device_, Nodes(), Nodes(1, n), [n](void *s) { n->obj->stream_ = s; n->obj->x2z(s); }, true));
+			if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
+			domain_ = 0;
+			schedDetach();                                             // a host value lives in the client's object
+			return;
+		}
+		// take the polynomial back (waits for the gates recorded on it) and convert HERE, on the thread that asked (see hostValueUp)
+		schedDetach();
+		DirectGates here;
+		x2z(st);
 		return;
 	}
 	GateScope chain;                                           // r2z ends with the copy to the host and its own synchronise
@@ -592,6 +614,7 @@ void CuPolynomial::x2z(cudaStream_t st) {
 void CuPolynomial::x2r(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ == 1 || domain_ < 0) return;
+		if (domain_ == 0 && clientStaging()) { hostValueUp(st); if (domain_ == 1) return; }
 		RECORD_SELF(x2r(s));
 		if (domain_ == 3) { isProd_ = false; prodTerms_ = 0; }
 		domain_ = 1;
@@ -604,6 +627,7 @@ void CuPolynomial::x2r(cudaStream_t st) {
 void CuPolynomial::x2c(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ == 2 || domain_ < 0) return;
+		if (domain_ == 0 && clientStaging()) { hostValueUp(st); if (domain_ == 2) return; }
 		CuCtxt *ct = dynamic_cast<CuCtxt *>(this);
 		if (ct && domain_ == 3) RECORD_SELF_BATCH(x2c(s), kBatchX2C, batchKey(ct->level(), 3, isProd_));
 		else RECORD_SELF(x2c(s));
@@ -618,6 +642,7 @@ void CuPolynomial::x2c(cudaStream_t st) {
 void CuPolynomial::x2n(cudaStream_t st) {
 	if (scheduled()) {
 		if (domain_ == 3 || domain_ < 0) return;
+		if (domain_ == 0 && clientStaging()) { hostValueUp(st); if (domain_ == 3) return; }
 		CuCtxt *ct = dynamic_cast<CuCtxt *>(this);
 		if (ct && domain_ == 2) RECORD_SELF_BATCH(x2n(s), kBatchX2N, batchKey(ct->level(), 2, false));
 		else RECORD_SELF(x2n(s));

@@ -94,6 +94,7 @@ protected:
 	void schedRelease();             // let go of the node: its buffers are released by a recorded task
 	void z2r(cudaStream_t st = 0);   // ZZX -> RAW
 	void r2z(cudaStream_t st = 0);   // RAW -> ZZX
+	void hostValueUp(cudaStream_t st);   // (addition, scheduled mode) ZZX -> RAW at once, on the calling (client) thread
 	void r2c(cudaStream_t st = 0);   // CRT
 	void c2r(cudaStream_t st = 0);   // ICRT
 	void c2n(cudaStream_t st = 0);   // NTT

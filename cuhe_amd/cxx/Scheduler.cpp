@@ -79,6 +79,7 @@ struct Task {
 	std::atomic<bool> issued{false};       // set under the lock of device `dev`, after ss / seq
 	StreamState *ss = nullptr; long seq = 0;     // where it ran: task #seq of that stream
 	int kind = 0; long key = 0; Node *subject = nullptr, *op1 = nullptr, *op2 = nullptr;      // batchable gate (Scheduler.h)
+	bool blocking = false;                 // ends with a wait on the host (a copy to or from the host and its synchronise): kept off the workers that take groups
 	std::atomic<int> refs{1};              // the graph itself until the task has run; + nodes, successors, waiters
 };
 
@@ -95,11 +96,15 @@ struct DevState {
 	std::condition_variable cv;
 	std::deque<Task *> ready;              // tasks that were ready when the client recorded them, or that another device's worker made ready
 	std::vector<std::deque<Task *>> local; // per worker: tasks its own tasks made ready (newest at the back; thieves take the oldest)
+	std::deque<Task *> blocking;           // ready tasks that block their worker on the host (uploads, x2z): for the workers that take no groups, when there are any
 	std::map<GroupKey, Group> staged;      // batchable ready tasks by (kind, key)
 	std::map<GroupKey, long> groupPending; // batchable tasks of that (kind, key) recorded but not staged yet
 	long stagedCount = 0;
 	int busyRegular = 0, busyBatch = 0;    // workers inside a regular task / inside a batch
 	int batchIdle = 0;                     // workers that take groups and are waiting for work right now
+	std::atomic<long> epoch{0};            // bumped whenever a waiting worker might find something new (work made ready, a busy count dropped): what a worker that
+	                                       // SPINS for a moment before it sleeps watches -- a condition-variable wake-up costs 20-60 us, and a client that blocks once per
+	                                       // S-box (the reference's Prince.cu: ZZX in, ZZX out) pays it on every step of the S-box's dependency chain
 	std::vector<std::thread> workers;
 	int started = 0;
 	bool used = false;
@@ -120,6 +125,10 @@ int workersPerDev = 3, stealing = 1, policy = 1, trace = 0;
 int batchWorkers = 1;                      // how many of a device's workers take staged groups (0 = all; CUHE_SCHED_BATCH_WORKERS).  ONE: the batches of a device
                                            // follow each other on one stream with one set of batch scratch, the other workers run the regular tasks --
                                            // PRINCE gate by gate 0.074-0.085 s against 0.090-0.110 s with every worker taking groups (profiles/r05_sched_prince.txt)
+long spinNs = 40000;                       // a worker with nothing to do polls its device's epoch for this long before it sleeps (CUHE_SCHED_SPIN_US; 0 = sleep at once)
+std::atomic<int> clientsWaiting{0};        // client threads blocked in wait() / drain(): they record nothing while they wait, so a group they were feeding has stopped growing
+std::atomic<int> resultWaiters{0};         // ... of them, those that wait for ONE result (x2z, a raw pointer: wait() / waitNode()), not for everything (drain()): while there
+                                           // are any, the device runs for LATENCY -- a group goes as soon as a worker is free for it, whatever is still in flight (takeBatch)
 long quietNs = 100000;                     // policies 1, 2: a group the CLIENT is adding ready gates to right now is taken only after it has been quiet for this long (CUHE_SCHED_QUIET_US)
 BatchRunner batchRunner = nullptr; int maxBatch = 1;
 thread_local bool tlsWorker = false;
@@ -158,6 +167,7 @@ void pruneReaders(Node *n) {               // recMu held
 // the stream of `me` (a worker's own, on device `dev`) waits until task #seq of `from` has finished, unless it has done so already;
 // returns the number of events recorded (0 or 1), *waited: whether a wait was enqueued
 std::atomic<long> waitsSkipped{0}, waitsDone{0};
+int latencyOn = 1;                         // CUHE_SCHED_LATENCY=0: no latency mode, host-blocking tasks on any worker (A/B)
 int waitDedup = 1, releaseOnlyOn = 1;      // CUHE_SCHED_WAIT_DEDUP / CUHE_SCHED_RELEASE_ONLY = 0: the behaviour before (A/B runs)
 int orderAfter(int dev, StreamState *me, StreamState *from, long seq, bool *waited = nullptr) {
 	std::pair<StreamState *, long> *mine = nullptr;
@@ -213,9 +223,12 @@ void flushCache() {                        // the devices have been synchronised
 }
 
 // D.m held: this worker's newest task, else the oldest the client recorded, else the oldest of the fullest other worker of the device
+inline bool takesGroups(int me) { return batchWorkers <= 0 || me < batchWorkers; }
+inline bool keepsOffBlocking(int me) { return batchWorkers > 0 && me < batchWorkers && workersPerDev > batchWorkers; }     // a group taker with colleagues that are not
 Task *takeTask(DevState &D, int me) {
 	if (!D.local[me].empty()) { Task *t = D.local[me].back(); D.local[me].pop_back(); return t; }
 	if (!D.ready.empty()) { Task *t = D.ready.front(); D.ready.pop_front(); return t; }
+	if (!D.blocking.empty() && !keepsOffBlocking(me)) { Task *t = D.blocking.front(); D.blocking.pop_front(); return t; }
 	size_t best = 0; int from = -1;
 	for (size_t w = 0; w < D.local.size(); ++w) if (D.local[w].size() > best) { best = D.local[w].size(); from = (int)w; }
 	if (from < 0) return nullptr;
@@ -247,8 +260,11 @@ bool takeBatch(DevState &D, std::vector<Task *> &batch, long *retryNs) {
 		if (pick == D.staged.end()) {
 			// only incomplete groups.  What a regular task in flight makes ready may belong to any of them; so may what the
 			// batch in flight on another worker makes ready (policy 1 waits for that too)
-			if (D.busyRegular > 0) return false;
-			if (policy == 1 && D.busyBatch > 0) return false;
+			// -- unless a client is blocked on a result: then the oldest group goes now (the worker asking is free, and what is in flight may be the
+			// upload or the copy down of ANOTHER client thread, hundreds of microseconds on the host; groups still fill up while the takers are busy)
+			const bool latency = latencyOn && resultWaiters.load(std::memory_order_relaxed) > 0;
+			if (D.busyRegular > 0 && !latency) return false;
+			if (policy == 1 && D.busyBatch > 0 && !latency) return false;
 			for (auto it = D.staged.begin(); it != D.staged.end(); ++it) {
 				if (it->second.q.empty()) continue;
 				if (pick == D.staged.end() || it->second.q.front()->id < pick->second.q.front()->id) pick = it;
@@ -258,7 +274,7 @@ bool takeBatch(DevState &D, std::vector<Task *> &batch, long *retryNs) {
 		if (pick == D.staged.end()) return false;
 		// the client is recording this very group (its gates are ready as they are recorded, so nothing is "pending" -- the first layers
 		// of a circuit, before the client is ahead of the workers): a group that is not full waits until it has been quiet for quietNs
-		if ((int)pick->second.q.size() < maxBatch && quietNs > 0 && pick->second.fromClient) {
+		if ((int)pick->second.q.size() < maxBatch && quietNs > 0 && pick->second.fromClient && clientsWaiting.load(std::memory_order_relaxed) == 0) {
 			const long age = (long)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - pick->second.lastArrival).count();
 			if (age < quietNs) { *retryNs = quietNs - age; return false; }
 		}
@@ -284,13 +300,22 @@ void makeReady(Task *t, Task **next) {
 		// the one woken must be a worker that takes groups: with a restricted set, everybody is woken -- but only when one of that set
 		// is waiting at all (it is busy most of the time and finds the group when it comes back; a broadcast per staged gate showed as
 		// 5 % of the busy worker's time in the sampling profile)
+		D.epoch.fetch_add(1, std::memory_order_release);
 		if (batchWorkers <= 0) D.cv.notify_one(); else if (D.batchIdle > 0) D.cv.notify_all();
+		return;
+	}
+	if (t->blocking && latencyOn && workersPerDev > batchWorkers && batchWorkers > 0) {        // to a worker that takes no groups (whoever is woken may be one that does: wake all)
+		std::lock_guard<std::mutex> lk(D.m);
+		D.blocking.push_back(t);
+		D.epoch.fetch_add(1, std::memory_order_release);
+		D.cv.notify_all();
 		return;
 	}
 	if (next && !*next && t->dev == tlsDev) { *next = t; return; }      // follow the chain on this stream: no event wait, warm scratch
 	std::lock_guard<std::mutex> lk(D.m);
 	if (tlsWorker && t->dev == tlsDev && stealing && tlsIndex >= 0 && tlsIndex < (int)D.local.size()) D.local[tlsIndex].push_back(t);
 	else D.ready.push_back(t);
+	D.epoch.fetch_add(1, std::memory_order_release);
 	D.cv.notify_one();
 }
 // streams of workers that have gone (setScheduled(false) ; setScheduled(true) cycles): a stream costs ~10 ms to create, and issued
@@ -335,12 +360,23 @@ void workerMain(DevState *Dp, int me) {
 			for (;;) {
 				if (Task *t = takeTask(D, me)) { batch.push_back(t); break; }
 				long retryNs = 0;
-				if ((batchWorkers <= 0 || me < batchWorkers) && takeBatch(D, batch, &retryNs)) break;
+				if (takesGroups(me) && takeBatch(D, batch, &retryNs)) break;
 				if (stopping.load()) return;
-				const bool takesGroups = batchWorkers <= 0 || me < batchWorkers;
-				if (takesGroups) ++D.batchIdle;
+				if (spinNs > 0) {                  // poll for a moment (lock released) before going to sleep
+					const long seen = D.epoch.load(std::memory_order_acquire);
+					lk.unlock();
+					const auto until = clk::now() + std::chrono::nanoseconds(retryNs > 0 && retryNs < spinNs ? retryNs : spinNs);
+					bool changed = false;
+					while (!(changed = D.epoch.load(std::memory_order_acquire) != seen) && !stopping.load(std::memory_order_relaxed) && clk::now() < until) __builtin_ia32_pause();
+					lk.lock();
+					// (a bump or a stop between the last poll and the lock would otherwise be slept through: every bump happens before its notify)
+					if (stopping.load()) return;
+					if (changed || D.epoch.load(std::memory_order_acquire) != seen || (retryNs > 0 && retryNs <= spinNs)) continue;
+				}
+				const bool groupTaker = takesGroups(me);
+				if (groupTaker) ++D.batchIdle;
 				if (retryNs > 0) D.cv.wait_for(lk, std::chrono::nanoseconds(retryNs)); else D.cv.wait(lk);
-				if (takesGroups) --D.batchIdle;
+				if (groupTaker) --D.batchIdle;
 			}
 			D.idleSeconds += std::chrono::duration<double>(clk::now() - w0).count();
 		}
@@ -419,6 +455,7 @@ void workerMain(DevState *Dp, int me) {
 		for (CuPolynomial *p : dead) delete p;
 		lk.lock();
 		if (asBatch) --D.busyBatch; else --D.busyRegular;                // (only now: what this task made ready has been staged)
+		D.epoch.fetch_add(1, std::memory_order_release);
 		if (D.stagedCount && D.batchIdle > 0 && (D.busyRegular == 0 || batchWorkers > 0)) D.cv.notify_all();     // groups that waited for the work in flight to drain
 	}
 }
@@ -469,8 +506,8 @@ void dumpState(const char *where, Task *stuck) {
 		if (!lk.owns_lock()) { fprintf(stderr, "  device %d: its lock is HELD (a worker is inside the queues)\n", d); continue; }
 		if (D->workers.empty() && !D->used) continue;
 		size_t local = 0; for (auto &q : D->local) local += q.size();
-		fprintf(stderr, "  device %d: %zu worker(s), ready %zu, local %zu, staged %ld in %zu group(s), busy regular %d / batch %d, group takers idle %d\n", d, D->workers.size(),
-		        D->ready.size(), local, D->stagedCount, D->staged.size(), D->busyRegular, D->busyBatch, D->batchIdle);
+		fprintf(stderr, "  device %d: %zu worker(s), ready %zu, host-blocking %zu, local %zu, staged %ld in %zu group(s), busy regular %d / batch %d, group takers idle %d\n", d, D->workers.size(),
+		        D->ready.size(), D->blocking.size(), local, D->stagedCount, D->staged.size(), D->busyRegular, D->busyBatch, D->batchIdle);
 		for (auto &g : D->staged) {
 			auto gp = D->groupPending.find(g.first);
 			fprintf(stderr, "    group kind %d key %ld: %zu staged (oldest #%ld), %ld still on their way%s\n", g.first.kind, g.first.key, g.second.q.size(),
@@ -481,7 +518,27 @@ void dumpState(const char *where, Task *stuck) {
 	fflush(stderr);
 }
 // cvDone.wait with the watchdog; doneMu held through lk
+struct ClientWaiting {                     // a client thread inside wait() / drain(): groups it was feeding have stopped growing -- no "quiet" delay for them
+	const bool result;                     // ... inside wait(): for one result (resultWaiters)
+	explicit ClientWaiting(bool oneResult) : result(oneResult) {
+		const bool first = clientsWaiting.fetch_add(1, std::memory_order_acq_rel) == 0;
+		const bool firstResult = result && resultWaiters.fetch_add(1, std::memory_order_acq_rel) == 0;
+		if (first || firstResult)            // what the group takers decided not to take may go now
+			for (DevState *D : devs) if (D) { D->epoch.fetch_add(1, std::memory_order_release); { std::lock_guard<std::mutex> lk(D->m); } D->cv.notify_all(); }
+	}
+	~ClientWaiting() { if (result) resultWaiters.fetch_sub(1, std::memory_order_acq_rel); clientsWaiting.fetch_sub(1, std::memory_order_acq_rel); }
+};
 template <typename Pred> void waitDone(std::unique_lock<std::mutex> &lk, const char *where, Task *stuck, Pred pred) {
+	if (pred()) return;
+	if (tlsWorker) { cvDone.wait(lk, pred); return; }          // (never: workers do not wait on tasks)
+	lk.unlock();
+	ClientWaiting here(stuck != nullptr);
+	if (spinNs > 0) {                          // the answer is usually microseconds away: poll before sleeping
+		const auto until = clk::now() + std::chrono::nanoseconds(4 * spinNs);
+		while (!pred() && clk::now() < until) __builtin_ia32_pause();
+	}
+	lk.lock();
+	if (pred()) return;
 	const long limit = watchdogSeconds();
 	if (limit <= 0) { cvDone.wait(lk, pred); return; }
 	long seen = issuedTotal.load(std::memory_order_relaxed);
@@ -521,9 +578,11 @@ void start(int n) {
 	if (getenv("CUHE_SCHED_LOCAL")) stealing = atoi(getenv("CUHE_SCHED_LOCAL"));
 	if (getenv("CUHE_SCHED_POLICY")) policy = atoi(getenv("CUHE_SCHED_POLICY"));
 	if (getenv("CUHE_SCHED_QUIET_US")) quietNs = 1000L * atol(getenv("CUHE_SCHED_QUIET_US"));
+	if (getenv("CUHE_SCHED_SPIN_US")) spinNs = 1000L * atol(getenv("CUHE_SCHED_SPIN_US"));
 	if (getenv("CUHE_SCHED_BATCH_WORKERS")) batchWorkers = atoi(getenv("CUHE_SCHED_BATCH_WORKERS"));
 	if (getenv("CUHE_SCHED_WAIT_DEDUP")) waitDedup = atoi(getenv("CUHE_SCHED_WAIT_DEDUP"));
 	if (getenv("CUHE_SCHED_RELEASE_ONLY")) releaseOnlyOn = atoi(getenv("CUHE_SCHED_RELEASE_ONLY"));
+	if (getenv("CUHE_SCHED_LATENCY")) latencyOn = atoi(getenv("CUHE_SCHED_LATENCY"));
 	trace = getenv("CUHE_SCHED_TRACE") ? atoi(getenv("CUHE_SCHED_TRACE")) : 0;
 	const int nd = std::max(1, std::min(cuhe_hip_num_gpus(), kMaxDevices));
 	for (int d = 0; d < nd; ++d) ensureWorkers(d);
@@ -684,6 +743,8 @@ Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *
 	if (dev < 0) dev = 0;                       // (an object that was never placed: its task only releases host state)
 	ensureWorkers(dev);
 	Task *t = new Task;
+	if (kind == kHostBlocking) { t->blocking = true; kind = 0; }
+	if (keep && kind == 0) t->blocking = true;  // (the client waits for it: x2z ends with the copy down and its synchronise; a batchable gate somebody waits for is still a gate)
 	t->fn = std::move(fn); t->dev = dev; t->kind = kind; t->key = key; t->subject = subject; t->op1 = op1; t->op2 = op2;
 	const bool batchable = kind > 0 && batchRunner && maxBatch > 1;
 	{

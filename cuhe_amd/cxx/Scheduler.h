@@ -49,6 +49,10 @@ void releaseNode(Node *n);                 // the client object lets go (tasks m
 // waits for nothing on its worker's stream: every block it releases carries the positions of the task's dependencies (the block's real
 // last uses), so that the next taker on the stream of those uses -- the batch of the next layer -- gets it without any event.
 constexpr int kReleaseOnly = -1;
+// kind == kHostBlocking (and every task submitted with keep = true): fn ends with a wait on the host -- an upload from a host value, the copy
+// down of x2z, each with its synchronise.  Such a task goes to a worker that takes NO groups when the device has one, so that the batches
+// of the other client threads do not queue behind a PCIe copy.
+constexpr int kHostBlocking = -2;
 Task *submit(int dev, const std::vector<Node *> &reads, const std::vector<Node *> &writes, std::function<void(void *)> fn, bool keep = false,
              int kind = 0, long key = 0, Node *subject = nullptr, Node *op1 = nullptr, Node *op2 = nullptr);
 typedef void (*BatchRunner)(int kind, Node *const *subjects, Node *const *op1, Node *const *op2, int count, void *stream);

@@ -99,7 +99,10 @@ struct Gate {
 	std::vector<int> mustFollow;                       // gate ids, from the test's own model of the dependency rule
 	std::atomic<int> runs{0};
 	mock::Clock stamp; int stream = -1;
+	bool blocking = false;                             // sched::kHostBlocking or keep = true: must not run on a worker that takes groups when the device has others
 };
+// streams that ran the batch runner / that ran host-blocking gates, per program (round 6: Scheduler.h, kHostBlocking)
+std::set<int> groupStreams, blockingStreams;
 std::vector<Gate *> gates;
 std::mutex gm;
 std::atomic<long> failures{0}, batchesSeen{0}, batchedGates{0};
@@ -148,6 +151,7 @@ void runGate(Gate *g, void *stream) {
 			if (seen < need) fail("device order: the producer's launch does not precede the consumer's", g->id, d);
 		}
 		g->stamp = now; g->stream = mock::idOf(stream);
+		if (g->blocking) blockingStreams.insert(g->stream);
 	}
 	if (g->runs.fetch_add(1) != 0) fail("gate ran twice", g->id);
 }
@@ -166,6 +170,7 @@ void batchRunner(int kind, sched::Node *const *subjects, sched::Node *const *, s
 	++batchesSeen; batchedGates += count;
 	int seen = maxBatchSeen.load(); while (count > seen && !maxBatchSeen.compare_exchange_weak(seen, count)) {}
 	if (count < 2) fail("batch runner called for fewer than two gates", count);
+	{ std::lock_guard<std::mutex> lk(gm); groupStreams.insert(mock::idOf(stream)); }
 	Gate *first = nullptr;
 	for (int i = 0; i < count; ++i) {
 		Gate *g;
@@ -185,6 +190,7 @@ void batchRunner(int kind, sched::Node *const *subjects, sched::Node *const *, s
 // one random program: `nodes` polynomials spread over `ndev` devices, `ngates` gates
 void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int policyNo, int cap, bool blocks = false, int workers = 3) {
 	mock::numGpus = ndev;
+	groupStreams.clear(); blockingStreams.clear();
 	blocksOn = blocks; blk.assign(nodesN, nullptr); uses.clear();
 	setenv("CUHE_SCHED_POLICY", std::to_string(policyNo).c_str(), 1);
 	sched::setBatchRunner(batches ? batchRunner : nullptr, cap);
@@ -213,6 +219,7 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 		g->kind = isBatchable ? 1 + (int)(rng() % 3) : 0;
 		const bool release = blocks && rng() % 5 == 0;                    // the polynomial is reset: a release-only task
 		if (release) { rd.clear(); g->kind = sched::kReleaseOnly; }
+		else if (!isBatchable && rng() % 3 == 0) { g->kind = sched::kHostBlocking; g->blocking = true; }      // an upload from a host value
 		g->w = w; g->rd = rd; g->allocs = blocks && rng() % 2 == 0;
 		g->key = (long)(rng() % 2);
 		// the dependency rule, restated: after the last writer of everything touched, and after every reader since of what is written
@@ -228,9 +235,10 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 		for (int r : rd) reads.push_back(nodes[r]);
 		if (g->kind > 0) { std::lock_guard<std::mutex> lk(gm); pendingBySubject[nodes[w]].push_back(g); }
 		const bool keep = rng() % 50 == 0;
+		if (keep && g->kind == 0) g->blocking = true;
 		sched::Task *task = sched::submit(g->dev, reads, writes, [g](void *s) {
 			if (g->kind == sched::kReleaseOnly) { runRelease(g, s); return; }
-			if (g->kind) {                                   // ran alone although batchable: take it off its subject's list
+			if (g->kind > 0) {                                   // ran alone although batchable: take it off its subject's list
 				std::lock_guard<std::mutex> lk(gm);
 				for (auto &kv : pendingBySubject) { auto &v = kv.second; for (size_t i = 0; i < v.size(); ++i) if (v[i] == g) { v.erase(v.begin() + i); goto done; } }
 				done:;
@@ -243,6 +251,7 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 	}
 	for (sched::Task *k : kept) sched::wait(k);
 	sched::drain();
+	if (workers > 1) for (int sid : blockingStreams) if (groupStreams.count(sid)) fail("a host-blocking task ran on a worker that takes groups", sid, workers);
 	for (Gate *g : gates) if (g->runs.load() != 1) fail("gate did not run exactly once", g->id, g->runs.load());
 	if (sched::stats().tasks != ngates) fail("task count", (int)sched::stats().tasks, ngates);
 	for (sched::Node *n : nodes) sched::releaseNode(n);
@@ -250,6 +259,69 @@ void program(int ndev, int nodesN, int ngates, unsigned seed, bool batches, int 
 	sched::stop();
 	if (sched::on() || sched::threads() != 0) fail("stop() left workers behind");
 	blocksOn = false;
+}
+// Several CLIENT threads, each recording chains of gates on its own polynomials and blocking on a result after every chain (the reference's PRINCE
+// client: one OpenMP thread per S-box, ZZX in, gates, x2z -- Prince.cu:188-322).  While a client waits for ONE result the device runs for latency: groups
+// go before they are complete although other clients' uploads / copies down are in flight; the rules checked are the same -- host order, device
+// order, every gate once, the result is there when wait() returns, host-blocking tasks stay off the group takers.
+void clientThreads(int ndev, int T, int rounds, int workers, int policyNo, unsigned seed) {
+	mock::numGpus = ndev;
+	groupStreams.clear(); blockingStreams.clear();
+	blocksOn = false;
+	setenv("CUHE_SCHED_POLICY", std::to_string(policyNo).c_str(), 1);
+	sched::setBatchRunner(batchRunner, 64);
+	sched::start(workers);
+	const int per = 12, mine = 6;
+	for (Gate *g : gates) delete g;
+	gates.assign((size_t)T * rounds * per, nullptr); pendingBySubject.clear();
+	std::atomic<int> nextGate{0};
+	std::vector<std::thread> clients;
+	for (int t = 0; t < T; ++t) clients.emplace_back([&, t] {
+		std::mt19937 rng(seed + 31u * t);
+		const int dev = t % ndev;
+		std::vector<sched::Node *> nodes(mine);
+		for (auto &n : nodes) n = sched::newNode(nullptr);
+		std::vector<int> lastWrite(mine, -1);
+		std::vector<std::vector<int>> readers(mine);
+		for (int r = 0; r < rounds; ++r)
+			for (int k = 0; k < per; ++k) {
+				const bool last = k == per - 1;
+				Gate *g = new Gate;
+				g->id = nextGate.fetch_add(1); g->dev = dev;
+				const int w = (int)(rng() % mine);
+				std::vector<int> rd;
+				for (int i = (int)(rng() % 3); i > 0; --i) rd.push_back((int)(rng() % mine));
+				g->kind = last ? 0 : k < 2 ? (int)sched::kHostBlocking : 1 + (int)(rng() % 3);       // two uploads, gates, the copy down
+				g->blocking = last || g->kind == sched::kHostBlocking;
+				g->key = (long)(r % 2); g->w = w; g->rd = rd;
+				std::set<int> mf;
+				for (int x : rd) if (lastWrite[x] >= 0) mf.insert(lastWrite[x]);
+				if (lastWrite[w] >= 0) mf.insert(lastWrite[w]);
+				for (int x : readers[w]) mf.insert(x);
+				g->mustFollow.assign(mf.begin(), mf.end());
+				for (int x : rd) if (x != w) readers[x].push_back(g->id);
+				lastWrite[w] = g->id; readers[w].clear();
+				{ std::lock_guard<std::mutex> lk(gm); gates[g->id] = g; if (g->kind > 0) pendingBySubject[nodes[w]].push_back(g); }
+				std::vector<sched::Node *> reads, writes(1, nodes[w]);
+				for (int x : rd) reads.push_back(nodes[x]);
+				sched::Task *task = sched::submit(dev, reads, writes, [g](void *s) {
+					if (g->kind > 0) {
+						std::lock_guard<std::mutex> lk(gm);
+						for (auto &kv : pendingBySubject) { auto &v = kv.second; for (size_t i = 0; i < v.size(); ++i) if (v[i] == g) { v.erase(v.begin() + i); goto done; } }
+						done:;
+					}
+					runGate(g, s);
+				}, last, g->kind, g->key, g->kind > 0 ? nodes[w] : nullptr, nullptr, nullptr);
+				if (last) { sched::wait(task); if (g->runs.load() != 1) fail("wait() returned before the task had run", g->id); }
+			}
+		for (auto &n : nodes) sched::releaseNode(n);
+	});
+	for (auto &c : clients) c.join();
+	sched::drain();
+	if (workers > 1) for (int sid : blockingStreams) if (groupStreams.count(sid)) fail("a host-blocking task ran on a worker that takes groups", sid, workers);
+	for (Gate *g : gates) if (!g || g->runs.load() != 1) fail("gate did not run exactly once (client threads)", g ? g->id : -1);
+	if (sched::stats().tasks != (long)gates.size()) fail("task count (client threads)", (int)sched::stats().tasks, (int)gates.size());
+	sched::stop();
 }
 //  blocks and threads that have no stream on the block's device.  A task of device 0 that allocates on device 1 (work after a moveTo /
 // copyTo) cannot be ordered behind the last use of a block in device 1's cache: it must get a FRESH block from the library, and handing it
@@ -406,6 +478,10 @@ int main(int argc, char **argv) {
 						}
 					}
 				}
+	for (int round = 0; round < rounds; ++round)
+		for (int ndev : {1, 2})
+			for (int workers : {1, 2, 3})
+				for (int pol : {1, 2}) { clientThreads(ndev, 8, 40, workers, pol, 500u * round + 10u * workers + pol); ++programs; }
 	crossDeviceBlocks();
 	if (blocksTaken.load() < 1000 || blocksReused.load() * 4 < blocksTaken.load() || blocksReleased.load() * 2 < blocksTaken.load())
 		fail("the block model did not exercise reuse", (int)blocksTaken.load(), (int)blocksReused.load());

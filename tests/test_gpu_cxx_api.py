@@ -55,10 +55,14 @@ def test_dhs_scheme_flow(params, sched):
 @pytest.mark.parametrize("flags", [["--threads", "8"], ["--threads", "4", "--async"], ["--threads", "1", "--async"],
                                    ["--threads", "6", "--async", "--devices", "3", "--virtual"],
                                    ["--threads", "1", "--sched"], ["--threads", "1", "--sched", "3", "--devices", "3", "--virtual"],
-                                   ["--threads", "1", "--sched", "5", "--no-batching"], ["--threads", "1", "--default"], ["--threads", "1", "--sched", "1"]],
+                                   ["--threads", "1", "--sched", "5", "--no-batching"], ["--threads", "1", "--default"], ["--threads", "1", "--sched", "1"],
+                                   ["--threads", "8", "--zzx-state", "--default"], ["--threads", "1", "--zzx-state", "--default"], ["--threads", "8", "--zzx-state"],
+                                   ["--threads", "4", "--zzx-state", "--default", "--devices", "3", "--virtual"]],
                          ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices",
                               "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices", "scheduled-1-thread-no-batching",
-                              "library-default-1-thread", "scheduled-1-thread-1-worker"])
+                              "library-default-1-thread", "scheduled-1-thread-1-worker",
+                              "zzx-state-library-default-8-threads", "zzx-state-library-default-1-thread", "zzx-state-sync-8-threads",
+                              "zzx-state-library-default-3-virtual-devices"])
 def test_prince_known_answer(flags):
     """BASELINE config 5 on one GPU: homomorphic PRINCE through CuHE.h (tests/cxx/test_prince_flow.cpp).  The
     reference's known answer 0x9fb51935fc3df524 (examples/Prince/Prince.cu:96) and its 12 intermediate round states
@@ -69,7 +73,9 @@ def test_prince_known_answer(flags):
     threads, moveTo to and from the device that holds the state) on three virtual devices of the one GPU.
     scheduled-*: ONE client thread, default stream, a gate per call (the reference client's pattern) with the library's gate
     scheduler on (setScheduled): ready gates of one kind run as one call of the array entry points; CUHE_SCHED_CHECK=1
-    verifies the client-side metadata mirrors whenever an object is taken back."""
+    verifies the client-side metadata mirrors whenever an object is taken back.
+    zzx-state-*: the reference example's LITERAL structure (Prince.cu:188-322): the state lives on the host as ZZX between S-boxes, every
+    S-box hands four ZZX in (setLevel(lvl, dev, ZZX)) and takes four back (x2z ; zRep), the linear layers are host additions."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
