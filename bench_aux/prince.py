@@ -85,6 +85,20 @@ def bench_prince_gate_by_gate():
                                                if ok2 else {"error": (r2.stdout[-200:] + r2.stderr[-200:]).strip()})
         except Exception as ex:
             secs["library_default_1thread"] = {"error": repr(ex)[:200]}
+        # the reference example's LITERAL structure (Prince.cu:188-322): the state lives on the host as ZZX between S-boxes, every S-box hands four
+        # ZZX in and takes four back, 8 client threads (one per S-box in flight).  Library default against CUHE_SCHED=0; the host linear layers (fallback
+        # big integer) are excluded from the time by the program, the client's own ZZX copies are not.
+        try:
+            lit = {"unit": "s per PRINCE block, ZZX state on the host between S-boxes (test_prince_flow --zzx-state), 8 client threads", "blocks_per_process": 3}
+            for name, extra in (("library_default", {}), ("synchronous", {"CUHE_SCHED": "0"})):
+                env = dict(os.environ); env.pop("CUHE_SCHED", None); env.update(extra)
+                r3 = subprocess.run([exe, "--threads", "8", "--zzx-state", "--no-round-checks", "--default", "--repeat", "3"], capture_output=True, text=True, timeout=900, env=env)
+                lines = [l for l in r3.stdout.splitlines() if l.startswith("Prince Encryption:")]
+                ok3 = r3.returncode == 0 and len(lines) == 3 and r3.stdout.count("9fb51935fc3df524   expected 9fb51935fc3df524   right") == 3
+                lit[name] = sorted(float(l.split()[2]) for l in lines)[1] if ok3 else {"error": (r3.stdout[-200:] + r3.stderr[-200:]).strip()}
+            secs["literal_client_zzx_state_8threads"] = lit
+        except Exception as ex:
+            secs["literal_client_zzx_state_8threads"] = {"error": repr(ex)[:200]}
         return secs
     except Exception as ex:
         return {"error": repr(ex)[:300]}

@@ -31,6 +31,9 @@ run "test_prince_flow --default (1 client thread)"   5 "ALL PASSED" $L/test_prin
 run "test_prince_flow --default, round states"       2 "ALL PASSED" $L/test_prince_flow --threads 1 --default
 run "test_prince_flow --default 8 client threads"    3 "ALL PASSED" $L/test_prince_flow --threads 8 --default --no-round-checks
 run "test_prince_flow --default 3 virtual devices"   3 "ALL PASSED" $L/test_prince_flow --threads 1 --default --no-round-checks --devices 3 --virtual
+run "test_prince_flow --zzx-state --default 8 client threads" 3 "ALL PASSED" $L/test_prince_flow --threads 8 --zzx-state --default --no-round-checks
+run "test_prince_flow --zzx-state --default 1 thread, round states" 1 "ALL PASSED" $L/test_prince_flow --threads 1 --zzx-state --default
+run "test_prince_flow --zzx-state --default 6 threads 3 virtual devices" 2 "ALL PASSED" $L/test_prince_flow --threads 6 --zzx-state --default --no-round-checks --devices 3 --virtual
 run "test_multi_device (3 virtual devices)"          5 "ALL PASSED" $L/test_multi_device
 export CUHE_SCHED=1
 run "test_prince_batched (C-ABI arrays), CUHE_SCHED=1" 3 "ALL PASSED" $L/test_prince_batched
