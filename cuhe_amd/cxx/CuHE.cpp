@@ -523,6 +523,7 @@ void CuPolynomial::hostValueUp(cudaStream_t st) {
 	if (node_) schedDetach();                                  // (attached in the ZZX domain: a recorded copy of a host value)
 	DirectGates here;
 	z2r(st);
+	sched::adoptBlock(device_, rRep_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());     // (idle after z2r's synchronise)
 }
 void CuPolynomial::r2c(cudaStream_t st) {
 	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }

@@ -632,6 +632,16 @@ void *taskAlloc(int dev, size_t bytes) {
 	C.sizeOf[p] = bytes;
 	return p;
 }
+// a block the CLIENT thread took from the library for a polynomial that now enters the graph (the upload of a host value, CuHE.cpp: hostValueUp):
+// nothing is pending on it, and the task that releases it may keep it for the next taker like one of taskAlloc's -- otherwise it goes back through
+// the library's stream-ordered pool and the next stream to take it waits for the whole stream that released it (39 such hand-overs per PRINCE block)
+void adoptBlock(int dev, void *p, size_t bytes) {
+	if (!p || dev < 0 || dev >= kMaxDevices || !active.load(std::memory_order_acquire)) return;
+	BlockCache &C = caches[dev];
+	std::lock_guard<std::mutex> lk(C.m);
+	C.checkGeneration();
+	C.sizeOf[p] = bytes;
+}
 void forgetBlock(void *p) {                // released outside a task (the client thread, after a detach): the library owns it again
 	for (int d = 0; d < kMaxDevices; ++d) {
 		if (!devs[d]) continue;               // (blocks are only ever handed out on devices that have run tasks)

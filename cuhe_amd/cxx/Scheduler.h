@@ -65,6 +65,7 @@ void drain();                              // until everything recorded so far h
 void *taskAlloc(int dev, size_t bytes);
 bool taskFree(int dev, void *ptr);
 void forgetBlock(void *ptr);               // a block released outside any task
+void adoptBlock(int dev, void *ptr, size_t bytes);   // a block taken from the library OUTSIDE any task, idle, whose owner enters the graph: taskFree may keep it
 struct Stats { long tasks, crossStreamWaits, maxQueued; };
 Stats stats();
 
