@@ -41,6 +41,7 @@ from bench_aux.prince import bench_prince                                       
 from bench_aux.sharded import bench_mulrelin_sharded, sharded_comm_guard                  # noqa: E402,F401
 from bench_aux.ciphertext import bench_mul_full, bench_mulrelin                           # noqa: E402
 from bench_aux.cpu import cpu_ntt_baseline                                                # noqa: E402
+from bench_aux.placement import pin_process_to_gpu                                        # noqa: E402
 
 
 def main():
@@ -74,8 +75,11 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)       # the process the live PMC passes profile: 1 + 2 steps of the headline batch
     ap.add_argument("--no-limiter", action="store_true", help="skip the ~3 s clock / power / dense-stream measurement (roofline.valu_ceiling.live)")
     ap.add_argument("--perf-table", default="", help="write the bundle-size table of doc/Perf_NTT.txt (tests/test_ntt.cu:140-151) to this file and exit")
+    ap.add_argument("--no-pin", action="store_true", help="leave the process where the kernel put it (default: the CPUs local to its GPU, bench_aux/placement.py)")
     args = ap.parse_args()
     args.relin_params = RING_PARAMS[args.ring]
+    # before any HIP call: the process runs next to its GPU (CUHE_BENCH_SINGLE_DEVICE: every rank drives device 0)
+    placement = {"pinned": False, "reason": "--no-pin"} if args.no_pin else pin_process_to_gpu(0 if os.environ.get("CUHE_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
 
     import numpy as np
     import torch
@@ -363,7 +367,8 @@ def main():
             "dtype": "u64 (mod 2^64-2^32+1)", "data": "synthetic",
             "config": {"workload": "batched 64K-point forward NTT, %d transforms per step per GPU, reference contract "
                                    "of ntt_{1,2,3}_64k (cuhe/Base.cu:659-785)" % B,
-                       "transform_len": L, "batch_per_gpu": B, "sharding": "independent transforms per rank, no collective"},
+                       "transform_len": L, "batch_per_gpu": B, "sharding": "independent transforms per rank, no collective",
+                       "host_placement": placement},
             "roofline": roofline, "cpu_baseline": cpu,
             "reference_best_published": {"value": 44121, "unit": "NTT/s", "hardware": "unstated NVIDIA GPU",
                                          "source": "doc/Perf_NTT.txt:14 (bundle 512)"},

@@ -54,6 +54,8 @@ SIGNATURES = {
     "cuhe_hip_get_crt_primes": (i32, [vp, i32]),
     "cuhe_hip_reduce_kind": (i32, []),
     "cuhe_hip_force_generic_reduce": (i32, [i32]),
+    "cuhe_hip_device_local_cpus": (i32, [i32, vp, sz]),
+    "cuhe_hip_pin_thread_to_device": (i32, [i32]),
     "cuhe_hip_start_allocator": (i32, []),
     "cuhe_hip_reserve_blocks": (i32, [i32, sz, i32]),
     "cuhe_hip_stop_allocator": (i32, []),

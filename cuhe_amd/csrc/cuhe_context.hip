@@ -3,6 +3,8 @@
 // (cuhe/Base.cu:40-305, cuhe/DeviceManager.cu:40-138).  One of three translation units: cuhe_transforms.hip (NTT launch
 // sequencing), cuhe_keyswitch.hip (CRT / ICRT, relinearisation, batched and sharded chains).
 #include "cuhe_internal.hpp"
+#include <sched.h>
+#include <dirent.h>
 #include "comm.hpp"
 
 namespace cuhe_impl {
@@ -360,8 +362,110 @@ int cuhe_hip_words_coeff(int lvl) { return G_.prm.wordsCoeff(lvl); }
 int cuhe_hip_num_eval_key(int lvl) { return G_.prm.numEvalKeyAt(lvl); }
 int cuhe_hip_get_level(int logq) { return G_.prm.getLevel(logq); }
 
+// ---- the CPUs local to a device.  After the library is up the PCI function comes from HIP (hipDeviceGetPCIBusId); BEFORE any HIP call of the
+// process it is read from sysfs alone -- AMD display / processing-accelerator functions in bus order, the n-th one the runtime will show (a plain
+// integer list in HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES is followed; anything else: unknown) -- because the first HIP call already places the
+// runtime's host-side state (kernel-argument pools, signals, its helper threads) on the NUMA node of the thread that makes it.
+static bool read_line(const char *path, char *buf, size_t n) {
+    buf[0] = 0;
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const bool ok = fgets(buf, (int)n, f) != NULL;
+    fclose(f);
+    size_t k = strlen(buf);
+    while (k && (buf[k - 1] == '\n' || buf[k - 1] == ' ')) buf[--k] = 0;
+    return ok;
+}
+static std::string sysfs_gpu_bdf(int phys) {
+    int pick = phys;
+    for (const char *name : {"ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"}) {
+        const char *e = getenv(name);
+        if (!e || !*e) continue;
+        std::vector<int> ids;
+        for (const char *q = e; *q;) {
+            char *end; long v = strtol(q, &end, 10);
+            if (end == q || (*end && *end != ',')) return std::string();           // (UUIDs and the like: not guessed)
+            ids.push_back((int)v); q = *end ? end + 1 : end;
+        }
+        if (pick < 0 || pick >= (int)ids.size()) return std::string();
+        pick = ids[pick];
+    }
+    std::vector<std::string> bdfs;
+    if (DIR *d = opendir("/sys/bus/pci/devices")) {
+        while (dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            char path[320], v[64], c[64];
+            snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/vendor", e->d_name);
+            if (!read_line(path, v, sizeof v) || strcmp(v, "0x1002") != 0) continue;
+            snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/class", e->d_name);
+            if (!read_line(path, c, sizeof c)) continue;
+            if (strncmp(c, "0x03", 4) != 0 && strncmp(c, "0x12", 4) != 0) continue;   // display controllers, processing accelerators (MI300 / MI355X: 0x1200xx)
+            bdfs.push_back(e->d_name);
+        }
+        closedir(d);
+    }
+    std::sort(bdfs.begin(), bdfs.end());
+    return pick >= 0 && pick < (int)bdfs.size() ? bdfs[pick] : std::string();
+}
+static std::atomic<bool> hip_in_use{false};             // some entry point of this library has called into HIP already
+int cuhe_hip_device_local_cpus(int dev, char *buf, size_t buf_bytes) {
+    if (!buf || buf_bytes == 0) return fail(CUHE_EINVAL, "device_local_cpus: no buffer");
+    buf[0] = 0;
+    if (dev < 0) return fail(CUHE_EINVAL, "device_local_cpus: bad device");
+    std::string bdf;
+    if (G_.inited || hip_in_use.load()) {
+        char b[64] = {0};
+        if (hipDeviceGetPCIBusId(b, (int)sizeof b, phys_dev(dev)) == hipSuccess) bdf = b; else (void)hipGetLastError();
+        for (char &c : bdf) if (c >= 'A' && c <= 'F') c = (char)(c - 'A' + 'a');      // sysfs names are lower case
+    } else bdf = sysfs_gpu_bdf(phys_dev(dev));
+    if (bdf.empty()) return CUHE_OK;
+    char path[320];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf.c_str());
+    read_line(path, buf, buf_bytes);
+    return CUHE_OK;
+}
+// narrow `want` to the listed CPUs the thread may use; false when nothing would change
+static bool local_mask(int dev, cpu_set_t *want) {
+    char list[1024];
+    if (cuhe_hip_device_local_cpus(dev, list, sizeof list) != CUHE_OK || !list[0]) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed); CPU_ZERO(want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    int chosen = 0; const int had = CPU_COUNT(&allowed);
+    for (const char *p = list; *p;) {                       // "a-b,c,d-e"
+        char *e; long a = strtol(p, &e, 10); if (e == p) break;
+        long b = a; if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); if (e == p) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, want); ++chosen; }
+        if (*e != ',') break;
+        p = e + 1;
+    }
+    return chosen != 0 && chosen != had;                     // (nothing local is allowed / everything allowed is local already: leave it)
+}
+int cuhe_hip_pin_thread_to_device(int dev) {
+    cpu_set_t want;
+    if (!local_mask(dev, &want)) return 0;
+    return sched_setaffinity(0, sizeof want, &want) == 0 ? 1 : 0;
+}
+// The thread that brings the library up (multiGPUs / initCuHE: the first HIP calls of a client process) runs on the CPUs local to its device
+// WHILE it does so -- the HIP runtime's host-side state and helper threads then live next to the GPU -- and gets its own affinity back afterwards
+// (CUHE_PIN_CLIENT=1: it stays narrowed; 0: untouched).  profiles/r06_numa_pinning.txt.
+namespace {
+struct ClientPin {
+    cpu_set_t saved; bool narrowed = false;
+    ClientPin() {
+        static const int mode = getenv("CUHE_PIN_CLIENT") ? atoi(getenv("CUHE_PIN_CLIENT")) : 2;
+        if (mode <= 0) return;
+        cpu_set_t want;
+        if (sched_getaffinity(0, sizeof saved, &saved) != 0 || !local_mask(0, &want)) return;
+        narrowed = sched_setaffinity(0, sizeof want, &want) == 0 && mode == 2;
+    }
+    ~ClientPin() { if (narrowed) sched_setaffinity(0, sizeof saved, &saved); }
+};
+}
 int cuhe_hip_multi_gpus(int num) {
     int cnt = 0;
+    ClientPin local;
+    hip_in_use.store(true);
     HIPCHK(hipGetDeviceCount(&cnt));
     if (num < 1 || (!G_.virtual_devices && G_.dev_base + num > cnt)) return fail(CUHE_EINVAL, "multiGPUs(%d): %d device(s) visible", num, cnt);
     if (G_.inited) return fail(CUHE_EINVAL, "multiGPUs must precede initCuHE (cuhe/DeviceManager.cu:38-41)");
@@ -396,6 +500,8 @@ int cuhe_hip_same_ring(const int32_t *modulus, int ncoeffs) {
 
 int cuhe_hip_init(const int32_t *modulus, int ncoeffs) {
     if (!G_.params_set) return fail(CUHE_EINVAL, "setParameters must precede initCuHE");
+    ClientPin local;
+    hip_in_use.store(true);
     if (G_.inited) {
         // A second scheme object built in the same process (examples/DHS/simple_DHS.cu:176,186: CuDHS(string) runs setParameters
         // + initCuHE again while the first object is alive and is used afterwards): the reference re-creates its tables beside the

@@ -74,6 +74,15 @@ int cuhe_hip_set_device_base(int dev);
    in-process multi-device paths can run on a single-GPU box; before init */
 int cuhe_hip_set_virtual_devices(int on);
 
+/* The CPUs local to logical device `dev` (the NUMA node its PCIe root hangs off), as the kernel's cpulist string ("0-63,128-191") in buf;
+ * empty when the platform does not say.  On a two-socket MI355X host a thread that launches from the far socket pays every doorbell and every
+ * completion signal across the socket link: the gate scheduler's workers launch 900 small kernels per PRINCE block, and blocks issued from the far
+ * socket take 0.065-0.070 s against 0.058-0.059 s (profiles/r06_numa_pinning.txt).  No counterpart in the reference (one GPU per host thread,
+ * placement left to OpenMP).  cuhe_hip_pin_thread_to_device restricts the CALLING thread to those CPUs (intersected with what it may use now;
+ * nothing is changed when that is empty or the list is unknown): returns 1 if the affinity was narrowed, 0 if left alone. */
+int cuhe_hip_device_local_cpus(int dev, char *buf, size_t buf_bytes);
+int cuhe_hip_pin_thread_to_device(int dev);
+
 /* ---- init: initCuHE (cuhe/CuHE.h:153; CuHE.cu:36-50 = initNtt + initCrt + initBarrett).
  * modulus: monic integer polynomial, modLen+1 coefficients low-to-high
  * (NULL => the cyclotomic polynomial Phi_m).  Synchronous. */

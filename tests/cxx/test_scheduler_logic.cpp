@@ -75,6 +75,7 @@ int cuhe_hip_stream_wait_event(int dev, void *st, void *ev) {
 }
 int cuhe_hip_event_sync(int, void *) { return 0; }
 int cuhe_hip_device_sync(int) { return 0; }
+int cuhe_hip_pin_thread_to_device(int) { return 0; }
 // (mock::recycle: the next cuhe_hip_free keeps the pointer and the next cuhe_hip_malloc hands the SAME address out again whatever the size --
 // what a real allocator may do at any time -- for the stale-size check of crossDeviceBlocks)
 void *cuhe_hip_malloc(int, size_t bytes) {

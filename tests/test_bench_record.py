@@ -96,3 +96,27 @@ def test_sharded_value_is_refused_unless_every_rank_reports_a_communicator_of_th
         assert bench.sharded_comm_guard([info(r, world, state="not initialised") for r in range(world)], world, True) is not None
         assert bench.sharded_comm_guard([info(r, world, lib_ranks=1) for r in range(world)], world, True) is not None
     assert bench.sharded_comm_guard(["RCCL unavailable: librccl.so not found"] * 2, 2, True) is not None
+
+
+def test_gpu_local_cpus_from_a_sysfs_tree(tmp_path, monkeypatch):
+    """bench_aux/placement.py: the CPUs local to the n-th AMD GPU function in bus order (what bench.py narrows itself to before any HIP call;
+    the library's cuhe_hip_pin_thread_to_device reads the same files), visible-device lists followed, anything unparsable -> unknown."""
+    from bench_aux.placement import gpu_local_cpus
+    def dev(name, vendor, cls, cpus):
+        d = tmp_path / name; d.mkdir()
+        (d / "vendor").write_text(vendor + "\n"); (d / "class").write_text(cls + "\n"); (d / "local_cpulist").write_text(cpus + "\n")
+    dev("0000:85:00.0", "0x1002", "0x120000", "64-127,192-255")
+    dev("0000:05:00.0", "0x1002", "0x120000", "0-63,128-191")
+    dev("0000:01:00.0", "0x8086", "0x020000", "0-63")                # a NIC
+    dev("0000:03:00.0", "0x1002", "0x060400", "0-63")                # an AMD bridge: not a GPU
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    text, cpus = gpu_local_cpus(0, str(tmp_path))
+    assert text == "0-63,128-191" and cpus == set(range(0, 64)) | set(range(128, 192))
+    text, cpus = gpu_local_cpus(1, str(tmp_path))
+    assert text == "64-127,192-255" and 200 in cpus and 5 not in cpus
+    assert gpu_local_cpus(2, str(tmp_path)) == ("", set())
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    assert gpu_local_cpus(0, str(tmp_path))[0] == "64-127,192-255"
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")
+    assert gpu_local_cpus(0, str(tmp_path)) == ("", set())

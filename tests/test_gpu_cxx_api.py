@@ -209,3 +209,42 @@ def test_allocation_failure_ends_the_program_like_the_reference(n, sched):
     assert r.returncode == 255, (r.returncode, r.stdout[-1000:], r.stderr[-1000:])          # exit(-1)
     assert "cuheSafeCall() failed" in r.stderr and "injected" in r.stderr
     assert time.time() - t0 < 120
+
+
+def test_worker_threads_run_on_the_cpus_local_to_their_device():
+    """cuhe_hip_device_local_cpus / cuhe_hip_pin_thread_to_device (include/cuhe_hip.h): the kernel's local_cpulist of the GPU's PCI function, and a
+    thread narrowed to it (what the gate scheduler does with its workers: blocks issued from the far socket of a two-socket host take 0.065-0.070 s
+    against 0.058-0.059 s, profiles/r06_numa_pinning.txt).  Checked in a thread of its own: the affinity of the pytest process is left alone."""
+    import ctypes
+    import threading
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from cuhe_amd import capi
+    buf = ctypes.create_string_buffer(1024)
+    assert capi.lib.cuhe_hip_device_local_cpus(0, buf, 1024) == 0
+    cpulist = buf.value.decode()
+    print("local cpulist of device 0:", repr(cpulist))
+    out = {}
+
+    def body():
+        tid = threading.get_native_id()
+        before = os.sched_getaffinity(tid)
+        out["rc"] = capi.lib.cuhe_hip_pin_thread_to_device(0)
+        out["before"], out["after"] = before, os.sched_getaffinity(tid)
+
+    th = threading.Thread(target=body); th.start(); th.join()
+    assert out["after"] <= out["before"] and len(out["after"]) > 0
+    if not cpulist:
+        assert out["rc"] == 0 and out["after"] == out["before"]          # the platform does not say: nothing changes
+        return
+    local = set()
+    for part in cpulist.split(","):
+        a, _, b = part.partition("-")
+        local.update(range(int(a), int(b or a) + 1))
+    want = out["before"] & local
+    if want and want != out["before"]:
+        assert out["rc"] == 1 and out["after"] == want
+    else:
+        assert out["rc"] == 0 and out["after"] == out["before"]
+    assert os.sched_getaffinity(threading.main_thread().native_id) == out["before"]       # the main thread (same mask before the call) was not touched
