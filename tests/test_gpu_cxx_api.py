@@ -56,8 +56,8 @@ def test_dhs_scheme_flow(params, sched):
                                    ["--threads", "6", "--async", "--devices", "3", "--virtual"],
                                    ["--threads", "1", "--sched"], ["--threads", "1", "--sched", "3", "--devices", "3", "--virtual"],
                                    ["--threads", "1", "--sched", "5", "--no-batching"], ["--threads", "1", "--default"], ["--threads", "1", "--sched", "1"],
-                                   ["--threads", "8", "--zzx-state", "--default"], ["--threads", "1", "--zzx-state", "--default"], ["--threads", "8", "--zzx-state"],
-                                   ["--threads", "4", "--zzx-state", "--default", "--devices", "3", "--virtual"]],
+                                   ["--threads", "8", "--zzx-state", "--default"], ["--threads", "1", "--zzx-state", "--default"], ["--threads", "8", "--zzx-state", "--no-round-checks"],
+                                   ["--threads", "4", "--zzx-state", "--default", "--devices", "3", "--virtual", "--no-round-checks"]],
                          ids=["sync-8-threads", "async-4-threads", "async-1-thread", "async-3-virtual-devices",
                               "scheduled-1-thread", "scheduled-1-thread-3-virtual-devices", "scheduled-1-thread-no-batching",
                               "library-default-1-thread", "scheduled-1-thread-1-worker",
