@@ -248,3 +248,14 @@ def test_worker_threads_run_on_the_cpus_local_to_their_device():
     else:
         assert out["rc"] == 0 and out["after"] == out["before"]
     assert os.sched_getaffinity(threading.main_thread().native_id) == out["before"]       # the main thread (same mask before the call) was not touched
+    # the thread that brings the library up is narrowed only WHILE it does so (CUHE_PIN_CLIENT unset = 2): same mask after the call, whatever it returns
+    seen = {}
+
+    def bring_up():
+        tid = threading.get_native_id()
+        seen["before"] = os.sched_getaffinity(tid)
+        seen["rc"] = capi.lib.cuhe_hip_multi_gpus(1)          # (refused when another test has initialised the library: the placement code runs first either way)
+        seen["after"] = os.sched_getaffinity(tid)
+
+    th = threading.Thread(target=bring_up); th.start(); th.join()
+    assert seen["after"] == seen["before"]
