@@ -523,7 +523,8 @@ void CuPolynomial::hostValueUp(cudaStream_t st) {
 	if (node_) schedDetach();                                  // (attached in the ZZX domain: a recorded copy of a host value)
 	DirectGates here;
 	z2r(st);
-	sched::adoptBlock(device_, rRep_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());     // (idle after z2r's synchronise)
+	// (idle after z2r's synchronise; a block taken in stream order -- asynchronous gates on as well -- stays the library's)
+	if (!asyncGates) sched::adoptBlock(device_, rRep_, deviceAllocatorIsOn() ? poolBlock() : rRepSize());
 }
 void CuPolynomial::r2c(cudaStream_t st) {
 	if (domain_ != 1) { printf("Error: Not in domain RAW!\n"); terminate(); }
