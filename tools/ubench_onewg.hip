@@ -15,6 +15,24 @@ using namespace cuhe;
 #define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP %s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 enum { kPhases = 10 };
+// variant bit 32 (the un-overlapped exchange time): the 32-point stage that FOLLOWS an exchange is done as two 16-point
+// transforms and 16 combining butterflies (the same 80 butterflies), and the waves that do not write in the second round of the exchange
+// run their first 16-point transform -- on the values the first round delivered -- while the other half of the workgroup writes; the
+// writers of round 1 run theirs after the exchange.  TIMING ONLY: the real kernel would have to deliver the even-indexed values in round 0
+// (a permutation of which wave holds which row), the arithmetic here is the same amount of the same instructions on the wrong pairs.
+__device__ __forceinline__ void half16(u64 (&v)[32], int h) {
+    u64 (&sub)[16] = *reinterpret_cast<u64(*)[16]>(&v[16 * h]);
+    dft_regs<16, false>(sub);
+}
+template <int J>
+struct Combine16 {
+    static __device__ __forceinline__ void run(u64 (&v)[32]) {
+        const u64 a = v[J], b = v[16 + J];
+        v[J] = addp(a, b);
+        v[16 + J] = sub_shlp<6 * J>(a, b);
+        if constexpr (J + 1 < 16) Combine16<J + 1>::run(v);
+    }
+};
 // variant bits: 1 = contiguous stores ([even | odd] halves instead of X[2k + h]); 2 = no stores (kept alive by an impossible
 // condition); 4 = no stage-1 table loads (the sample itself stands in); 8 = samples by plain global loads (no LDS-DMA prefetch)
 template <int H, int variant>
@@ -70,6 +88,8 @@ __device__ __forceinline__ void loop(u64 *dst_, const u32 *src, const u64 *TW1, 
                 u64 *wr = lb + lo * 545 + (hi & 15);
 #pragma unroll
                 for (int ka = 0; ka < 32; ++ka) wr[ka * 17] = x[bitrev<32>(ka)];
+            } else if constexpr ((variant & 32) != 0) {
+                if (hh == 1) half16(y, 0);                                               // round-0 writers: compute while round 1 is written
             }
             __syncthreads();
             const u64 *rd = lb + hi * 545 + lo * 17;
@@ -78,7 +98,11 @@ __device__ __forceinline__ void loop(u64 *dst_, const u32 *src, const u64 *TW1, 
             __syncthreads();
         }
         unsigned long long c4 = __builtin_readcyclecounter(); acc[3] += c4 - c3;          // exchange 1 (4 barriers)
-        dft_regs<32, false>(y);
+        if constexpr ((variant & 32) != 0) {
+            if ((hi >> 4) == 1) half16(y, 0);
+            half16(y, 1);
+            Combine16<0>::run(y);
+        } else dft_regs<32, false>(y);
 #pragma unroll
         for (int kb = 1; kb < 32; ++kb) y[bitrev<32>(kb)] = mulp(y[bitrev<32>(kb)], tw2[32 * kb + hi + opaque]);
         unsigned long long c5 = __builtin_readcyclecounter(); acc[4] += c5 - c4;          // stage 2
@@ -88,6 +112,8 @@ __device__ __forceinline__ void loop(u64 *dst_, const u32 *src, const u64 *TW1, 
                 u64 *wr = lb + lo * 17 + (hi & 15);
 #pragma unroll
                 for (int kb = 0; kb < 32; ++kb) wr[kb * 544] = y[bitrev<32>(kb)];
+            } else if constexpr ((variant & 32) != 0) {
+                if (hh == 1) half16(z, 0);
             }
             __syncthreads();
             const u64 *rd = lb + hi * 544 + lo * 17;
@@ -97,7 +123,11 @@ __device__ __forceinline__ void loop(u64 *dst_, const u32 *src, const u64 *TW1, 
         }
         unsigned long long c6 = __builtin_readcyclecounter(); acc[5] += c6 - c5;          // exchange 2 (4 barriers)
         if (dma && item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
-        dft_regs<32, false>(z);
+        if constexpr ((variant & 32) != 0) {
+            if ((hi >> 4) == 1) half16(z, 0);
+            half16(z, 1);
+            Combine16<0>::run(z);
+        } else dft_regs<32, false>(z);
         unsigned long long c7 = __builtin_readcyclecounter(); acc[6] += c7 - c6;          // prefetch issue + stage 3
         if constexpr (variant & 2) {
             if (z[3] == 0x123456789abcdef0ull) dst_[t] = z[5];
@@ -155,7 +185,8 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const char *names[] = {"drain+barrier", "samples->regs", "stage1 dft+tw", "exchange 1", "stage 2", "exchange 2", "prefetch+stage3", "store issue"};
     typedef void (*kern_t)(u64 *, const u32 *, const u64 *, const u64 *, int, unsigned long long *);
-    struct V { int variant; kern_t k; } vs[] = {{0, k_stream<0>}, {1, k_stream<1>}, {2, k_stream<2>}, {16, k_stream<16>}, {17, k_stream<17>}, {0, k_stream<0>}, {16, k_stream<16>}};
+    struct V { int variant; kern_t k; } vs[] = {{1, k_stream<1>}, {33, k_stream<33>}, {2, k_stream<2>}, {34, k_stream<34>}, {1, k_stream<1>}, {33, k_stream<33>}, {2, k_stream<2>}, {34, k_stream<34>}};
+    if (argc > 3) { V all[] = {{0, k_stream<0>}, {1, k_stream<1>}, {2, k_stream<2>}, {16, k_stream<16>}, {17, k_stream<17>}, {0, k_stream<0>}, {16, k_stream<16>}}; (void)all; }
     for (auto &v : vs) {
         const int variant = v.variant;
         HK(hipFuncSetAttribute((const void *)v.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -168,7 +199,7 @@ int main(int argc, char **argv) {
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         const double per = ms / iters * 1e-3 / nbatch;
         printf("variant %2d [%s%s%s%s]: %.4f ms per %d transforms, %.3f M/s, frac %.4f\n", variant, variant & 1 ? "contiguous-stores " : "", variant & 2 ? "no-stores " : "",
-               variant & 4 ? "no-table-loads " : "", variant & 8 ? "plain-loads " : variant & 16 ? "one-code-path " : "", ms / iters, nbatch, 1e-6 / per, 655360.0 / per / 8e12);
+               variant & 4 ? "no-table-loads " : "", variant & 32 ? "split-stage-overlap " : variant & 8 ? "plain-loads " : variant & 16 ? "one-code-path " : "", ms / iters, nbatch, 1e-6 / per, 655360.0 / per / 8e12);
         std::vector<unsigned long long> st(256 * 2 * kPhases);
         HK(hipMemcpy(st.data(), dst_amps, st.size() * 8, hipMemcpyDeviceToHost));
         for (int blk : {0, 8, 100}) for (int wv = 0; wv < 2; ++wv) {
