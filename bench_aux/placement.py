@@ -50,13 +50,27 @@ def gpu_local_cpus(index, base="/sys/bus/pci/devices"):
     return text, cpus
 
 
+ORIGINAL_AFFINITY = None        # what the process was allowed before pin_process_to_gpu narrowed it
+
+
+def restore_original_affinity():
+    """for a child that drives SEVERAL GPUs (preexec_fn): back to everything the process was allowed; its threads place themselves per device"""
+    if ORIGINAL_AFFINITY:
+        try:
+            os.sched_setaffinity(0, ORIGINAL_AFFINITY)
+        except OSError:
+            pass
+
+
 def pin_process_to_gpu(index):
     """Narrow this process (and what it starts afterwards) to the CPUs local to GPU `index`; returns a record for the bench line."""
+    global ORIGINAL_AFFINITY
     text, cpus = gpu_local_cpus(index)
     try:
         allowed = os.sched_getaffinity(0)
     except OSError:
         return {"pinned": False, "reason": "no affinity call"}
+    ORIGINAL_AFFINITY = set(allowed)
     want = allowed & cpus
     if not want or want == allowed:
         return {"pinned": False, "local_cpus": text, "reason": "unknown" if not text else "already local" if want else "no local CPU allowed"}

@@ -7,6 +7,7 @@ import subprocess
 import sys
 import time
 
+from .placement import restore_original_affinity
 from .record import HBM_PEAK_GBS, ROOT
 
 
@@ -21,7 +22,8 @@ def bench_prince(world, single_dev):
         # the later ones no longer pay the first-time hipMalloc of the arrays (profiles/r05_prince_gaps_arrays.txt)
         # (one GPU only: the repeated form of the multi-device client has not run on hardware)
         cmd = [exe, "--no-round-checks", "--async", "--json"] + (["--repeat", "3"] if world == 1 else []) + ["--devices", str(world)] + (["--virtual"] if single_dev and world > 1 else [])
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        # (N > 1: the client's threads drive GPUs on both sockets and place themselves per device -- not inside the mask of rank 0's own GPU)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, preexec_fn=restore_original_affinity if world > 1 else None)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"error": (r.stdout[-300:] + r.stderr[-300:]).strip()}

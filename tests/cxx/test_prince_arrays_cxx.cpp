@@ -132,6 +132,7 @@ struct Machine {
 			std::vector<std::thread> th;
 			for (int t = 0; t < nd; ++t)
 				th.emplace_back([&, t] {
+					cuhe_hip_pin_thread_to_device(t);                       // the thread that drives device t launches from the CPUs local to it (include/cuhe_hip.h)
 					moveTo(*part[t], t);
 					res[t] = units[t]->eval(*part[t], inverse);
 					if (isAsynchronous() && cuhe_hip_stream_sync(t, NULL) != 0) { printf("stream sync failed\n"); exit(2); }

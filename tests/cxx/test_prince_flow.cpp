@@ -79,6 +79,8 @@ struct Pool {
 	}
 	void worker(int t) {
 		int seen = 0;
+		if (ndev > 1) cuhe_hip_pin_thread_to_device(t % ndev);       // several GPUs, possibly on both sockets: a thread launches from the CPUs local to ITS device
+		                                                              // (one device: the client's threads stay where the kernel put them, like an unchanged client's)
 		for (;;) {
 			{ std::unique_lock<std::mutex> lk(m); cvStart.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
 			const int dev = spread ? t % ndev : 0;
