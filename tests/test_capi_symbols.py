@@ -188,3 +188,26 @@ def test_exchange_path_policy_for_every_level_of_config4(capi, golden):
         assert seen >= {1, 2}
         assert lib.cuhe_hip_exchange_path(depth, 2, 0) == -1
     lib.cuhe_hip_reset_parameters()
+
+
+def test_device_local_cpus_without_a_gpu_changes_nothing(capi):
+    """cuhe_hip_device_local_cpus / cuhe_hip_pin_thread_to_device before any HIP call of the process read sysfs only (no compute, no HIP): on a machine
+    without an AMD GPU the list is empty and the calling thread keeps its affinity (include/cuhe_hip.h; the parsing of the lists is the same code the GPU
+    test exercises, and bench_aux/placement.py's Python twin is tested against a sysfs tree in tests/test_bench_record.py)."""
+    import threading
+    buf = C.create_string_buffer(256)
+    assert capi.lib.cuhe_hip_device_local_cpus(0, buf, 256) == 0
+    listed = buf.value.decode()
+    assert capi.lib.cuhe_hip_device_local_cpus(-1, buf, 256) != 0          # a bad device is an error, not a crash
+    out = {}
+
+    def body():
+        tid = threading.get_native_id()
+        out["before"] = os.sched_getaffinity(tid)
+        out["rc"] = capi.lib.cuhe_hip_pin_thread_to_device(0)
+        out["after"] = os.sched_getaffinity(tid)
+
+    th = threading.Thread(target=body); th.start(); th.join()
+    assert out["after"] <= out["before"] and len(out["after"]) > 0
+    if not listed:
+        assert out["rc"] == 0 and out["after"] == out["before"]
