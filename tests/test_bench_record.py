@@ -120,3 +120,31 @@ def test_gpu_local_cpus_from_a_sysfs_tree(tmp_path, monkeypatch):
     assert gpu_local_cpus(0, str(tmp_path))[0] == "64-127,192-255"
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")
     assert gpu_local_cpus(0, str(tmp_path)) == ("", set())
+
+
+def test_bench_process_pins_itself_and_a_multi_gpu_child_gets_everything_back():
+    """bench_aux/placement.py in a process of its own (the affinity of the pytest process is left alone): pin_process_to_gpu narrows the process to the
+    GPU's local CPUs it may use and records it; restore_original_affinity (the preexec hook of the N > 1 PRINCE child, whose threads place
+    themselves per device) gives everything back."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+from bench_aux import placement
+allowed = sorted(os.sched_getaffinity(0))
+if len(allowed) < 2:
+    print("SKIP"); sys.exit(0)
+local = set(allowed[: len(allowed) // 2])
+placement.gpu_local_cpus = lambda index, base=None: (",".join(map(str, sorted(local))), set(local) | {100000})
+rec = placement.pin_process_to_gpu(0)
+assert rec["pinned"] and rec["cpus_allowed"] == len(local) and rec["of"] == len(allowed), rec
+assert os.sched_getaffinity(0) == local
+placement.restore_original_affinity()
+assert os.sched_getaffinity(0) == set(allowed)
+placement.gpu_local_cpus = lambda index, base=None: ("", set())
+assert placement.pin_process_to_gpu(0)["pinned"] is False and os.sched_getaffinity(0) == set(allowed)
+print("OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() in ("OK", "SKIP"), r.stdout + r.stderr
